@@ -1,0 +1,123 @@
+"""ctypes binding of libbbx.so (the C ABI declared in include/bbx.h).
+
+The reference's precedent for this layer is design_matrix/mkl_matvec.py:1-56
+(ctypes -> MKL).  There is NO CPU fallback: if the HIP library is missing or no
+MI355X is visible, the product path raises.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, byref, c_char_p, c_double, c_int, c_int32,
+                    c_int64, c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get(
+    "BBX_LIBRARY", os.path.join(os.path.dirname(_HERE), "libbbx.so"))
+
+FORMAT_AUTO, FORMAT_CSR, FORMAT_TILED = 0, 1, 2
+F64, F32 = 0, 1
+MODEL_LINEAR, MODEL_LOGIT = 0, 1
+
+_lib = None
+
+
+class BbxError(RuntimeError):
+    """A libbbx call returned a negative status."""
+
+
+def _declare(lib):
+    dp = POINTER(c_double)
+    ip = POINTER(c_int32)
+    hp = c_void_p
+    sigs = {
+        "bbx_version": ([], c_int),
+        "bbx_last_error": ([], c_char_p),
+        "bbx_device_count": ([POINTER(c_int)], c_int),
+        "bbx_design_create_csr": (
+            [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+             c_int, c_int, c_int, POINTER(hp)], c_int),
+        "bbx_design_create_csr_dev": (
+            [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+             c_int, c_int, c_int, POINTER(hp)], c_int),
+        "bbx_design_create_dense": (
+            [c_int64, c_int64, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+             POINTER(hp)], c_int),
+        "bbx_design_create_dense_dev": (
+            [c_int64, c_int64, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+             POINTER(hp)], c_int),
+        "bbx_design_destroy": ([hp], c_int),
+        "bbx_design_shape": ([hp, POINTER(c_int64), POINTER(c_int64)], c_int),
+        "bbx_design_nnz": ([hp, POINTER(c_int64)], c_int),
+        "bbx_design_is_sparse": ([hp, POINTER(c_int)], c_int),
+        "bbx_design_format": ([hp, POINTER(c_int)], c_int),
+        "bbx_design_storage_bytes": ([hp, POINTER(c_int64)], c_int),
+        "bbx_design_matvec_bytes": (
+            [hp, POINTER(c_int64), POINTER(c_int64)], c_int),
+        "bbx_design_dot": ([hp, c_void_p, c_void_p], c_int),
+        "bbx_design_tdot": ([hp, c_void_p, c_void_p], c_int),
+        "bbx_design_dot_dev": ([hp, c_void_p, c_void_p], c_int),
+        "bbx_design_tdot_dev": ([hp, c_void_p, c_void_p], c_int),
+        "bbx_design_stream": ([hp, POINTER(c_void_p)], c_int),
+        "bbx_design_synchronize": ([hp], c_int),
+        "bbx_cg_sample": (
+            [hp, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+             c_void_p, c_void_p, c_uint64, c_int, c_double, c_void_p,
+             POINTER(c_int), POINTER(c_int)], c_int),
+        "bbx_cg_sample_dev": (
+            [hp, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+             c_void_p, c_void_p, c_uint64, c_int, c_double, c_void_p,
+             POINTER(c_int), POINTER(c_int)], c_int),
+        "bbx_design_matvec_count": (
+            [hp, POINTER(c_int64), POINTER(c_int64)], c_int),
+        "bbx_design_reset_matvec_count": ([hp], c_int),
+        "bbx_design_set_timing": ([hp, c_int], c_int),
+        "bbx_design_get_timing": (
+            [hp, c_int, POINTER(c_int64), POINTER(c_double)], c_int),
+        "bbx_design_reset_timing": ([hp], c_int),
+    }
+    for name, (argtypes, restype) in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return sigs
+
+
+EXPORTED_SYMBOLS = None
+
+
+def load():
+    """Loads libbbx.so once; raises if it has not been built."""
+    global _lib, EXPORTED_SYMBOLS
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BbxError(
+                "libbbx.so not found at %s: build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C bayes-bridge_amd/csrc`. There is no CPU fallback."
+                % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        EXPORTED_SYMBOLS = sorted(_declare(lib))
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().bbx_last_error().decode("utf-8", "replace")
+
+
+def check(status):
+    """Negative status -> exception; non-negative is returned unchanged."""
+    if status < 0:
+        raise BbxError("libbbx status %d: %s" % (status, last_error()))
+    return status
+
+
+def device_count():
+    n = c_int(0)
+    check(load().bbx_device_count(byref(n)))
+    return n.value
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise BbxError(
+            "no HIP device visible: the MI355X path has no CPU fallback")

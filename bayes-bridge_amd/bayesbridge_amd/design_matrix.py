@@ -1,0 +1,297 @@
+"""Design-matrix operators backed by libbbx.so.
+
+Mirror of the reference's duck-typed operator interface
+(design_matrix/abstract_matrix.py:14-77, sparse_matrix.py:18-129,
+dense_matrix.py:7-52): same attribute names (`use_cupy`, `intercept_added`,
+`centered`), same properties (`shape`, `is_sparse`, `nnz`, `n_matvec`) and the
+same methods (`dot`, `Tdot`, `get_dot_count`, `reset_matvec_count`,
+`memoize_dot`), so an object of this module drops in wherever the reference
+uses SparseDesignMatrix / DenseDesignMatrix on the 'cg' path.  The new
+dispatch attribute is `use_hip` (the reference's seam is `use_cupy`,
+sparse_matrix.py:35).
+"""
+import ctypes
+import warnings
+from ctypes import byref, c_double, c_int, c_int64, c_void_p
+
+import numpy as np
+import scipy.sparse as sparse
+
+from . import _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+def remove_intercept_indicator(X):
+    """Drops zero-variance columns (abstract_matrix.py:93-107)."""
+    if sparse.issparse(X):
+        col_variance = np.squeeze(np.array(
+            X.power(2).mean(axis=0) - np.power(X.mean(axis=0), 2)))
+    else:
+        col_variance = np.var(X, axis=0)
+    has_zero_variance = (col_variance < X.shape[0] * 2 ** -52)
+    if np.any(has_zero_variance):
+        warnings.warn(
+            "Intercept column (or numerically indistinguishable from "
+            "such) detected. Do not add intercept manually. Removing....")
+        X = X[:, np.logical_not(has_zero_variance)]
+    return X
+
+
+class HipDesignMatrix():
+    """Common part: handle ownership, counters, dot/Tdot through the C ABI."""
+
+    use_cupy = False
+    use_hip = True
+
+    def __init__(self):
+        self._h = c_void_p()
+        self._lib = _lib.load()
+        self.memoized = False
+        self.X_dot_v = None
+        self.v_prev = None
+        self._count_offset = [0, 0]
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self._lib.bbx_design_destroy(h)
+            except Exception:
+                pass
+            self._h = c_void_p()
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def shape(self):
+        n, P = c_int64(), c_int64()
+        _lib.check(self._lib.bbx_design_shape(self._h, byref(n), byref(P)))
+        return int(n.value), int(P.value)
+
+    @property
+    def nnz(self):
+        v = c_int64()
+        _lib.check(self._lib.bbx_design_nnz(self._h, byref(v)))
+        return int(v.value)
+
+    @property
+    def storage_format(self):
+        v = c_int()
+        _lib.check(self._lib.bbx_design_format(self._h, byref(v)))
+        return {0: "dense", 1: "csr", 2: "tiled"}[v.value]
+
+    @property
+    def storage_bytes(self):
+        v = c_int64()
+        _lib.check(self._lib.bbx_design_storage_bytes(self._h, byref(v)))
+        return int(v.value)
+
+    @property
+    def matvec_bytes(self):
+        """Algorithmic HBM bytes of (one dot, one Tdot)."""
+        a, b = c_int64(), c_int64()
+        _lib.check(self._lib.bbx_design_matvec_bytes(self._h, byref(a),
+                                                      byref(b)))
+        return int(a.value), int(b.value)
+
+    # -- the operator -------------------------------------------------------
+    def dot(self, v):
+        """X~ v (sparse_matrix.py:68-101, dense_matrix.py:37-48)."""
+        if self.memoized:
+            if np.all(self.v_prev == v):
+                return self.X_dot_v
+            self.v_prev = v.copy()
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        n, P = self.shape
+        if v.shape != (P,):
+            raise ValueError("dot expects a vector of length %d" % P)
+        out = np.empty(n, dtype=np.float64)
+        _lib.check(self._lib.bbx_design_dot(self._h, _ptr(v), _ptr(out)))
+        if self.memoized:
+            self.X_dot_v = out
+        return out
+
+    def Tdot(self, w):
+        """X~^T w (sparse_matrix.py:103-129, dense_matrix.py:50-52)."""
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        n, P = self.shape
+        if w.shape != (n,):
+            raise ValueError("Tdot expects a vector of length %d" % n)
+        out = np.empty(P, dtype=np.float64)
+        _lib.check(self._lib.bbx_design_tdot(self._h, _ptr(w), _ptr(out)))
+        return out
+
+    def memoize_dot(self, flag=True):
+        """abstract_matrix.py:41-47."""
+        self.memoized = flag
+        if self.v_prev is None:
+            self.v_prev = np.full(self.shape[1], float('nan'))
+        if not flag:
+            self.X_dot_v = None
+            self.v_prev = None
+
+    # -- counters (abstract_matrix.py:61-72) --------------------------------
+    def get_dot_count(self):
+        a, b = c_int64(), c_int64()
+        _lib.check(self._lib.bbx_design_matvec_count(self._h, byref(a),
+                                                      byref(b)))
+        return (int(a.value) + self._count_offset[0],
+                int(b.value) + self._count_offset[1])
+
+    @property
+    def dot_count(self):
+        return self.get_dot_count()[0]
+
+    @property
+    def Tdot_count(self):
+        return self.get_dot_count()[1]
+
+    @property
+    def n_matvec(self):
+        return sum(self.get_dot_count())
+
+    def reset_matvec_count(self, count=0):
+        if not hasattr(count, "__len__"):
+            count = 2 * [count]
+        _lib.check(self._lib.bbx_design_reset_matvec_count(self._h))
+        self._count_offset = [int(count[0]), int(count[1])]
+
+    # -- profiling ----------------------------------------------------------
+    def set_timing(self, enabled=True):
+        _lib.check(self._lib.bbx_design_set_timing(self._h, int(enabled)))
+
+    def reset_timing(self):
+        _lib.check(self._lib.bbx_design_reset_timing(self._h))
+
+    def get_timing(self):
+        """{'dot': (launches, total_ms), 'tdot': (...)} from HIP events."""
+        res = {}
+        for which, name in ((0, "dot"), (1, "tdot")):
+            cnt, ms = c_int64(), c_double()
+            _lib.check(self._lib.bbx_design_get_timing(
+                self._h, which, byref(cnt), byref(ms)))
+            res[name] = (int(cnt.value), float(ms.value))
+        return res
+
+    def synchronize(self):
+        _lib.check(self._lib.bbx_design_synchronize(self._h))
+
+    def compute_fisher_info(self, weight, diag_only=False):
+        raise NotImplementedError(
+            "compute_fisher_info belongs to the 'cholesky' sampler, which is "
+            "outside the CG hot path this backend implements.")
+
+    def compute_transposed_fisher_info(self, weight, include_intrcpt=False):
+        raise NotImplementedError(
+            "outside the CG hot path this backend implements.")
+
+
+class HipSparseDesignMatrix(HipDesignMatrix):
+    """Counterpart of SparseDesignMatrix (sparse_matrix.py:18-49)."""
+
+    def __init__(self, X, center_predictor=False, add_intercept=True,
+                 copy_array=False, dot_format='csr', Tdot_format='csr',
+                 device=0, storage='auto'):
+        super().__init__()
+        if dot_format == 'csc' or Tdot_format == 'csc':
+            raise NotImplementedError(
+                "Current dot operations are only implemented for the CSR "
+                "format.")  # sparse_matrix.py:31-34
+        if not sparse.issparse(X):
+            raise TypeError("X must be a scipy sparse matrix")
+        _lib.require_gpu()
+        self.centered = center_predictor
+        self.intercept_added = add_intercept
+        X = remove_intercept_indicator(X)
+        X = X.tocsr()
+        if copy_array:
+            X = X.copy()
+        X.sort_indices()
+        n, p = X.shape
+        if center_predictor:
+            self.column_offset = np.ascontiguousarray(
+                np.squeeze(np.array(X.mean(axis=0))), dtype=np.float64
+            ).reshape(p)
+            offset = self.column_offset
+        else:
+            self.column_offset = np.zeros(p)
+            offset = None
+        indptr = np.ascontiguousarray(X.indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(X.indices, dtype=np.int32)
+        data = np.ascontiguousarray(X.data, dtype=np.float64)
+        fmt = {'auto': _lib.FORMAT_AUTO, 'csr': _lib.FORMAT_CSR,
+               'tiled': _lib.FORMAT_TILED}[storage]
+        _lib.check(self._lib.bbx_design_create_csr(
+            n, p, X.nnz, _ptr(indptr), _ptr(indices), _ptr(data),
+            _ptr(offset), int(bool(add_intercept)), int(device), fmt,
+            byref(self._h)))
+
+    @classmethod
+    def from_device_csr(cls, n, p, nnz, indptr_ptr, indices_ptr, data_ptr=None,
+                        offset_ptr=None, add_intercept=True, device=0,
+                        storage='auto'):
+        """Adopts CSR arrays that already live in HBM (raw device pointers,
+        e.g. torch tensors' data_ptr()); the arrays are copied."""
+        self = cls.__new__(cls)
+        HipDesignMatrix.__init__(self)
+        _lib.require_gpu()
+        self.centered = offset_ptr is not None
+        self.intercept_added = add_intercept
+        self.column_offset = None
+        fmt = {'auto': _lib.FORMAT_AUTO, 'csr': _lib.FORMAT_CSR,
+               'tiled': _lib.FORMAT_TILED}[storage]
+        _lib.check(self._lib.bbx_design_create_csr_dev(
+            n, p, nnz, c_void_p(indptr_ptr), c_void_p(indices_ptr),
+            c_void_p(data_ptr) if data_ptr else None,
+            c_void_p(offset_ptr) if offset_ptr else None,
+            int(bool(add_intercept)), int(device), fmt, byref(self._h)))
+        return self
+
+    @property
+    def is_sparse(self):
+        return True
+
+
+class HipDenseDesignMatrix(HipDesignMatrix):
+    """Counterpart of DenseDesignMatrix (dense_matrix.py:7-27).  Unlike the
+    reference, the caller's array is never modified (the reference centres it
+    in place unless copy_array=True, dense_matrix.py:17-22)."""
+
+    def __init__(self, X, center_predictor=False, add_intercept=True,
+                 copy_array=False, device=0, storage_dtype='float64'):
+        super().__init__()
+        _lib.require_gpu()
+        X = np.asarray(X)
+        X = remove_intercept_indicator(X)
+        if X.dtype == np.float32:
+            in_dtype = _lib.F32
+        else:
+            X = np.asarray(X, dtype=np.float64)
+            in_dtype = _lib.F64
+        X = np.ascontiguousarray(X)
+        n, p = X.shape
+        self.centered = center_predictor
+        self.intercept_added = add_intercept
+        offset = None
+        if center_predictor:
+            offset = np.ascontiguousarray(
+                np.mean(X, axis=0, dtype=np.float64), dtype=np.float64)
+        self.column_offset = offset
+        st = {'float64': _lib.F64, 'float32': _lib.F32}[storage_dtype]
+        _lib.check(self._lib.bbx_design_create_dense(
+            n, p, _ptr(X), in_dtype, st, _ptr(offset),
+            int(bool(add_intercept)), int(device), byref(self._h)))
+
+    @property
+    def is_sparse(self):
+        return False
+
+    @property
+    def nnz(self):
+        n, P = self.shape
+        return n * P

@@ -1,0 +1,547 @@
+// extern "C" entry points of libbbx.so (declared in include/bbx.h): handle
+// life cycle, host-pointer wrappers, format dispatch, kernel timers.
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "common.hpp"
+
+namespace bbx {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+int DevMem::alloc(size_t nbytes) {
+  release();
+  if (nbytes == 0) nbytes = 8;
+  hipError_t e = hipMalloc(&ptr, nbytes);
+  if (e != hipSuccess) {
+    ptr = nullptr;
+    return fail(BBX_ERR_HIP, std::string("hipMalloc(") +
+                                 std::to_string(nbytes) +
+                                 "): " + hipGetErrorString(e));
+  }
+  bytes = nbytes;
+  return BBX_OK;
+}
+
+void DevMem::release() {
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  bytes = 0;
+}
+
+// ------------------------------------------------------------------- timers
+
+int timer_begin(bbx_design* h, int which) {
+  if (!h->timer.enabled) return BBX_OK;
+  KernelTimer::Pair pr;
+  if (!h->timer.pool.empty()) {
+    pr = h->timer.pool.back();
+    h->timer.pool.pop_back();
+  } else {
+    BBX_HIP(hipEventCreate(&pr.a));
+    BBX_HIP(hipEventCreate(&pr.b));
+  }
+  BBX_HIP(hipEventRecord(pr.a, h->stream));
+  h->timer.pending[which].push_back(pr);
+  return BBX_OK;
+}
+
+int timer_end(bbx_design* h, int which) {
+  if (!h->timer.enabled) return BBX_OK;
+  BBX_HIP(hipEventRecord(h->timer.pending[which].back().b, h->stream));
+  return BBX_OK;
+}
+
+static int timer_collect(bbx_design* h) {
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  for (int which = 0; which < 2; ++which) {
+    for (auto& pr : h->timer.pending[which]) {
+      float ms = 0.f;
+      BBX_HIP(hipEventElapsedTime(&ms, pr.a, pr.b));
+      h->timer.total_ms[which] += (double)ms;
+      h->timer.n_launch[which] += 1;
+      h->timer.pool.push_back(pr);
+    }
+    h->timer.pending[which].clear();
+  }
+  return BBX_OK;
+}
+
+// ----------------------------------------------------------------- dispatch
+
+int launch_dot_dense(bbx_design* h, const double* d_v,
+                     const double* d_rowscale, double* d_t);
+int launch_tdot_dense(bbx_design* h, const double* d_w,
+                      const double* d_sumw_part, const TdotEpilogue& ep,
+                      double* d_out);
+int launch_dot_tiled(bbx_design* h, const double* d_v,
+                     const double* d_rowscale, double* d_t);
+int launch_tdot_tiled(bbx_design* h, const double* d_w,
+                      const double* d_sumw_part, const TdotEpilogue& ep,
+                      double* d_out);
+
+int launch_dot(bbx_design* h, const double* d_v, const double* d_rowscale,
+               double* d_t, double* d_sum_part) {
+  h->n_dot += 1;
+  if (!h->sparse) {
+    BBX_TRY(launch_dot_dense(h, d_v, d_rowscale, d_t));
+  } else if (h->format == BBX_FORMAT_TILED) {
+    BBX_TRY(launch_dot_tiled(h, d_v, d_rowscale, d_t));
+  } else {
+    BBX_TRY(launch_dot_csr(h, d_v, d_rowscale, d_t));
+  }
+  if (d_sum_part) BBX_TRY(launch_sum_n(h, d_t, h->n, d_sum_part));
+  return BBX_OK;
+}
+
+int launch_tdot(bbx_design* h, const double* d_w, const double* d_sumw_part,
+                const TdotEpilogue& ep, double* d_out) {
+  h->n_tdot += 1;
+  if (!h->sparse) return launch_tdot_dense(h, d_w, d_sumw_part, ep, d_out);
+  if (h->format == BBX_FORMAT_TILED)
+    return launch_tdot_tiled(h, d_w, d_sumw_part, ep, d_out);
+  return launch_tdot_csr(h, d_w, d_sumw_part, ep, d_out);
+}
+
+int design_alloc_work(bbx_design* h) {
+  for (auto& m : h->w_n) BBX_TRY(m.alloc(sizeof(double) * (size_t)h->n));
+  for (auto& m : h->w_P) BBX_TRY(m.alloc(sizeof(double) * (size_t)h->P));
+  BBX_TRY(h->part.alloc(sizeof(double) * NPART * PS_COUNT));
+  BBX_HIP(hipMemset(h->part.ptr, 0, sizeof(double) * NPART * PS_COUNT));
+  BBX_TRY(h->cg_state.alloc(sizeof(CGState)));
+  BBX_TRY(h->stage_n.alloc(sizeof(double) * (size_t)h->n * 2));
+  BBX_TRY(h->stage_P.alloc(sizeof(double) * (size_t)h->P * 6));
+  BBX_HIP(hipHostMalloc(&h->host_pinned, 256, hipHostMallocDefault));
+  return BBX_OK;
+}
+
+static int open_device(int device, bbx_design* h) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(BBX_ERR_NODEVICE,
+                "no HIP device visible (libbbx has no CPU fallback)");
+  if (device < 0 || device >= count)
+    return fail(BBX_ERR_INVALID, "device index out of range");
+  BBX_HIP(hipSetDevice(device));
+  h->device = device;
+  BBX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  return BBX_OK;
+}
+
+static int check_csr_args(int64_t n, int64_t p, int64_t nnz,
+                          const void* indptr, const void* indices,
+                          bbx_design** out) {
+  if (!out) return fail(BBX_ERR_INVALID, "out handle pointer is NULL");
+  *out = nullptr;
+  if (n <= 0 || p <= 0 || nnz < 0)
+    return fail(BBX_ERR_INVALID, "n and p must be positive, nnz >= 0");
+  if (nnz >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31) - 1 ||
+      p >= ((int64_t)1 << 31) - 1)
+    return fail(BBX_ERR_INVALID, "sizes must fit int32 indices (SciPy CSR)");
+  if (!indptr || (nnz > 0 && !indices))
+    return fail(BBX_ERR_INVALID, "indptr/indices must not be NULL");
+  return BBX_OK;
+}
+
+__global__ void all_ones_kernel(int64_t nnz, const double* __restrict__ data,
+                                int* __restrict__ flag) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz;
+       i += (int64_t)gridDim.x * blockDim.x)
+    if (data[i] != 1.0) *flag = 0;
+}
+
+int build_tiled(bbx_design* h);
+
+// Common tail of the two CSR constructors: the device CSR arrays are in place.
+static int finish_csr(bbx_design* h, int format) {
+  // Values that are all exactly 1.0 are dropped (binary designs,
+  // simulate_data.py:100-117): the kernels then read indices only.
+  if (h->data.ptr && h->nnz > 0) {
+    int* d_flag = static_cast<int*>(h->cg_state.ptr);  // scratch
+    int one = 1;
+    BBX_HIP(hipMemcpy(d_flag, &one, sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(all_ones_kernel, dim3(2048), dim3(256), 0, h->stream,
+                       h->nnz, h->data.as<double>(), d_flag);
+    BBX_HIP(hipGetLastError());
+    BBX_HIP(hipStreamSynchronize(h->stream));
+    int flag = 0;
+    BBX_HIP(hipMemcpy(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) {
+      h->binary = true;
+      h->data.release();
+    }
+  } else {
+    h->binary = true;
+  }
+  BBX_TRY(build_transpose_csr(h));
+  if (format == BBX_FORMAT_AUTO) format = BBX_FORMAT_CSR;
+  h->format = format;
+  if (format == BBX_FORMAT_TILED) BBX_TRY(build_tiled(h));
+  return BBX_OK;
+}
+
+static int create_csr_common(int64_t n, int64_t p, int64_t nnz,
+                             const int32_t* indptr, const int32_t* indices,
+                             const double* data, const double* col_offset,
+                             int add_intercept, int device, int format,
+                             bool from_device, bbx_design** out) {
+  BBX_TRY(check_csr_args(n, p, nnz, indptr, indices, out));
+  if (format != BBX_FORMAT_AUTO && format != BBX_FORMAT_CSR &&
+      format != BBX_FORMAT_TILED)
+    return fail(BBX_ERR_INVALID, "unknown storage format");
+  bbx_design* h = new (std::nothrow) bbx_design();
+  if (!h) return fail(BBX_ERR_INVALID, "out of host memory");
+  int st = open_device(device, h);
+  if (st < 0) {
+    delete h;
+    return st;
+  }
+  h->n = n;
+  h->p = p;
+  h->intercept = add_intercept ? 1 : 0;
+  h->P = p + h->intercept;
+  h->nnz = nnz;
+  h->sparse = true;
+  h->centred = (col_offset != nullptr);
+  const hipMemcpyKind kind =
+      from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  auto body = [&]() -> int {
+    BBX_TRY(design_alloc_work(h));
+    BBX_TRY(h->indptr.alloc(sizeof(int32_t) * (size_t)(n + 1)));
+    BBX_TRY(h->indices.alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+    BBX_HIP(hipMemcpy(h->indptr.ptr, indptr, sizeof(int32_t) * (size_t)(n + 1),
+                      kind));
+    if (nnz > 0)
+      BBX_HIP(hipMemcpy(h->indices.ptr, indices,
+                        sizeof(int32_t) * (size_t)nnz, kind));
+    if (data && nnz > 0) {
+      BBX_TRY(h->data.alloc(sizeof(double) * (size_t)nnz));
+      BBX_HIP(hipMemcpy(h->data.ptr, data, sizeof(double) * (size_t)nnz, kind));
+    }
+    BBX_TRY(h->offset.alloc(sizeof(double) * (size_t)p));
+    if (col_offset)
+      BBX_HIP(hipMemcpy(h->offset.ptr, col_offset, sizeof(double) * (size_t)p,
+                        kind));
+    else
+      BBX_HIP(hipMemset(h->offset.ptr, 0, sizeof(double) * (size_t)p));
+    if (!from_device) {
+      // validate the host CSR structure (cheap, catches wrong dtypes early)
+      if (indptr[0] != 0 || indptr[n] != nnz)
+        return fail(BBX_ERR_INVALID, "indptr[0] != 0 or indptr[n] != nnz");
+      for (int64_t i = 0; i < n; ++i)
+        if (indptr[i + 1] < indptr[i])
+          return fail(BBX_ERR_INVALID, "indptr is not non-decreasing");
+      for (int64_t k = 0; k < nnz; ++k)
+        if (indices[k] < 0 || indices[k] >= p)
+          return fail(BBX_ERR_INVALID, "column index out of range");
+    }
+    BBX_TRY(finish_csr(h, format));
+    return BBX_OK;
+  };
+  st = body();
+  if (st < 0) {
+    bbx_design_destroy(h);
+    return st;
+  }
+  *out = h;
+  return BBX_OK;
+}
+
+static int check_handle(const bbx_design* h) {
+  if (!h) return fail(BBX_ERR_INVALID, "design handle is NULL");
+  return BBX_OK;
+}
+
+}  // namespace bbx
+
+using namespace bbx;
+
+extern "C" {
+
+int bbx_version(void) { return BBX_VERSION; }
+
+const char* bbx_last_error(void) { return g_last_error.c_str(); }
+
+int bbx_device_count(int* count) {
+  if (!count) return fail(BBX_ERR_INVALID, "count is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) c = 0;
+  *count = c;
+  return BBX_OK;
+}
+
+int bbx_design_create_csr(int64_t n, int64_t p, int64_t nnz,
+                          const int32_t* indptr, const int32_t* indices,
+                          const double* data, const double* col_offset,
+                          int add_intercept, int device, int format,
+                          bbx_design** out) {
+  return create_csr_common(n, p, nnz, indptr, indices, data, col_offset,
+                           add_intercept, device, format, false, out);
+}
+
+int bbx_design_create_csr_dev(int64_t n, int64_t p, int64_t nnz,
+                              const int32_t* d_indptr,
+                              const int32_t* d_indices, const double* d_data,
+                              const double* d_col_offset, int add_intercept,
+                              int device, int format, bbx_design** out) {
+  return create_csr_common(n, p, nnz, d_indptr, d_indices, d_data,
+                           d_col_offset, add_intercept, device, format, true,
+                           out);
+}
+
+int bbx_design_destroy(bbx_design* h) {
+  if (!h) return BBX_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (int which = 0; which < 2; ++which)
+    for (auto& pr : h->timer.pending[which]) h->timer.pool.push_back(pr);
+  for (auto& pr : h->timer.pool) {
+    (void)hipEventDestroy(pr.a);
+    (void)hipEventDestroy(pr.b);
+  }
+  if (h->host_pinned) (void)hipHostFree(h->host_pinned);
+  hipStream_t s = h->stream;
+  delete h;  // frees every DevMem
+  if (s) (void)hipStreamDestroy(s);
+  return BBX_OK;
+}
+
+int bbx_design_shape(const bbx_design* h, int64_t* n, int64_t* P) {
+  BBX_TRY(check_handle(h));
+  if (n) *n = h->n;
+  if (P) *P = h->P;
+  return BBX_OK;
+}
+
+int bbx_design_nnz(const bbx_design* h, int64_t* nnz) {
+  BBX_TRY(check_handle(h));
+  if (nnz) *nnz = h->nnz;
+  return BBX_OK;
+}
+
+int bbx_design_is_sparse(const bbx_design* h, int* flag) {
+  BBX_TRY(check_handle(h));
+  if (flag) *flag = h->sparse ? 1 : 0;
+  return BBX_OK;
+}
+
+int bbx_design_format(const bbx_design* h, int* format) {
+  BBX_TRY(check_handle(h));
+  if (format) *format = h->sparse ? h->format : 0;
+  return BBX_OK;
+}
+
+int bbx_design_stream(bbx_design* h, void** stream) {
+  BBX_TRY(check_handle(h));
+  if (stream) *stream = (void*)h->stream;
+  return BBX_OK;
+}
+
+int bbx_design_synchronize(bbx_design* h) {
+  BBX_TRY(check_handle(h));
+  BBX_HIP(hipSetDevice(h->device));
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  return BBX_OK;
+}
+
+int bbx_design_dot_dev(bbx_design* h, const double* d_v, double* d_out) {
+  BBX_TRY(check_handle(h));
+  if (!d_v || !d_out) return fail(BBX_ERR_INVALID, "NULL vector");
+  BBX_HIP(hipSetDevice(h->device));
+  BBX_TRY(launch_prep_v(h, d_v, nullptr, nullptr, part_slot(h, PS_C)));
+  return launch_dot(h, d_v, nullptr, d_out, nullptr);
+}
+
+int bbx_design_tdot_dev(bbx_design* h, const double* d_w, double* d_out) {
+  BBX_TRY(check_handle(h));
+  if (!d_w || !d_out) return fail(BBX_ERR_INVALID, "NULL vector");
+  BBX_HIP(hipSetDevice(h->device));
+  BBX_TRY(launch_sum_n(h, d_w, h->n, part_slot(h, PS_SUMW)));
+  TdotEpilogue ep;
+  return launch_tdot(h, d_w, part_slot(h, PS_SUMW), ep, d_out);
+}
+
+int bbx_design_dot(bbx_design* h, const double* v, double* out) {
+  BBX_TRY(check_handle(h));
+  if (!v || !out) return fail(BBX_ERR_INVALID, "NULL vector");
+  BBX_HIP(hipSetDevice(h->device));
+  double* d_v = h->stage_P.as<double>();
+  double* d_o = h->stage_n.as<double>();
+  BBX_HIP(hipMemcpyAsync(d_v, v, sizeof(double) * (size_t)h->P,
+                         hipMemcpyHostToDevice, h->stream));
+  BBX_TRY(bbx_design_dot_dev(h, d_v, d_o));
+  BBX_HIP(hipMemcpyAsync(out, d_o, sizeof(double) * (size_t)h->n,
+                         hipMemcpyDeviceToHost, h->stream));
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  return BBX_OK;
+}
+
+int bbx_design_tdot(bbx_design* h, const double* w, double* out) {
+  BBX_TRY(check_handle(h));
+  if (!w || !out) return fail(BBX_ERR_INVALID, "NULL vector");
+  BBX_HIP(hipSetDevice(h->device));
+  double* d_w = h->stage_n.as<double>();
+  double* d_o = h->stage_P.as<double>();
+  BBX_HIP(hipMemcpyAsync(d_w, w, sizeof(double) * (size_t)h->n,
+                         hipMemcpyHostToDevice, h->stream));
+  BBX_TRY(bbx_design_tdot_dev(h, d_w, d_o));
+  BBX_HIP(hipMemcpyAsync(out, d_o, sizeof(double) * (size_t)h->P,
+                         hipMemcpyDeviceToHost, h->stream));
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  return BBX_OK;
+}
+
+int bbx_cg_sample_dev(bbx_design* h, const double* d_obs_prec,
+                      const double* d_prior_prec_sqrt, const double* d_z,
+                      const double* d_x0, const double* d_precond_sd,
+                      int n_unshrunk, const double* d_randn_n,
+                      const double* d_randn_P, uint64_t seed, int maxiter,
+                      double atol, double* d_coef_out, int* n_iter_out,
+                      int* info_out) {
+  BBX_TRY(check_handle(h));
+  if (!d_obs_prec || !d_prior_prec_sqrt || !d_z || !d_x0 || !d_precond_sd ||
+      !d_coef_out)
+    return fail(BBX_ERR_INVALID, "NULL array argument");
+  BBX_HIP(hipSetDevice(h->device));
+  return cg_sample_device(h, d_obs_prec, d_prior_prec_sqrt, d_z, d_x0,
+                          d_precond_sd, n_unshrunk, d_randn_n, d_randn_P, seed,
+                          maxiter, atol, d_coef_out, n_iter_out, info_out);
+}
+
+int bbx_cg_sample(bbx_design* h, const double* obs_prec,
+                  const double* prior_prec_sqrt, const double* z,
+                  const double* x0, const double* precond_sd, int n_unshrunk,
+                  const double* randn_n, const double* randn_P, uint64_t seed,
+                  int maxiter, double atol, double* coef_out, int* n_iter_out,
+                  int* info_out) {
+  BBX_TRY(check_handle(h));
+  if (!obs_prec || !prior_prec_sqrt || !z || !x0 || !precond_sd || !coef_out)
+    return fail(BBX_ERR_INVALID, "NULL array argument");
+  if ((randn_n == nullptr) != (randn_P == nullptr))
+    return fail(BBX_ERR_INVALID,
+                "randn_n and randn_P must both be given or both be NULL");
+  BBX_HIP(hipSetDevice(h->device));
+  const size_t nb = sizeof(double) * (size_t)h->n;
+  const size_t Pb = sizeof(double) * (size_t)h->P;
+  double* sn = h->stage_n.as<double>();
+  double* sP = h->stage_P.as<double>();
+  double* d_omega = sn;
+  double* d_eta1 = sn + h->n;
+  double* d_phi = sP;
+  double* d_z = sP + h->P;
+  double* d_x0 = sP + 2 * h->P;
+  double* d_sd = sP + 3 * h->P;
+  double* d_eta2 = sP + 4 * h->P;
+  double* d_coef = sP + 5 * h->P;
+  BBX_HIP(hipMemcpyAsync(d_omega, obs_prec, nb, hipMemcpyHostToDevice,
+                         h->stream));
+  BBX_HIP(hipMemcpyAsync(d_phi, prior_prec_sqrt, Pb, hipMemcpyHostToDevice,
+                         h->stream));
+  BBX_HIP(hipMemcpyAsync(d_z, z, Pb, hipMemcpyHostToDevice, h->stream));
+  BBX_HIP(hipMemcpyAsync(d_x0, x0, Pb, hipMemcpyHostToDevice, h->stream));
+  BBX_HIP(hipMemcpyAsync(d_sd, precond_sd, Pb, hipMemcpyHostToDevice,
+                         h->stream));
+  if (randn_n) {
+    BBX_HIP(hipMemcpyAsync(d_eta1, randn_n, nb, hipMemcpyHostToDevice,
+                           h->stream));
+    BBX_HIP(hipMemcpyAsync(d_eta2, randn_P, Pb, hipMemcpyHostToDevice,
+                           h->stream));
+  }
+  // pageable host memory: the copies above must not outlive the call
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  int st = cg_sample_device(h, d_omega, d_phi, d_z, d_x0, d_sd, n_unshrunk,
+                            randn_n ? d_eta1 : nullptr,
+                            randn_n ? d_eta2 : nullptr, seed, maxiter, atol,
+                            d_coef, n_iter_out, info_out);
+  if (st < 0) return st;
+  BBX_HIP(hipMemcpyAsync(coef_out, d_coef, Pb, hipMemcpyDeviceToHost,
+                         h->stream));
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  return st;
+}
+
+int bbx_design_matvec_count(const bbx_design* h, int64_t* n_dot,
+                            int64_t* n_tdot) {
+  BBX_TRY(check_handle(h));
+  if (n_dot) *n_dot = h->n_dot;
+  if (n_tdot) *n_tdot = h->n_tdot;
+  return BBX_OK;
+}
+
+int bbx_design_reset_matvec_count(bbx_design* h) {
+  BBX_TRY(check_handle(h));
+  h->n_dot = 0;
+  h->n_tdot = 0;
+  return BBX_OK;
+}
+
+int bbx_design_set_timing(bbx_design* h, int enabled) {
+  BBX_TRY(check_handle(h));
+  BBX_HIP(hipSetDevice(h->device));
+  if (!enabled && h->timer.enabled) BBX_TRY(timer_collect(h));
+  h->timer.enabled = enabled != 0;
+  return BBX_OK;
+}
+
+int bbx_design_get_timing(bbx_design* h, int which, int64_t* n_launch,
+                          double* total_ms) {
+  BBX_TRY(check_handle(h));
+  if (which < 0 || which > 1) return fail(BBX_ERR_INVALID, "which must be 0/1");
+  BBX_HIP(hipSetDevice(h->device));
+  BBX_TRY(timer_collect(h));
+  if (n_launch) *n_launch = h->timer.n_launch[which];
+  if (total_ms) *total_ms = h->timer.total_ms[which];
+  return BBX_OK;
+}
+
+int bbx_design_reset_timing(bbx_design* h) {
+  BBX_TRY(check_handle(h));
+  BBX_HIP(hipSetDevice(h->device));
+  BBX_TRY(timer_collect(h));
+  for (int which = 0; which < 2; ++which) {
+    h->timer.n_launch[which] = 0;
+    h->timer.total_ms[which] = 0.;
+  }
+  return BBX_OK;
+}
+
+int bbx_design_storage_bytes(const bbx_design* h, int64_t* bytes) {
+  BBX_TRY(check_handle(h));
+  int64_t b = 0;
+  b += (int64_t)(h->indptr.bytes + h->indices.bytes + h->data.bytes);
+  b += (int64_t)(h->t_indptr.bytes + h->t_indices.bytes + h->t_data.bytes);
+  b += (int64_t)(h->t_chunk_row.bytes + h->t_chunk_begin.bytes +
+                 h->t_row_chunk_ptr.bytes);
+  b += (int64_t)h->dense.bytes;
+  if (bytes) *bytes = b;
+  return BBX_OK;
+}
+
+int bbx_design_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
+                            int64_t* tdot_bytes) {
+  BBX_TRY(check_handle(h));
+  int64_t db = 0, tb = 0;
+  if (!h->sparse) {
+    const int64_t el = h->dense_dtype == BBX_F32 ? 4 : 8;
+    db = tb = h->n * h->P * el + 8 * (h->n + h->P);
+  } else {
+    // nnz*(b_val+b_idx) + (rows+1)*b_ptr + 8*len(in) + 8*len(out)
+    const int64_t bval = h->binary ? 0 : 8;
+    db = h->nnz * (bval + 4) + (h->n + 1) * 4 + 8 * h->P + 8 * h->n;
+    tb = h->nnz * (bval + 4) + (h->p + 1) * 4 + 8 * h->n + 8 * h->P;
+  }
+  if (dot_bytes) *dot_bytes = db;
+  if (tdot_bytes) *tdot_bytes = tb;
+  return BBX_OK;
+}
+
+}  // extern "C"

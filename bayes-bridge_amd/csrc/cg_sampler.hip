@@ -1,0 +1,191 @@
+// The prior-preconditioned conjugate-gradient sampler, device resident.
+//
+// Replaces ConjugateGradientSampler.sample (reg_coef_sampler/cg_sampler.py:20-94)
+// for precond_by='prior':
+//   s, d                          cg_sampler.py:104,128-138
+//   v = X~^T(sqrt(Omega) eta1) + phi eta2 ;  b = s (z + v)   :66-68
+//   x = x0 / s                    :76
+//   CG on  A x = d x + s X~^T Omega X~ (s x)                 :106-109
+//   coef = s x                    :89
+// and the SciPy >= 1.14 `cg` recurrence called at cg_sampler.py:77-80
+// (scipy/sparse/linalg/_isolve/iterative.py `cg`, M = identity):
+//   r = b - A x0
+//   for k < maxiter: if ||r|| < atol: return; rho = r.r;
+//                    p = r + (rho/rho_prev) p; q = A p; alpha = rho/(p.q);
+//                    x += alpha p; r -= alpha q
+//
+// The loop's scalars live in a CGState on the device; the host only enqueues
+// kernels and polls the `done` flag every few iterations.
+#include "common.hpp"
+#include "philox.hpp"
+
+namespace bbx {
+
+int launch_cg_setup(bbx_design* h, int n_unshrunk, const double* phi,
+                    const double* sd, const double* x0, double* s, double* d,
+                    double* xs);
+int launch_cg_init_resid(bbx_design* h, const double* b, const double* q,
+                         double* r, double* rr_part);
+int launch_cg_direction(bbx_design* h, int k, CGState* st,
+                        const double* rr_part, const double* r, double* pvec,
+                        const double* s, double* sp, double* c_part);
+int launch_cg_update(bbx_design* h, int k, CGState* st, const double* pq_part,
+                     const double* pvec, const double* q, double* x, double* r,
+                     double* rr_part);
+int launch_cg_finish(bbx_design* h, const double* s, const double* x,
+                     double* coef);
+
+__global__ __launch_bounds__(256) void fill_normal_kernel(
+    int64_t len, uint64_t seed, uint64_t stream, double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    Philox g(seed, stream, (uint64_t)i);
+    out[i] = g.normal();
+  }
+}
+
+int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,
+                       uint64_t stream, double* d_out) {
+  int64_t nb = (len + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)nb), dim3(256), 0,
+                     h->stream, len, seed, stream, d_out);
+  BBX_HIP(hipGetLastError());
+  return BBX_OK;
+}
+
+// One application of  q = d x + s X~^T (Omega (X~ (s x)))  given sp = s.*x and
+// the partials of <offset, sp[1:]> already in PS_C.  Leaves partials of x.q in
+// PS_PQ.
+static int apply_operator(bbx_design* h, const double* d_omega,
+                          const double* sp, const double* x, const double* s,
+                          const double* d, double* q) {
+  double* t = h->w_n[0].as<double>();
+  BBX_TRY(launch_dot(h, sp, d_omega, t, part_slot(h, PS_SUMW)));
+  TdotEpilogue ep;
+  ep.mode = TD_OPER;
+  ep.s = s;
+  ep.d = d;
+  ep.x = x;
+  ep.dot_part = part_slot(h, PS_PQ);
+  BBX_TRY(launch_tdot(h, t, part_slot(h, PS_SUMW), ep, q));
+  return BBX_OK;
+}
+
+int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
+                     const double* d_z, const double* d_x0,
+                     const double* d_sd, int n_unshrunk, const double* d_eta1,
+                     const double* d_eta2, uint64_t seed, int maxiter,
+                     double atol, double* d_coef, int* n_iter_out,
+                     int* info_out) {
+  if (maxiter < 0) return fail(BBX_ERR_INVALID, "maxiter must be >= 0");
+  if (n_unshrunk < 0 || n_unshrunk > h->P)
+    return fail(BBX_ERR_INVALID, "n_unshrunk out of range");
+  if ((d_eta1 == nullptr) != (d_eta2 == nullptr))
+    return fail(BBX_ERR_INVALID,
+                "randn_n and randn_P must both be given or both be NULL");
+  double* s = h->w_P[0].as<double>();
+  double* d = h->w_P[1].as<double>();
+  double* x = h->w_P[2].as<double>();
+  double* r = h->w_P[3].as<double>();
+  double* pvec = h->w_P[4].as<double>();
+  double* q = h->w_P[5].as<double>();
+  double* sp = h->w_P[6].as<double>();
+  double* b = h->w_P[7].as<double>();
+  CGState* st = h->cg_state.as<CGState>();
+
+  if (d_eta1 == nullptr) {
+    double* e1 = h->w_n[2].as<double>();
+    double* e2 = h->w_P[8].as<double>();
+    BBX_TRY(launch_fill_normal(h, h->n, seed, STREAM_ETA1, e1));
+    BBX_TRY(launch_fill_normal(h, h->P, seed, STREAM_ETA2, e2));
+    d_eta1 = e1;
+    d_eta2 = e2;
+  }
+
+  BBX_TRY(launch_cg_setup(h, n_unshrunk, d_phi, d_sd, d_x0, s, d, x));
+
+  // b = s (z + X~^T(sqrt(Omega) eta1) + phi eta2)
+  {
+    double* w = h->w_n[1].as<double>();
+    BBX_TRY(launch_sqrt_scale(h, d_omega, d_eta1, w, part_slot(h, PS_SUMW)));
+    TdotEpilogue ep;
+    ep.mode = TD_RHS;
+    ep.s = s;
+    ep.z = d_z;
+    ep.phi = d_phi;
+    ep.eta2 = d_eta2;
+    ep.dot_part = part_slot(h, PS_MISC);
+    BBX_TRY(launch_tdot(h, w, part_slot(h, PS_SUMW), ep, b));
+  }
+
+  // r = b - A x0
+  BBX_TRY(launch_prep_v(h, x, s, sp, part_slot(h, PS_C)));
+  BBX_TRY(apply_operator(h, d_omega, sp, x, s, d, q));
+  BBX_TRY(launch_cg_init_resid(h, b, q, r, part_slot(h, PS_RR)));
+
+  CGState init;
+  init.rho[0] = init.rho[1] = 0.;
+  init.atol = atol;
+  init.bnorm2 = 0.;
+  init.n_iter = 0;
+  init.done = 0;
+  init.bad = 0;
+  init.pad = 0;
+  CGState* host_st = static_cast<CGState*>(h->host_pinned);
+  *host_st = init;
+  BBX_HIP(hipMemcpyAsync(st, host_st, sizeof(CGState), hipMemcpyHostToDevice,
+                         h->stream));
+  // the pinned buffer is reused for the read-back below
+  BBX_HIP(hipStreamSynchronize(h->stream));
+
+  int k = 0;
+  bool done = false;
+  // Enqueue close to the previous solve's iteration count before the first
+  // poll, then poll every other iteration.
+  int next_poll = h->last_cg_iter > 2 ? h->last_cg_iter - 1 : 1;
+  while (!done) {
+    const int stop = (next_poll < maxiter) ? next_poll : maxiter;
+    for (; k < stop; ++k) {
+      BBX_TRY(launch_cg_direction(h, k, st, part_slot(h, PS_RR), r, pvec, s, sp,
+                                  part_slot(h, PS_C)));
+      BBX_TRY(apply_operator(h, d_omega, sp, pvec, s, d, q));
+      BBX_TRY(launch_cg_update(h, k, st, part_slot(h, PS_PQ), pvec, q, x, r,
+                               part_slot(h, PS_RR)));
+    }
+    if (k >= maxiter) break;
+    // Stop test of iteration k (SciPy checks at the loop top) rides along
+    // with the next direction kernel; peek at the flag it left behind.
+    BBX_TRY(launch_cg_direction(h, k, st, part_slot(h, PS_RR), r, pvec, s, sp,
+                                part_slot(h, PS_C)));
+    BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,
+                           h->stream));
+    BBX_HIP(hipStreamSynchronize(h->stream));
+    if (host_st->done) {
+      done = true;
+      break;
+    }
+    // direction(k) already ran: finish iteration k, then continue.
+    BBX_TRY(apply_operator(h, d_omega, sp, pvec, s, d, q));
+    BBX_TRY(launch_cg_update(h, k, st, part_slot(h, PS_PQ), pvec, q, x, r,
+                             part_slot(h, PS_RR)));
+    ++k;
+    next_poll = k + 2;
+  }
+  BBX_TRY(launch_cg_finish(h, s, x, d_coef));
+  BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,
+                         h->stream));
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  const int n_iter = host_st->n_iter;
+  int info = host_st->done ? 0 : maxiter;
+  if (host_st->bad) info = -1;
+  h->last_cg_iter = n_iter;
+  if (n_iter_out) *n_iter_out = n_iter;
+  if (info_out) *info_out = info;
+  if (info < 0)
+    return fail(BBX_ERR_NUMERIC, "non-finite residual inside CG");
+  return info;
+}
+
+}  // namespace bbx

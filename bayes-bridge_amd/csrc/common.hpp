@@ -1,0 +1,201 @@
+// Internal declarations shared by the translation units of libbbx.so.
+// gfx950 (MI355X, CDNA4) only: 64-lane wavefronts are hard-coded.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/bbx.h"
+
+namespace bbx {
+
+constexpr int WAVE = 64;
+// Grid of the P-length vector kernels and number of partial sums every
+// two-stage reduction leaves behind.  Consumers re-add the NPART partials in a
+// fixed order, so every reduction is bitwise reproducible run to run.
+constexpr int NPART = 256;
+constexpr int VEC_BLOCK = 256;
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define BBX_HIP(expr)                                                          \
+  do {                                                                         \
+    hipError_t err__ = (expr);                                                 \
+    if (err__ != hipSuccess) {                                                 \
+      return ::bbx::fail(BBX_ERR_HIP, std::string(#expr) + ": " +              \
+                                          hipGetErrorString(err__));           \
+    }                                                                          \
+  } while (0)
+
+#define BBX_TRY(expr)                                                          \
+  do {                                                                         \
+    int st__ = (expr);                                                         \
+    if (st__ < 0) return st__;                                                 \
+  } while (0)
+
+// Device allocation owned by a handle; freed in the handle's destructor.
+struct DevMem {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  DevMem() = default;
+  DevMem(const DevMem&) = delete;
+  DevMem& operator=(const DevMem&) = delete;
+  ~DevMem() { release(); }
+  int alloc(size_t nbytes);
+  void release();
+  template <typename T>
+  T* as() const {
+    return static_cast<T*>(ptr);
+  }
+};
+
+// Scalars of one CG solve, resident on the device so that the loop never has
+// to round-trip to the host.
+struct CGState {
+  double rho[2];     // r.r of iteration k in slot k&1
+  double atol;       // stop when ||r||_2 < atol   (cg_sampler.py:75-80)
+  double bnorm2;     // ||b||^2 (diagnostic)
+  int n_iter;        // completed iterations == callback count (cg_sampler.py:71-72)
+  int done;          // 1 once the stop rule fired; later kernels exit at entry
+  int bad;           // 1 if a non-finite or non-positive curvature was seen
+  int pad;
+};
+
+struct KernelTimer {
+  bool enabled = false;
+  struct Pair {
+    hipEvent_t a, b;
+  };
+  std::vector<Pair> pending[2];
+  std::vector<Pair> pool;
+  int64_t n_launch[2] = {0, 0};
+  double total_ms[2] = {0., 0.};
+};
+
+}  // namespace bbx
+
+// One design operator on one GPU.  Layout of everything in HBM is described
+// in DESIGN.md, section "Data layout".
+struct bbx_design {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t n = 0, p = 0, P = 0, nnz = 0;
+  int intercept = 0;
+  bool sparse = true;
+  bool binary = false;   // every stored value is 1.0 => values never read
+  bool centred = false;
+  int format = BBX_FORMAT_CSR;
+  int dense_dtype = BBX_F64;
+
+  // --- reference layout (BBX_FORMAT_CSR): CSR of X and CSR of X^T
+  bbx::DevMem indptr, indices, data;        // X      : n rows
+  bbx::DevMem t_indptr, t_indices, t_data;  // X^T    : p rows
+  // X^T rows are split into chunks of <= T_CHUNK stored entries so that the
+  // skewed column counts (1 ... 0.5 n, simulate_data.py:100-117) load-balance.
+  bbx::DevMem t_chunk_row, t_chunk_begin;   // per chunk: row id, first entry
+  bbx::DevMem t_row_chunk_ptr;              // per row : first chunk id  (p+1)
+  int64_t n_tchunk = 0;
+  bbx::DevMem t_partial;                    // per chunk partial sum
+
+  // --- dense layout
+  bbx::DevMem dense;  // row-major n x P (intercept column included), f32 or f64
+
+  bbx::DevMem offset;  // column means (p), zeros when not centred
+
+  // --- persistent work vectors
+  bbx::DevMem w_n[3];     // n-length: t, eta1*sqrt(omega), spare
+  bbx::DevMem w_P[10];    // P-length CG vectors
+  bbx::DevMem part;       // NPART-length partial-sum slots (several)
+  bbx::DevMem cg_state;   // CGState
+  bbx::DevMem stage_n, stage_P;  // staging for the host-pointer entry points
+  void* host_pinned = nullptr;   // small pinned buffer for flag read-back
+
+  int64_t n_dot = 0, n_tdot = 0;
+  int last_cg_iter = 0;  // iterations of the previous solve (poll scheduling)
+  bbx::KernelTimer timer;
+};
+
+namespace bbx {
+
+// Partial-sum slots inside bbx_design::part (each NPART doubles).
+enum PartSlot {
+  PS_C = 0,     // <offset, v[1:]> of the current dot input
+  PS_SUMW = 1,  // sum of the current Tdot input
+  PS_PQ = 2,    // p.q
+  PS_RR = 3,    // r.r
+  PS_MISC = 4,
+  PS_COUNT = 8
+};
+
+inline double* part_slot(const bbx_design* h, int slot) {
+  return h->part.as<double>() + (size_t)slot * NPART;
+}
+
+// ---- operator launches (spmv_csr.hip / dense.hip) --------------------------
+// t[n] = rowscale ? rowscale .* (X~ v) : X~ v ;  v is a device P-vector.
+// `c_part` must hold the NPART partials of <offset, v[1:]> (see launch_prep_v).
+// If sum_part != nullptr the NPART partial sums of t are written there.
+int launch_dot(bbx_design* h, const double* d_v, const double* d_rowscale,
+               double* d_t, double* d_sum_part);
+// Modes of the Tdot epilogue.
+enum TdotMode {
+  TD_PLAIN = 0,  // out = g
+  TD_OPER = 1,   // out = d .* x + s .* g            (cg_sampler.py:107-108)
+  TD_RHS = 2     // out = s .* (z + g + phi .* eta2) (cg_sampler.py:66-68)
+};
+struct TdotEpilogue {
+  int mode = TD_PLAIN;
+  const double* s = nullptr;
+  const double* d = nullptr;
+  const double* x = nullptr;
+  const double* z = nullptr;
+  const double* phi = nullptr;
+  const double* eta2 = nullptr;
+  double* dot_part = nullptr;  // TD_OPER: partials of x.out ; TD_RHS: of out.out
+};
+// out[P] = epilogue([sum w ; X_main^T w - sum(w) offset]).  `sumw_part` holds
+// the NPART partials of sum(w).
+int launch_tdot(bbx_design* h, const double* d_w, const double* d_sumw_part,
+                const TdotEpilogue& ep, double* d_out);
+
+// ---- vector kernels (vecops.hip) -------------------------------------------
+// v = s ? s .* x : x  (written to d_v unless d_v == x and s == nullptr), and the
+// NPART partials of <offset, v[1:]> into c_part.
+int launch_prep_v(bbx_design* h, const double* d_x, const double* d_s,
+                  double* d_v, double* d_c_part);
+// partials of sum(w .* a) (a may be nullptr => sum(w)) over n entries.
+int launch_sum_n(bbx_design* h, const double* d_w, int64_t len,
+                 double* d_part);
+// w[i] = sqrt(omega[i]) * eta[i], plus partials of sum(w).
+int launch_sqrt_scale(bbx_design* h, const double* d_omega,
+                      const double* d_eta, double* d_w, double* d_part);
+
+int design_alloc_work(bbx_design* h);
+int build_transpose_csr(bbx_design* h);
+int launch_dot_csr(bbx_design* h, const double* d_v, const double* d_rowscale,
+                   double* d_t);
+int launch_tdot_csr(bbx_design* h, const double* d_w,
+                    const double* d_sumw_part, const TdotEpilogue& ep,
+                    double* d_out);
+int launch_tdot_finalize(bbx_design* h, const double* d_gfull,
+                         const double* d_sumw_part, const TdotEpilogue& ep,
+                         double* d_out);
+int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,
+                       uint64_t stream, double* d_out);
+
+int timer_begin(bbx_design* h, int which);
+int timer_end(bbx_design* h, int which);
+
+// ---- CG sampler (cg_sampler.hip) -------------------------------------------
+int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
+                     const double* d_z, const double* d_x0,
+                     const double* d_sd, int n_unshrunk, const double* d_eta1,
+                     const double* d_eta2, uint64_t seed, int maxiter,
+                     double atol, double* d_coef, int* n_iter_out,
+                     int* info_out);
+
+}  // namespace bbx

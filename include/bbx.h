@@ -1,0 +1,222 @@
+/*
+ * bbx.h -- C ABI of libbbx.so: the MI355X (gfx950) implementation of the
+ * bayes-bridge CG-accelerated regression-coefficient sampler.
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes
+ * plain pointers and sizes, returns an int status and never throws.  The
+ * reference interface each one replaces is cited as file:line relative to the
+ * upstream repository (OHDSI/bayes-bridge, version 0.2.6).
+ *
+ * Status convention (mirrors SciPy's `info` of scipy.sparse.linalg.cg, which
+ * the reference inspects at cg_sampler.py:82-92):
+ *     0   success
+ *   < 0   invalid input / runtime failure (see bbx_last_error())
+ *   > 0   only from the CG entry points: the solver stopped at `maxiter`
+ *         without reaching the tolerance; the result is still written, as the
+ *         reference does (it warns and continues, cg_sampler.py:82-87).
+ *
+ * Threading/ownership: a handle is bound to one HIP device and one stream and
+ * is NOT thread-safe (the reference is single-threaded and uses the process
+ * global RNG, cg_sampler.py:51-62).  Host pointers are caller-owned and are
+ * only read/written for the duration of the call.  The library owns the device
+ * copies of X (both orientations) and all persistent work vectors.
+ *
+ * The ctypes precedent in the reference for such a boundary is
+ * design_matrix/mkl_matvec.py:17-56 (MKL `mkl_dcsrmv`).
+ */
+#ifndef BBX_H
+#define BBX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBX_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define BBX_OK 0
+#define BBX_ERR_INVALID (-1)   /* bad argument (shape, NULL pointer, ...)      */
+#define BBX_ERR_HIP (-2)       /* a HIP runtime call failed                     */
+#define BBX_ERR_NODEVICE (-3)  /* no usable gfx950 device                       */
+#define BBX_ERR_NUMERIC (-4)   /* NaN/Inf or non-positive curvature inside CG   */
+#define BBX_ERR_STATE (-5)     /* call order violated (e.g. chain not set up)   */
+
+/* storage formats of the sparse operator (bbx_design_create_csr `format`) */
+#define BBX_FORMAT_AUTO 0  /* tiled when it applies, else csr                   */
+#define BBX_FORMAT_CSR 1   /* reference layout: f64 values + i32 indices, CSR of
+                              X and CSR of X^T (sparse_matrix.py:49,96,126)     */
+#define BBX_FORMAT_TILED 2 /* LDS-tiled panels: u16 block-local indices, values
+                              dropped when every stored entry is 1.0 (the idea
+                              of cython_matmal/binary_matmul.pyx:21-25)         */
+
+/* dtypes of dense storage */
+#define BBX_F64 0
+#define BBX_F32 1
+
+/* likelihood families of a chain (model/factory.py:53-66) */
+#define BBX_MODEL_LINEAR 0
+#define BBX_MODEL_LOGIT 1
+
+typedef struct bbx_design bbx_design; /* opaque: one design operator on one GPU */
+typedef struct bbx_chain bbx_chain;   /* opaque: one device-resident Gibbs chain */
+
+/* ---------------------------------------------------------------- library */
+
+int bbx_version(void);
+/* Thread-local text of the last failure; never NULL. */
+const char* bbx_last_error(void);
+/* Number of visible HIP devices (0 on a CPU-only box; never touches a GPU
+ * context beyond counting). */
+int bbx_device_count(int* count);
+
+/* ---------------------------------------------------- design operator (L1) */
+
+/*
+ * Build the operator  X~ = [1_n | X - 1_n offset^T]  (never materialised) from
+ * a host CSR matrix.  Replaces SparseDesignMatrix.__init__
+ * (design_matrix/sparse_matrix.py:21-49) for the part after zero-variance
+ * column removal (done by the host wrapper, abstract_matrix.py:93-107).
+ *   indptr[n+1], indices[nnz]: int32, as SciPy CSR; data[nnz] f64 or NULL when
+ *   every stored value is 1.0; col_offset[p] f64 or NULL (= zeros, i.e. not
+ *   centred); add_intercept: 1 => shape is (n, p+1) (sparse_matrix.py:51-54).
+ */
+int bbx_design_create_csr(int64_t n, int64_t p, int64_t nnz,
+                          const int32_t* indptr, const int32_t* indices,
+                          const double* data, const double* col_offset,
+                          int add_intercept, int device, int format,
+                          bbx_design** out);
+
+/* Same, but indptr/indices/data/col_offset are DEVICE pointers on `device`
+ * (used when the matrix is generated on the GPU; the arrays are copied, the
+ * caller keeps ownership). */
+int bbx_design_create_csr_dev(int64_t n, int64_t p, int64_t nnz,
+                              const int32_t* d_indptr, const int32_t* d_indices,
+                              const double* d_data, const double* d_col_offset,
+                              int add_intercept, int device, int format,
+                              bbx_design** out);
+
+/*
+ * Dense operator.  Replaces DenseDesignMatrix.__init__/dot/Tdot
+ * (design_matrix/dense_matrix.py:9-27,37-52).  X is row-major n x p (C order,
+ * as NumPy), WITHOUT the intercept column; centring (col_offset != NULL) and
+ * the intercept column are applied while the device copy is made, so the host
+ * array is not modified (the reference centres the caller's array in place,
+ * dense_matrix.py:21-22).  in_dtype is the dtype of X, storage_dtype the dtype
+ * kept in HBM (BBX_F32 halves the traffic; all arithmetic stays f64).
+ */
+int bbx_design_create_dense(int64_t n, int64_t p, const void* X, int in_dtype,
+                            int storage_dtype, const double* col_offset,
+                            int add_intercept, int device, bbx_design** out);
+/* X is a DEVICE pointer (row-major n x p, in_dtype). */
+int bbx_design_create_dense_dev(int64_t n, int64_t p, const void* d_X,
+                                int in_dtype, int storage_dtype,
+                                const double* d_col_offset, int add_intercept,
+                                int device, bbx_design** out);
+
+int bbx_design_destroy(bbx_design* h);
+
+/* shape -> (n, P) with P = p + add_intercept (sparse_matrix.py:51-54);
+ * nnz -> stored entries of X_main (sparse_matrix.py:60-66; n*p for dense). */
+int bbx_design_shape(const bbx_design* h, int64_t* n, int64_t* P);
+int bbx_design_nnz(const bbx_design* h, int64_t* nnz);
+int bbx_design_is_sparse(const bbx_design* h, int* flag);
+/* Format actually in use (BBX_FORMAT_CSR / BBX_FORMAT_TILED; 0 for dense). */
+int bbx_design_format(const bbx_design* h, int* format);
+/* HBM bytes held by the operator's matrix storage (both orientations). */
+int bbx_design_storage_bytes(const bbx_design* h, int64_t* bytes);
+/* Algorithmic HBM bytes of one dot / one Tdot in the storage format actually
+ * read (nnz*(b_val+b_idx) + row pointers + in + out). */
+int bbx_design_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
+                            int64_t* tdot_bytes);
+
+/*
+ * out[n] = X~ v,  v[P].  Replaces SparseDesignMatrix.dot / main_dot
+ * (sparse_matrix.py:68-101) and DenseDesignMatrix.dot (dense_matrix.py:37-48):
+ *   out = v[0] + X_main v[1:] - <offset, v[1:]>.
+ * Host pointers; synchronous.
+ */
+int bbx_design_dot(bbx_design* h, const double* v, double* out);
+/*
+ * out[P] = X~^T w,  w[n].  Replaces SparseDesignMatrix.Tdot / main_Tdot
+ * (sparse_matrix.py:103-129) and DenseDesignMatrix.Tdot (dense_matrix.py:50-52):
+ *   out = [sum(w) ; X_main^T w - sum(w) * offset].
+ */
+int bbx_design_tdot(bbx_design* h, const double* w, double* out);
+/* Device-pointer forms: asynchronous on the handle's stream. */
+int bbx_design_dot_dev(bbx_design* h, const double* d_v, double* d_out);
+int bbx_design_tdot_dev(bbx_design* h, const double* d_w, double* d_out);
+
+/* The hipStream_t (as void*) every kernel of this handle is launched on, and a
+ * blocking wait on it. */
+int bbx_design_stream(bbx_design* h, void** stream);
+int bbx_design_synchronize(bbx_design* h);
+
+/* ------------------------------------------------------- CG sampler (L3) */
+
+/*
+ * One draw  beta ~ N(Sigma z, Sigma),  Sigma^-1 = X~^T diag(obs_prec) X~ +
+ * diag(prior_prec_sqrt^2), by perturbation-optimisation + prior-preconditioned
+ * conjugate gradient.  Replaces ConjugateGradientSampler.sample
+ * (reg_coef_sampler/cg_sampler.py:20-94) with precond_by='prior'
+ * (cg_sampler.py:128-138), including precondition_linear_system
+ * (cg_sampler.py:96-113) and the SciPy >= 1.14 `cg` recurrence it calls
+ * (cg_sampler.py:77-80).
+ *
+ *   obs_prec[n]          Omega
+ *   prior_prec_sqrt[P]   phi = 1/prior_sd (0 for a flat prior)
+ *   z[P]                 X~^T (Omega y)
+ *   x0[P]                coef_cg_init (CG warm start, in beta coordinates)
+ *   precond_sd[P]        coef_scaled_sd; only the first n_unshrunk entries are
+ *                        used: s_j = 2*precond_sd[j] (cg_sampler.py:133-136)
+ *   randn_n[n], randn_P[P]  the standard-normal draws eta1, eta2 of
+ *                        cg_sampler.py:61-62 (the reference draws them from the
+ *                        global NumPy RNG, n first).  Pass NULL for BOTH to
+ *                        draw them on the device from Philox4x32-10 keyed by
+ *                        `seed` (distribution parity only).
+ *   maxiter, atol        as cg_sampler.py:22-23; the stop rule is
+ *                        ||r||_2 < atol in preconditioned coordinates.
+ *   coef_out[P]          the draw; n_iter_out = number of completed CG
+ *                        iterations (the reference's callback count);
+ *   info_out             SciPy-style info: 0 converged, maxiter if exhausted.
+ * Return value: 0, or > 0 (= info) when not converged, or < 0 on error.
+ */
+int bbx_cg_sample(bbx_design* h, const double* obs_prec,
+                  const double* prior_prec_sqrt, const double* z,
+                  const double* x0, const double* precond_sd, int n_unshrunk,
+                  const double* randn_n, const double* randn_P, uint64_t seed,
+                  int maxiter, double atol, double* coef_out, int* n_iter_out,
+                  int* info_out);
+/* All array arguments are DEVICE pointers; n_iter_out/info_out stay host. */
+int bbx_cg_sample_dev(bbx_design* h, const double* d_obs_prec,
+                      const double* d_prior_prec_sqrt, const double* d_z,
+                      const double* d_x0, const double* d_precond_sd,
+                      int n_unshrunk, const double* d_randn_n,
+                      const double* d_randn_P, uint64_t seed, int maxiter,
+                      double atol, double* d_coef_out, int* n_iter_out,
+                      int* info_out);
+
+/* Counters of operator applications since creation / last reset, the
+ * equivalent of AbstractDesignMatrix.get_dot_count / reset_matvec_count
+ * (abstract_matrix.py:61-72).  Applications inside bbx_cg_sample count too. */
+int bbx_design_matvec_count(const bbx_design* h, int64_t* n_dot,
+                            int64_t* n_tdot);
+int bbx_design_reset_matvec_count(bbx_design* h);
+
+/* ------------------------------------------------ kernel timing (profiling) */
+
+/* When enabled, HIP events are recorded on the handle's stream around every
+ * dot / Tdot kernel launch (also those inside the CG loop and the chain). */
+int bbx_design_set_timing(bbx_design* h, int enabled);
+/* Resolves all pending event pairs (synchronises the stream) and returns the
+ * number of timed launches and their summed device time per kernel family:
+ * which = 0 dot (X v), 1 Tdot (X^T w). */
+int bbx_design_get_timing(bbx_design* h, int which, int64_t* n_launch,
+                          double* total_ms);
+int bbx_design_reset_timing(bbx_design* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBX_H */

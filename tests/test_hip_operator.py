@@ -1,0 +1,139 @@
+"""GPU parity of the design operator: libbbx (through the C ABI / ctypes) vs
+the CPU oracle on identical seeded inputs.
+
+Mirrors the reference's tests/test_design_matrix.py:12-24,49-61 (dot/Tdot with
+intercept + centring equal the explicit matrix, atol = rtol = 1e-5 there) and
+adds the edge cases of the domain: empty rows/columns, no intercept, no
+centring, non-binary values, skewed column counts.
+
+Tolerance: the reference's own bound is 1e-5; the oracle comparison uses
+|diff| <= 1e-11 * scale (f64 sums in a different order)."""
+import numpy as np
+import pytest
+import scipy.sparse as sparse
+
+import oracle
+from helpers import mixed_design
+
+pytestmark = pytest.mark.gpu
+
+REF_ATOL = REF_RTOL = 10e-6   # tests/test_design_matrix.py:8-9
+
+
+def _hip(X, storage, **kw):
+    from bayesbridge_amd import HipSparseDesignMatrix
+    return HipSparseDesignMatrix(X, storage=storage, **kw)
+
+
+def _check(hip, ora, seed=0, tol=1e-11):
+    n, P = ora.shape
+    assert hip.shape == (n, P)
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal(P)
+    w = rng.standard_normal(n)
+    a, b = hip.dot(v), ora.dot(v)
+    scale = max(1., np.abs(b).max())
+    assert np.abs(a - b).max() <= tol * scale
+    a, b = hip.Tdot(w), ora.Tdot(w)
+    scale = max(1., np.abs(b).max())
+    assert np.abs(a - b).max() <= tol * scale
+
+
+STORAGES = ['csr']
+
+
+@pytest.mark.parametrize("storage", STORAGES)
+def test_sparse_intercept_and_centering_vs_explicit(storage):
+    # tests/test_design_matrix.py:12-24
+    X = mixed_design(100, 10, binary_frac=.5, seed=0)
+    hip = _hip(X, storage, center_predictor=True, add_intercept=True)
+    A = X.toarray()
+    A = A - A.mean(axis=0)[None, :]
+    A = np.hstack((np.ones((100, 1)), A))
+    rng = np.random.default_rng(1)
+    w, v = rng.standard_normal(100), rng.standard_normal(11)
+    assert np.allclose(hip.dot(v), A.dot(v), atol=REF_ATOL, rtol=REF_RTOL)
+    assert np.allclose(hip.Tdot(w), A.T.dot(w), atol=REF_ATOL, rtol=REF_RTOL)
+    assert hip.get_dot_count() == (1, 1)
+
+
+@pytest.mark.parametrize("storage", STORAGES)
+@pytest.mark.parametrize("center,intercept", [(True, True), (False, True),
+                                              (True, False), (False, False)])
+def test_sparse_vs_oracle_flags(storage, center, intercept):
+    X = mixed_design(257, 33, binary_frac=.6, seed=2)
+    hip = _hip(X, storage, center_predictor=center, add_intercept=intercept)
+    ora = oracle.OracleSparseDesign(X, center_predictor=center,
+                                    add_intercept=intercept)
+    _check(hip, ora, seed=3)
+
+
+@pytest.mark.parametrize("storage", STORAGES)
+def test_binary_skewed_columns(storage):
+    # all-ones values => value-free kernels; column counts 1 ... 0.5 n
+    X = mixed_design(20000, 700, binary_frac=1., freq=.02, seed=5)
+    assert np.all(X.data == 1.)
+    hip = _hip(X, storage, center_predictor=True, add_intercept=True)
+    ora = oracle.OracleSparseDesign(X, center_predictor=True,
+                                    add_intercept=True)
+    _check(hip, ora, seed=6)
+
+
+@pytest.mark.parametrize("storage", STORAGES)
+def test_empty_rows_and_ragged(storage):
+    rng = np.random.default_rng(7)
+    X = sparse.random(513, 70, density=.03, random_state=8, format='lil')
+    X[5, :] = 0
+    X[100:140, :] = 0            # a band of empty rows
+    X[:, 69] = 0                 # trailing empty column (kept: made non-constant below)
+    X[3, 69] = 2.5
+    X[200, :] = rng.standard_normal(70)   # one full row
+    X[:, 7] = rng.standard_normal((513, 1))  # one full column
+    X = X.tocsr()
+    hip = _hip(X, storage, center_predictor=True, add_intercept=True)
+    ora = oracle.OracleSparseDesign(X, center_predictor=True,
+                                    add_intercept=True)
+    _check(hip, ora, seed=9)
+
+
+@pytest.mark.parametrize("storage", STORAGES)
+def test_tiny_shapes(storage):
+    for n, p in [(2, 1), (2, 3), (3, 2), (65, 1), (2, 65), (64, 64)]:
+        X = sparse.csr_matrix(
+            np.random.default_rng(n * 100 + p).standard_normal((n, p)))
+        hip = _hip(X, storage, center_predictor=False, add_intercept=False)
+        ora = oracle.OracleSparseDesign(X, center_predictor=False,
+                                        add_intercept=False)
+        _check(hip, ora, seed=n + p)
+
+
+@pytest.mark.parametrize("storage", STORAGES)
+def test_linearity_and_adjointness_large(storage):
+    # size-independent properties at a size the oracle would not enjoy:
+    # <X~ v, w> == <v, X~^T w>, and X~(a v1 + v2) == a X~ v1 + X~ v2.
+    from bayesbridge_amd import simulate
+    X = simulate.simulate_binary_csr_fast(200000, 5000, .004, seed=10)
+    hip = _hip(X, storage, center_predictor=True, add_intercept=True)
+    n, P = hip.shape
+    rng = np.random.default_rng(11)
+    v1, v2, w = rng.standard_normal(P), rng.standard_normal(P), \
+        rng.standard_normal(n)
+    lhs = np.dot(hip.dot(v1), w)
+    rhs = np.dot(v1, hip.Tdot(w))
+    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs), 1.)
+    lin = hip.dot(2.5 * v1 + v2) - (2.5 * hip.dot(v1) + hip.dot(v2))
+    assert np.abs(lin).max() <= 1e-10 * max(1., np.abs(hip.dot(v1)).max())
+
+
+def test_bad_arguments_raise():
+    from bayesbridge_amd import HipSparseDesignMatrix, BbxError
+    X = mixed_design(50, 8, seed=12)
+    with pytest.raises(NotImplementedError):
+        HipSparseDesignMatrix(X, dot_format='csc')   # sparse_matrix.py:31-34
+    hip = HipSparseDesignMatrix(X)
+    with pytest.raises(ValueError):
+        hip.dot(np.zeros(3))
+    with pytest.raises(ValueError):
+        hip.Tdot(np.zeros(3))
+    with pytest.raises(NotImplementedError):
+        hip.compute_fisher_info(np.ones(50))
