@@ -1,11 +1,18 @@
 """bayesbridge_amd: MI355X-native CG-accelerated coefficient sampler of
-bayes-bridge (drop-in for the `coef_sampler_type='cg'` path)."""
-from .design_matrix import (HipDesignMatrix, HipSparseDesignMatrix,
-                            HipDenseDesignMatrix)
-from .cg_sampler import HipCGSampler
+bayes-bridge -- a drop-in for the `BayesBridge.gibbs(coef_sampler_type='cg')`
+path (reference: OHDSI/bayes-bridge 0.2.6).  The top-level names are the
+reference's (bayesbridge/__init__.py:1-4)."""
 from ._lib import BbxError, device_count
+from .bayesbridge import BayesBridge, SamplerOptions
+from .cg_sampler import HipCGSampler
+from .design_matrix import (HipDenseDesignMatrix, HipDesignMatrix,
+                            HipSparseDesignMatrix)
+from .model import LinearModel, LogisticModel, RegressionModel
+from .prior import RegressionCoefPrior
 
 __all__ = [
+    "BayesBridge", "RegressionModel", "RegressionCoefPrior", "SamplerOptions",
     "HipDesignMatrix", "HipSparseDesignMatrix", "HipDenseDesignMatrix",
-    "HipCGSampler", "BbxError", "device_count",
+    "HipCGSampler", "LinearModel", "LogisticModel", "BbxError",
+    "device_count",
 ]

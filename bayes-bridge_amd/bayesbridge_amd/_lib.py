@@ -73,6 +73,32 @@ def _declare(lib):
         "bbx_design_get_timing": (
             [hp, c_int, POINTER(c_int64), POINTER(c_double)], c_int),
         "bbx_design_reset_timing": ([hp], c_int),
+        "bbx_chain_create": (
+            [hp, c_int, c_void_p, c_void_p, c_int, c_void_p, c_double,
+             c_double, c_double, c_double, c_uint64, POINTER(hp)], c_int),
+        "bbx_chain_destroy": ([hp], c_int),
+        "bbx_chain_set_state": (
+            [hp, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+        "bbx_chain_get_state": (
+            [hp, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+        "bbx_chain_set_summary": ([hp, c_void_p, c_void_p, c_int64], c_int),
+        "bbx_chain_get_summary": (
+            [hp, c_void_p, c_void_p, POINTER(c_int64)], c_int),
+        "bbx_chain_init_obs_prec": ([hp], c_int),
+        "bbx_chain_get_iteration": ([hp, POINTER(c_int64)], c_int),
+        "bbx_chain_set_iteration": ([hp, c_int64], c_int),
+        "bbx_chain_run": (
+            [hp, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
+             c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+        "bbx_chain_run_host": (
+            [hp, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
+             c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+        "bbx_device_polya_gamma": (
+            [c_int, c_uint64, c_int64, c_void_p, c_void_p, c_void_p], c_int),
+        "bbx_device_tilted_stable": (
+            [c_int, c_uint64, c_int64, c_double, c_void_p, c_void_p], c_int),
+        "bbx_device_gamma": (
+            [c_int, c_uint64, c_int64, c_double, c_void_p], c_int),
     }
     for name, (argtypes, restype) in sigs.items():
         fn = getattr(lib, name)
@@ -82,6 +108,22 @@ def _declare(lib):
 
 
 EXPORTED_SYMBOLS = None
+
+
+def _one_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.  A process that first
+    loads libbbx.so (bound to /opt/rocm's runtime) and later imports torch ends
+    up with two HIP runtimes and torch then sees no GPU.  Importing torch first
+    makes the dynamic linker hand the already loaded runtime to libbbx.so, so
+    both share one.  torch is used for nothing else here
+    (BBX_NO_TORCH=1 skips this)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("BBX_NO_TORCH") == "1":
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
 
 
 def load():
@@ -94,6 +136,7 @@ def load():
                 "`python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C bayes-bridge_amd/csrc`. There is no CPU fallback."
                 % LIB_PATH)
+        _one_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
         EXPORTED_SYMBOLS = sorted(_declare(lib))
         _lib = lib

@@ -102,3 +102,52 @@ def simulate_outcome(X, beta, model, intercept=0., n_trial=None, seed=None):
         n_success = np.random.binomial(n_trial.astype(np.int32), prob)
         return n_success, n_trial
     raise NotImplementedError(model)
+
+
+def simulate_binary_csr_device(n_obs, n_pred, binary_pred_freq=.1,
+                               max_freq_per_col=.5, seed=0, device='cuda:0'):
+    """The binary design of simulate_design (simulate_data.py:100-117)
+    generated directly in HBM with torch: column frequencies
+    0.5*Beta(.5, .5(.5/f - 1)) (host, NumPy Generator(PCG64(seed))), then for
+    every column exactly nnz_j = ceil(n f_j) DISTINCT uniformly drawn rows
+    (device, torch Philox generator seeded with `seed`): draw with replacement,
+    drop duplicates, top up until exact.  Same distribution as the reference's
+    per-column `choice(n, nnz_j, replace=False)`; not stream-identical.
+
+    Returns (indptr int32 [n+1], indices int32 [nnz]) as torch tensors on
+    `device`, column indices ascending inside each row; all values are 1.0.
+    """
+    import torch
+    rng = np.random.default_rng(seed)
+    a = .5
+    b = a * (max_freq_per_col / binary_pred_freq - 1)
+    freq = max_freq_per_col * rng.beta(a, b, n_pred)
+    counts_np = np.ceil(n_obs * freq).astype(np.int64)
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+    counts = torch.from_numpy(counts_np).to(dev)
+    need = counts.clone()
+    col_ids = torch.arange(n_pred, device=dev, dtype=torch.int64)
+    keys = torch.empty(0, dtype=torch.int64, device=dev)
+    while int(need.sum().item()) > 0:
+        cols = torch.repeat_interleave(col_ids, need)
+        rows = torch.randint(0, n_obs, (cols.numel(),), generator=gen,
+                             device=dev, dtype=torch.int64)
+        keys = torch.unique(torch.cat((keys, cols * n_obs + rows)))
+        del cols, rows
+        have = torch.bincount(torch.div(keys, n_obs, rounding_mode='floor'),
+                              minlength=n_pred)
+        need = counts - have
+    cols = torch.div(keys, n_obs, rounding_mode='floor')
+    rows = keys - cols * n_obs
+    del keys
+    key2, _ = torch.sort(rows * n_pred + cols)
+    row_counts = torch.bincount(rows, minlength=n_obs)
+    del rows, cols
+    rows2 = torch.div(key2, n_pred, rounding_mode='floor')
+    indices = (key2 - rows2 * n_pred).to(torch.int32)
+    del key2, rows2
+    indptr = torch.zeros(n_obs + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(row_counts, 0)
+    return indptr.to(torch.int32), indices

@@ -1,0 +1,878 @@
+// Device-resident Gibbs chain: everything BayesBridge.gibbs does per iteration
+// (bayesbridge.py:210-240) around the CG draw, as kernels on the design's
+// stream.  The scalar samplers are the shared templates of samplers.hpp driven
+// by Philox counters.
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "common.hpp"
+#include "philox.hpp"
+#include "samplers.hpp"
+
+namespace bbx {
+
+constexpr int ROW_GRID = 2048;  // blocks of the n-length sampler kernels
+
+struct ChainScalars {
+  double gscale;         // tau, raw parametrisation
+  double obs_prec;       // linear model only
+  double loglik;         // of the current coef
+  double logp;           // log posterior (bayesbridge.py:480-511)
+  double abs_pow_sum;    // sum |beta_j|^alpha over shrunk coordinates
+  long long n_gscale_clamped;
+  long long n_lscale_fixed;
+};
+
+}  // namespace bbx
+
+struct bbx_chain {
+  bbx_design* h = nullptr;
+  int model = BBX_MODEL_LOGIT;
+  int n_unshrunk = 0;
+  double bridge_exp = .5, slab = INFINITY, shape0 = 0., rate0 = 0.;
+  uint64_t seed = 0;
+  int64_t iter = 0;        // iterations done (Philox key)
+  int64_t n_averaged = 0;  // summariser count
+  bbx::DevMem outcome, n_trial, kappa;  // n
+  bbx::DevMem zbase;                    // P: X~^T kappa (logit) or X~^T y
+  bbx::DevMem coef, phi, x0, sd, z, mean, square, sd_unshrunk;  // P-length
+  bbx::DevMem lscale;                   // P - n_unshrunk
+  bbx::DevMem obs_prec, psi;            // n
+  bbx::DevMem scalars;                  // ChainScalars
+  bbx::DevMem row_part;                 // ROW_GRID partials x 2
+  bbx::DevMem samp_gscale, samp_logp;   // per kept sample (device)
+  void* pinned = nullptr;
+};
+
+namespace bbx {
+
+__device__ inline double wsum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+  return x;
+}
+
+__device__ inline double block_total_256(double x) {
+  __shared__ double s_w[256 / WAVE];
+  x = wsum(x);
+  if ((threadIdx.x & (WAVE - 1)) == 0) s_w[threadIdx.x / WAVE] = x;
+  __syncthreads();
+  double r = 0.;
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 256 / WAVE; ++k) r += s_w[k];
+  __syncthreads();
+  return r;  // thread 0 only
+}
+
+__device__ inline double shrunk_scale(double gscale, double lscale,
+                                      double slab) {
+  // reg_coef_sampler.py:194-201
+  const double raw = gscale * lscale;
+  const double ratio = raw / slab;
+  return raw / sqrt(1. + ratio * ratio);
+}
+
+// phi, CG warm start, preconditioner sd, z  (reg_coef_sampler.py:74-89;
+// reg_coef_posterior_summarizer.py:25-29,105-124).
+__global__ __launch_bounds__(256) void chain_prior_kernel(
+    int64_t P, int nu, int model, double slab, long long n_avg,
+    const ChainScalars* __restrict__ sc, const double* __restrict__ lscale,
+    const double* __restrict__ sd_unshrunk, const double* __restrict__ mean,
+    const double* __restrict__ square, const double* __restrict__ zbase,
+    double* __restrict__ phi, double* __restrict__ x0, double* __restrict__ sd,
+    double* __restrict__ z) {
+  const double g = sc->gscale;
+  const double zs = (model == BBX_MODEL_LINEAR) ? sc->obs_prec : 1.;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < P;
+       j += (int64_t)gridDim.x * 256) {
+    double prior_sd, guess = mean[j];
+    if (j < nu) {
+      prior_sd = sd_unshrunk[j];
+    } else {
+      prior_sd = shrunk_scale(g, lscale[j - nu], slab);
+      guess *= prior_sd;
+    }
+    phi[j] = 1. / prior_sd;
+    x0[j] = guess;
+    double est = 1.;
+    if (n_avg > 1) {
+      const double k = (double)n_avg;
+      const double m = mean[j];
+      const double var = k / (k - 1.) * (square[j] - m * m);
+      const double w = (k - 1.) / (k - 1. + 5.);
+      est = sqrt(w * var + (1. - w) * 1.);
+    }
+    sd[j] = est;
+    z[j] = zs * zbase[j];
+  }
+}
+
+// Running mean / second moment of the scaled coefficients
+// (reg_coef_posterior_summarizer.py:11-19,93-103).
+__global__ __launch_bounds__(256) void chain_summary_kernel(
+    int64_t P, int nu, double slab, long long n_avg,
+    const ChainScalars* __restrict__ sc, const double* __restrict__ lscale,
+    const double* __restrict__ coef, double* __restrict__ mean,
+    double* __restrict__ square) {
+  const double g = sc->gscale;
+  const double w = 1. / (1. + (double)n_avg);
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < P;
+       j += (int64_t)gridDim.x * 256) {
+    double theta = coef[j];
+    if (j >= nu) theta /= shrunk_scale(g, lscale[j - nu], slab);
+    mean[j] = w * theta + (1. - w) * mean[j];
+    square[j] = w * theta * theta + (1. - w) * square[j];
+  }
+}
+
+__device__ inline double log1pexp(double x) {
+  // np.logaddexp(0, x)  (logistic_model.py:52-55)
+  return x > 0. ? x + log1p(exp(-x)) : log1p(exp(x));
+}
+
+// Omega_i ~ PG(n_trial_i, psi_i) and the log-likelihood partials
+// (bayesbridge.py:405-408; logistic_model.py:49-55).
+__global__ __launch_bounds__(256) void chain_pg_kernel(
+    int64_t n, uint64_t seed, uint64_t stream,
+    const double* __restrict__ n_success, const double* __restrict__ n_trial,
+    const double* __restrict__ psi, double* __restrict__ omega,
+    double* __restrict__ ll_part) {
+  double acc = 0.;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256) {
+    const double eta = psi[i];
+    const double nt = n_trial[i];
+    Philox g(seed, stream, (uint64_t)i);
+    omega[i] = PolyaGamma::draw(g, (int)nt, eta);
+    acc += n_success[i] * eta - nt * log1pexp(eta);
+  }
+  const double tot = block_total_256(acc);
+  if (threadIdx.x == 0) ll_part[blockIdx.x] = tot;
+}
+
+// Polya-Gamma mean at the current linear predictor (logistic_model.py:80-87).
+__global__ __launch_bounds__(256) void chain_pg_mean_kernel(
+    int64_t n, const double* __restrict__ n_trial,
+    const double* __restrict__ psi, double* __restrict__ omega) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256) {
+    const double t = psi[i];
+    double m = n_trial[i] / 2.;
+    if (fabs(t) > 1e-5) m *= 1. / t * (exp(t) - 1.) / (exp(t) + 1.);
+    omega[i] = m;
+  }
+}
+
+// Residual sum of squares partials (linear model; bayesbridge.py:400-403).
+__global__ __launch_bounds__(256) void chain_rss_kernel(
+    int64_t n, const double* __restrict__ y, const double* __restrict__ psi,
+    double* __restrict__ part) {
+  double acc = 0.;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256) {
+    const double r = y[i] - psi[i];
+    acc += r * r;
+  }
+  const double tot = block_total_256(acc);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__device__ inline double sum_row_parts(const double* part, int count) {
+  // one block, fixed order
+  double acc = 0.;
+  for (int k = threadIdx.x; k < count; k += 256) acc += part[k];
+  return block_total_256(acc);
+}
+
+// Finishes the observation-level reductions (single block).
+//   logit : loglik = sum of partials
+//   linear: obs_prec ~ Gamma(n/2, 1) / (rss/2); loglik = n log(w)/2 - w rss/2
+//           (bayesbridge.py:400-404; linear_model.py:13-17); `init` => 1/mean
+__global__ __launch_bounds__(256) void chain_obs_finish_kernel(
+    int model, int init, int64_t n, uint64_t seed, uint64_t stream,
+    const double* __restrict__ part, int count, ChainScalars* __restrict__ sc) {
+  const double tot = sum_row_parts(part, count);
+  if (threadIdx.x != 0) return;
+  if (model == BBX_MODEL_LOGIT) {
+    sc->loglik = tot;
+  } else {
+    double w;
+    if (init) {
+      w = 1. / (tot / (double)n);
+    } else {
+      Philox g(seed, stream, 0);
+      const double obs_var = (tot / 2.) / gamma_draw(g, (double)n / 2.);
+      w = 1. / obs_var;
+    }
+    sc->obs_prec = w;
+    sc->loglik = (double)n * log(w) / 2. - w * tot / 2.;
+  }
+}
+
+__global__ __launch_bounds__(256) void chain_fill_obs_prec_kernel(
+    int64_t n, const ChainScalars* __restrict__ sc, double* __restrict__ omega) {
+  const double w = sc->obs_prec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256)
+    omega[i] = w;
+}
+
+// Partials of sum |beta_j|^alpha (shrunk), sum (beta_j/slab)^2 (all) and
+// sum (beta_j/sd_j)^2 (unshrunk).  Grid = NPART.
+__global__ __launch_bounds__(256) void chain_coef_sums_kernel(
+    int64_t P, int nu, double alpha, double slab,
+    const double* __restrict__ coef, const double* __restrict__ sd_unshrunk,
+    double* __restrict__ part_pow, double* __restrict__ part_slab,
+    double* __restrict__ part_fixed) {
+  double a = 0., b = 0., c = 0.;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < P;
+       j += (int64_t)gridDim.x * 256) {
+    const double x = coef[j];
+    const double xs = x / slab;
+    b += xs * xs;
+    if (j >= nu) {
+      a += pow(fabs(x), alpha);
+    } else {
+      const double xf = x / sd_unshrunk[j];
+      c += xf * xf;
+    }
+  }
+  const double ta = block_total_256(a);
+  const double tb = block_total_256(b);
+  const double tc = block_total_256(c);
+  if (threadIdx.x == 0) {
+    part_pow[blockIdx.x] = ta;
+    part_slab[blockIdx.x] = tb;
+    part_fixed[blockIdx.x] = tc;
+  }
+}
+
+// tau | beta: conjugate Gamma update of tau^-alpha (bayesbridge.py:412-448)
+// and, with the new tau, the log posterior (bayesbridge.py:480-511).
+__global__ __launch_bounds__(256) void chain_gscale_kernel(
+    int64_t n_shrunk, int nu, double alpha, double shape0, double rate0,
+    double lower_bd, uint64_t seed, uint64_t stream,
+    const double* __restrict__ part_pow, const double* __restrict__ part_slab,
+    const double* __restrict__ part_fixed,
+    const double* __restrict__ sd_unshrunk, ChainScalars* __restrict__ sc) {
+  const double pow_sum = sum_row_parts(part_pow, NPART);
+  const double slab_sum = sum_row_parts(part_slab, NPART);
+  const double fixed_sum = sum_row_parts(part_fixed, NPART);
+  if (threadIdx.x != 0) return;
+  double g = sc->gscale;
+  if (n_shrunk > 0) {
+    if (pow_sum == 0.) {
+      g = 0.;  // bayesbridge.py:430-431
+    } else {
+      const double shape = shape0 + (double)n_shrunk / alpha;
+      const double rate = rate0 + pow_sum;
+      Philox rng(seed, stream, 0);
+      const double ph = gamma_draw(rng, shape) / rate;
+      g = 1. / pow(ph, 1. / alpha);
+    }
+    if (g < lower_bd) {
+      g = lower_bd;
+      sc->n_gscale_clamped += 1;
+    }
+  } else {
+    g = 1.;  // bayesbridge.py:417-418 placeholder
+  }
+  sc->gscale = g;
+  sc->abs_pow_sum = pow_sum;
+  // log posterior with the NEW tau (bayesbridge.py:232-234,480-511)
+  double lp = sc->loglik - .5 * slab_sum;
+  double prior = 0.;
+  if (n_shrunk > 0)
+    prior += -(double)n_shrunk * log(g) - pow_sum / pow(g, alpha);
+  prior += -.5 * fixed_sum;
+  for (int j = 0; j < nu; ++j)
+    if (sd_unshrunk[j] < INFINITY) prior -= log(sd_unshrunk[j]);
+  prior += (shape0 - 1.) * log(g) - rate0 * g;
+  sc->logp = lp + prior;
+}
+
+// lambda_j | tau, beta_j (bayesbridge.py:458-478).
+__global__ __launch_bounds__(256) void chain_lscale_kernel(
+    int64_t n_shrunk, int nu, double alpha, uint64_t seed, uint64_t stream,
+    ChainScalars* __restrict__ sc, const double* __restrict__ coef,
+    double* __restrict__ lscale) {
+  const double g = sc->gscale;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n_shrunk;
+       j += (int64_t)gridDim.x * 256) {
+    if (alpha == 2.) {
+      lscale[j] = .5;  // bayesbridge.py:460-461
+      continue;
+    }
+    const double r = coef[j + nu] / g;
+    Philox rng(seed, stream, (uint64_t)j);
+    const double ts = TiltedStable::draw(rng, alpha / 2., r * r);
+    double l = sqrt(.5 / ts);
+    if (l == 0.) {
+      l = 10e-16;  // bayesbridge.py:470-472
+    } else if (isinf(l)) {
+      l = 2.0 / g;  // bayesbridge.py:473-476
+    }
+    lscale[j] = l;
+  }
+}
+
+__global__ void chain_store_scalars_kernel(const ChainScalars* __restrict__ sc,
+                                           int idx,
+                                           double* __restrict__ gs,
+                                           double* __restrict__ lp) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    gs[idx] = sc->gscale;
+    lp[idx] = sc->logp;
+  }
+}
+
+// kappa = n_success - n_trial/2 (bayesbridge.py:380 with Omega cancelled).
+__global__ __launch_bounds__(256) void chain_kappa_kernel(
+    int64_t n, const double* __restrict__ ns, const double* __restrict__ nt,
+    double* __restrict__ kappa) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256)
+    kappa[i] = ns[i] - nt[i] / 2.;
+}
+
+// -------------------------------------------- stand-alone sampler kernels
+
+__global__ __launch_bounds__(256) void dev_pg_kernel(
+    int64_t n, uint64_t seed, const int32_t* __restrict__ shape,
+    const double* __restrict__ tilt, double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256) {
+    Philox g(seed, STREAM_PG, (uint64_t)i);
+    out[i] = PolyaGamma::draw(g, shape[i], tilt[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void dev_ts_kernel(
+    int64_t n, uint64_t seed, double a, const double* __restrict__ tilt,
+    double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256) {
+    Philox g(seed, STREAM_LSCALE, (uint64_t)i);
+    out[i] = TiltedStable::draw(g, a, tilt[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void dev_gamma_kernel(
+    int64_t n, uint64_t seed, double shape, double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256) {
+    Philox g(seed, STREAM_GSCALE, (uint64_t)i);
+    out[i] = gamma_draw(g, shape);
+  }
+}
+
+// ------------------------------------------------------------ host helpers
+
+static inline uint64_t iter_stream(uint64_t stream, int64_t iter) {
+  return stream | ((uint64_t)iter << 8);
+}
+
+static int grid_for(int64_t len, int cap) {
+  int64_t nb = (len + 255) / 256;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+// psi = X~ coef
+static int chain_linear_predictor(bbx_chain* c) {
+  bbx_design* h = c->h;
+  BBX_TRY(launch_prep_v(h, c->coef.as<double>(), nullptr, nullptr,
+                        part_slot(h, PS_C)));
+  return launch_dot(h, c->coef.as<double>(), nullptr, c->psi.as<double>(),
+                    nullptr);
+}
+
+static int chain_check(const bbx_chain* c) {
+  if (!c || !c->h) return fail(BBX_ERR_INVALID, "chain handle is NULL");
+  return BBX_OK;
+}
+
+static double power_exp_ave_magnitude(double exponent) {
+  // prior.py:163-167
+  return std::tgamma(2. / exponent) / std::tgamma(1. / exponent);
+}
+
+// One Gibbs iteration (bayesbridge.py:210-240); returns the CG info (>= 0).
+static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
+  bbx_design* h = c->h;
+  hipStream_t s = h->stream;
+  const int64_t P = h->P, n = h->n;
+  const int nu = c->n_unshrunk;
+  const int64_t n_shrunk = P - nu;
+  ChainScalars* sc = c->scalars.as<ChainScalars>();
+  const uint64_t it = (uint64_t)c->iter;
+
+  // --- beta | Omega, tau, lambda  (bayesbridge.py:372-395)
+  hipLaunchKernelGGL(chain_prior_kernel, dim3(NPART), dim3(256), 0, s, P, nu,
+                     c->model, c->slab, (long long)c->n_averaged, sc,
+                     c->lscale.as<double>(), c->sd_unshrunk.as<double>(),
+                     c->mean.as<double>(), c->square.as<double>(),
+                     c->zbase.as<double>(), c->phi.as<double>(),
+                     c->x0.as<double>(), c->sd.as<double>(), c->z.as<double>());
+  if (c->model == BBX_MODEL_LINEAR)
+    hipLaunchKernelGGL(chain_fill_obs_prec_kernel, dim3(grid_for(n, ROW_GRID)),
+                       dim3(256), 0, s, n, sc, c->obs_prec.as<double>());
+  BBX_HIP(hipGetLastError());
+  int info = 0;
+  int st = cg_sample_device(
+      h, c->obs_prec.as<double>(), c->phi.as<double>(), c->z.as<double>(),
+      c->x0.as<double>(), c->sd.as<double>(), nu, nullptr, nullptr,
+      c->seed + 0x9E3779B97F4A7C15ull * (it + 1), maxiter, atol,
+      c->coef.as<double>(), n_cg_iter, &info);
+  if (st < 0) return st;
+  hipLaunchKernelGGL(chain_summary_kernel, dim3(NPART), dim3(256), 0, s, P, nu,
+                     c->slab, (long long)c->n_averaged, sc,
+                     c->lscale.as<double>(), c->coef.as<double>(),
+                     c->mean.as<double>(), c->square.as<double>());
+  c->n_averaged += 1;
+
+  // --- Omega | beta  (bayesbridge.py:397-410)
+  BBX_TRY(chain_linear_predictor(c));
+  const int rg = grid_for(n, ROW_GRID);
+  double* rp = c->row_part.as<double>();
+  if (c->model == BBX_MODEL_LOGIT) {
+    hipLaunchKernelGGL(chain_pg_kernel, dim3(rg), dim3(256), 0, s, n, c->seed,
+                       iter_stream(STREAM_PG, c->iter),
+                       c->outcome.as<double>(), c->n_trial.as<double>(),
+                       c->psi.as<double>(), c->obs_prec.as<double>(), rp);
+  } else {
+    hipLaunchKernelGGL(chain_rss_kernel, dim3(rg), dim3(256), 0, s, n,
+                       c->outcome.as<double>(), c->psi.as<double>(), rp);
+  }
+  hipLaunchKernelGGL(chain_obs_finish_kernel, dim3(1), dim3(256), 0, s,
+                     c->model, 0, n, c->seed,
+                     iter_stream(STREAM_OBSVAR, c->iter), rp, rg, sc);
+
+  // --- tau | beta, then lambda | tau, beta, then log posterior
+  double* pp = part_slot(h, PS_MISC);
+  hipLaunchKernelGGL(chain_coef_sums_kernel, dim3(NPART), dim3(256), 0, s, P,
+                     nu, c->bridge_exp, c->slab, c->coef.as<double>(),
+                     c->sd_unshrunk.as<double>(), pp, pp + NPART,
+                     pp + 2 * NPART);
+  const double lower_bd = .001 / power_exp_ave_magnitude(c->bridge_exp);
+  hipLaunchKernelGGL(chain_gscale_kernel, dim3(1), dim3(256), 0, s, n_shrunk,
+                     nu, c->bridge_exp, c->shape0, c->rate0, lower_bd, c->seed,
+                     iter_stream(STREAM_GSCALE, c->iter), pp, pp + NPART,
+                     pp + 2 * NPART, c->sd_unshrunk.as<double>(), sc);
+  if (n_shrunk > 0)
+    hipLaunchKernelGGL(chain_lscale_kernel,
+                       dim3(grid_for(n_shrunk, ROW_GRID)), dim3(256), 0, s,
+                       n_shrunk, nu, c->bridge_exp, c->seed,
+                       iter_stream(STREAM_LSCALE, c->iter), sc,
+                       c->coef.as<double>(), c->lscale.as<double>());
+  BBX_HIP(hipGetLastError());
+  c->iter += 1;
+  return info;
+}
+
+}  // namespace bbx
+
+using namespace bbx;
+
+extern "C" {
+
+int bbx_chain_create(bbx_design* design, int model, const double* outcome,
+                     const double* n_trial, int n_unshrunk,
+                     const double* sd_unshrunk, double bridge_exp,
+                     double slab_size, double gscale_shape0,
+                     double gscale_rate0, uint64_t seed, bbx_chain** out) {
+  if (!out) return fail(BBX_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!design || !outcome) return fail(BBX_ERR_INVALID, "NULL argument");
+  if (model != BBX_MODEL_LINEAR && model != BBX_MODEL_LOGIT)
+    return fail(BBX_ERR_INVALID, "unknown model");
+  if (n_unshrunk < 0 || n_unshrunk > design->P)
+    return fail(BBX_ERR_INVALID, "n_unshrunk out of range");
+  if (n_unshrunk > 0 && !sd_unshrunk)
+    return fail(BBX_ERR_INVALID, "sd_unshrunk is NULL");
+  if (!(bridge_exp > 0.) || bridge_exp > 2.)
+    return fail(BBX_ERR_INVALID, "bridge exponent must be in (0, 2]");
+  bbx_design* h = design;
+  BBX_HIP(hipSetDevice(h->device));
+  bbx_chain* c = new (std::nothrow) bbx_chain();
+  if (!c) return fail(BBX_ERR_INVALID, "out of host memory");
+  c->h = h;
+  c->model = model;
+  c->n_unshrunk = n_unshrunk;
+  c->bridge_exp = bridge_exp;
+  c->slab = slab_size;
+  c->shape0 = gscale_shape0;
+  c->rate0 = gscale_rate0;
+  c->seed = seed;
+  const int64_t n = h->n, P = h->P;
+  const size_t nb = sizeof(double) * (size_t)n, Pb = sizeof(double) * (size_t)P;
+  auto body = [&]() -> int {
+    BBX_TRY(c->outcome.alloc(nb));
+    BBX_TRY(c->n_trial.alloc(nb));
+    BBX_TRY(c->kappa.alloc(nb));
+    BBX_TRY(c->obs_prec.alloc(nb));
+    BBX_TRY(c->psi.alloc(nb));
+    for (DevMem* m : {&c->zbase, &c->coef, &c->phi, &c->x0, &c->sd, &c->z,
+                      &c->mean, &c->square})
+      BBX_TRY(m->alloc(Pb));
+    BBX_TRY(c->sd_unshrunk.alloc(sizeof(double) * (size_t)(n_unshrunk + 1)));
+    BBX_TRY(c->lscale.alloc(sizeof(double) * (size_t)(P - n_unshrunk + 1)));
+    BBX_TRY(c->scalars.alloc(sizeof(ChainScalars)));
+    BBX_TRY(c->row_part.alloc(sizeof(double) * ROW_GRID * 2));
+    BBX_HIP(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
+    BBX_HIP(hipMemcpy(c->outcome.ptr, outcome, nb, hipMemcpyHostToDevice));
+    if (model == BBX_MODEL_LOGIT) {
+      if (n_trial) {
+        BBX_HIP(hipMemcpy(c->n_trial.ptr, n_trial, nb, hipMemcpyHostToDevice));
+      } else {
+        std::vector<double> ones((size_t)n, 1.);
+        BBX_HIP(hipMemcpy(c->n_trial.ptr, ones.data(), nb,
+                          hipMemcpyHostToDevice));
+      }
+    }
+    if (n_unshrunk > 0)
+      BBX_HIP(hipMemcpy(c->sd_unshrunk.ptr, sd_unshrunk,
+                        sizeof(double) * (size_t)n_unshrunk,
+                        hipMemcpyHostToDevice));
+    // zbase = X~^T kappa (logit; bayesbridge.py:380 + reg_coef_sampler.py:74:
+    // Omega cancels) or X~^T y (linear; scaled by obs_prec each iteration).
+    const double* src = c->outcome.as<double>();
+    if (model == BBX_MODEL_LOGIT) {
+      hipLaunchKernelGGL(chain_kappa_kernel, dim3(grid_for(n, ROW_GRID)),
+                         dim3(256), 0, h->stream, n, c->outcome.as<double>(),
+                         c->n_trial.as<double>(), c->kappa.as<double>());
+      src = c->kappa.as<double>();
+    }
+    BBX_TRY(launch_sum_n(h, src, n, part_slot(h, PS_SUMW)));
+    TdotEpilogue ep;
+    BBX_TRY(launch_tdot(h, src, part_slot(h, PS_SUMW), ep,
+                        c->zbase.as<double>()));
+    // summariser initial state (reg_coef_posterior_summarizer.py:88-91)
+    BBX_HIP(hipMemsetAsync(c->mean.ptr, 0, Pb, h->stream));
+    std::vector<double> ones((size_t)P, 1.);
+    BBX_HIP(hipMemcpyAsync(c->square.ptr, ones.data(), Pb,
+                           hipMemcpyHostToDevice, h->stream));
+    BBX_HIP(hipMemsetAsync(c->coef.ptr, 0, Pb, h->stream));
+    BBX_HIP(hipMemcpyAsync(c->lscale.ptr, ones.data(),
+                           sizeof(double) * (size_t)(P - n_unshrunk),
+                           hipMemcpyHostToDevice, h->stream));
+    ChainScalars init{};
+    init.gscale = 1.;
+    init.obs_prec = 1.;
+    BBX_HIP(hipMemcpyAsync(c->scalars.ptr, &init, sizeof(init),
+                           hipMemcpyHostToDevice, h->stream));
+    BBX_HIP(hipStreamSynchronize(h->stream));
+    return BBX_OK;
+  };
+  int st = body();
+  if (st < 0) {
+    bbx_chain_destroy(c);
+    return st;
+  }
+  *out = c;
+  return BBX_OK;
+}
+
+int bbx_chain_destroy(bbx_chain* c) {
+  if (!c) return BBX_OK;
+  if (c->h) {
+    (void)hipSetDevice(c->h->device);
+    (void)hipStreamSynchronize(c->h->stream);
+  }
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  delete c;
+  return BBX_OK;
+}
+
+int bbx_chain_set_state(bbx_chain* c, const double* coef,
+                        const double* obs_prec, const double* lscale,
+                        const double* gscale) {
+  BBX_TRY(chain_check(c));
+  bbx_design* h = c->h;
+  BBX_HIP(hipSetDevice(h->device));
+  if (coef)
+    BBX_HIP(hipMemcpy(c->coef.ptr, coef, sizeof(double) * (size_t)h->P,
+                      hipMemcpyHostToDevice));
+  ChainScalars sc;
+  BBX_HIP(hipMemcpy(&sc, c->scalars.ptr, sizeof(sc), hipMemcpyDeviceToHost));
+  if (obs_prec) {
+    if (c->model == BBX_MODEL_LOGIT)
+      BBX_HIP(hipMemcpy(c->obs_prec.ptr, obs_prec,
+                        sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice));
+    else
+      sc.obs_prec = obs_prec[0];
+  }
+  if (lscale && h->P > c->n_unshrunk)
+    BBX_HIP(hipMemcpy(c->lscale.ptr, lscale,
+                      sizeof(double) * (size_t)(h->P - c->n_unshrunk),
+                      hipMemcpyHostToDevice));
+  if (gscale) sc.gscale = *gscale;
+  BBX_HIP(hipMemcpy(c->scalars.ptr, &sc, sizeof(sc), hipMemcpyHostToDevice));
+  return BBX_OK;
+}
+
+int bbx_chain_get_state(bbx_chain* c, double* coef, double* obs_prec,
+                        double* lscale, double* gscale) {
+  BBX_TRY(chain_check(c));
+  bbx_design* h = c->h;
+  BBX_HIP(hipSetDevice(h->device));
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  if (coef)
+    BBX_HIP(hipMemcpy(coef, c->coef.ptr, sizeof(double) * (size_t)h->P,
+                      hipMemcpyDeviceToHost));
+  ChainScalars sc;
+  BBX_HIP(hipMemcpy(&sc, c->scalars.ptr, sizeof(sc), hipMemcpyDeviceToHost));
+  if (obs_prec) {
+    if (c->model == BBX_MODEL_LOGIT)
+      BBX_HIP(hipMemcpy(obs_prec, c->obs_prec.ptr,
+                        sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost));
+    else
+      obs_prec[0] = sc.obs_prec;
+  }
+  if (lscale && h->P > c->n_unshrunk)
+    BBX_HIP(hipMemcpy(lscale, c->lscale.ptr,
+                      sizeof(double) * (size_t)(h->P - c->n_unshrunk),
+                      hipMemcpyDeviceToHost));
+  if (gscale) *gscale = sc.gscale;
+  return BBX_OK;
+}
+
+int bbx_chain_set_summary(bbx_chain* c, const double* mean,
+                          const double* square, int64_t n_averaged) {
+  BBX_TRY(chain_check(c));
+  if (!mean || !square || n_averaged < 0)
+    return fail(BBX_ERR_INVALID, "bad summary");
+  BBX_HIP(hipSetDevice(c->h->device));
+  const size_t Pb = sizeof(double) * (size_t)c->h->P;
+  BBX_HIP(hipMemcpy(c->mean.ptr, mean, Pb, hipMemcpyHostToDevice));
+  BBX_HIP(hipMemcpy(c->square.ptr, square, Pb, hipMemcpyHostToDevice));
+  c->n_averaged = n_averaged;
+  return BBX_OK;
+}
+
+int bbx_chain_get_summary(bbx_chain* c, double* mean, double* square,
+                          int64_t* n_averaged) {
+  BBX_TRY(chain_check(c));
+  BBX_HIP(hipSetDevice(c->h->device));
+  BBX_HIP(hipStreamSynchronize(c->h->stream));
+  const size_t Pb = sizeof(double) * (size_t)c->h->P;
+  if (mean) BBX_HIP(hipMemcpy(mean, c->mean.ptr, Pb, hipMemcpyDeviceToHost));
+  if (square)
+    BBX_HIP(hipMemcpy(square, c->square.ptr, Pb, hipMemcpyDeviceToHost));
+  if (n_averaged) *n_averaged = c->n_averaged;
+  return BBX_OK;
+}
+
+int bbx_chain_get_iteration(bbx_chain* c, int64_t* iteration) {
+  BBX_TRY(chain_check(c));
+  if (iteration) *iteration = c->iter;
+  return BBX_OK;
+}
+
+int bbx_chain_set_iteration(bbx_chain* c, int64_t iteration) {
+  BBX_TRY(chain_check(c));
+  if (iteration < 0) return fail(BBX_ERR_INVALID, "iteration < 0");
+  c->iter = iteration;
+  return BBX_OK;
+}
+
+int bbx_chain_init_obs_prec(bbx_chain* c) {
+  BBX_TRY(chain_check(c));
+  bbx_design* h = c->h;
+  BBX_HIP(hipSetDevice(h->device));
+  BBX_TRY(chain_linear_predictor(c));
+  const int rg = grid_for(h->n, ROW_GRID);
+  if (c->model == BBX_MODEL_LOGIT) {
+    hipLaunchKernelGGL(chain_pg_mean_kernel, dim3(rg), dim3(256), 0, h->stream,
+                       h->n, c->n_trial.as<double>(), c->psi.as<double>(),
+                       c->obs_prec.as<double>());
+  } else {
+    double* rp = c->row_part.as<double>();
+    hipLaunchKernelGGL(chain_rss_kernel, dim3(rg), dim3(256), 0, h->stream,
+                       h->n, c->outcome.as<double>(), c->psi.as<double>(), rp);
+    hipLaunchKernelGGL(chain_obs_finish_kernel, dim3(1), dim3(256), 0,
+                       h->stream, c->model, 1, h->n, c->seed, 0, rp, rg,
+                       c->scalars.as<ChainScalars>());
+  }
+  BBX_HIP(hipGetLastError());
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  return BBX_OK;
+}
+
+int bbx_chain_run(bbx_chain* c, int n_iter, int n_burnin, int thin,
+                  int maxiter, double atol, double* d_coef, double* d_lscale,
+                  double* d_obs_prec, double* gscale, double* logp,
+                  double* n_cg_iter) {
+  BBX_TRY(chain_check(c));
+  if (n_iter < 0 || n_burnin < 0 || thin < 1 || n_burnin > n_iter)
+    return fail(BBX_ERR_INVALID, "bad n_iter / n_burnin / thin");
+  bbx_design* h = c->h;
+  BBX_HIP(hipSetDevice(h->device));
+  const int64_t P = h->P, n = h->n;
+  if (maxiter <= 0) maxiter = 500;                      // reg_coef_sampler.py:95
+  if (!(atol > 0.)) atol = 10e-6 * std::sqrt((double)P);
+  const int n_sample = (n_iter - n_burnin) / thin;
+  BBX_TRY(c->samp_gscale.alloc(sizeof(double) * (size_t)(n_sample + 1)));
+  BBX_TRY(c->samp_logp.alloc(sizeof(double) * (size_t)(n_sample + 1)));
+  const int64_t n_shrunk = P - c->n_unshrunk;
+  int n_unconverged = 0;
+  for (int it = 1; it <= n_iter; ++it) {
+    int ncg = 0;
+    int info = chain_step(c, maxiter, atol, &ncg);
+    if (info < 0) return info;
+    if (info > 0) ++n_unconverged;
+    if (it <= n_burnin || (it - n_burnin) % thin != 0) continue;
+    const int idx = (it - n_burnin) / thin - 1;  // gibbs_util.py:170
+    if (idx >= n_sample) continue;
+    if (d_coef)
+      BBX_HIP(hipMemcpyAsync(d_coef + (size_t)idx * P, c->coef.ptr,
+                             sizeof(double) * (size_t)P,
+                             hipMemcpyDeviceToDevice, h->stream));
+    if (d_lscale && n_shrunk > 0)
+      BBX_HIP(hipMemcpyAsync(d_lscale + (size_t)idx * n_shrunk, c->lscale.ptr,
+                             sizeof(double) * (size_t)n_shrunk,
+                             hipMemcpyDeviceToDevice, h->stream));
+    if (d_obs_prec) {
+      if (c->model == BBX_MODEL_LOGIT)
+        BBX_HIP(hipMemcpyAsync(d_obs_prec + (size_t)idx * n, c->obs_prec.ptr,
+                               sizeof(double) * (size_t)n,
+                               hipMemcpyDeviceToDevice, h->stream));
+      else
+        BBX_HIP(hipMemcpyAsync(
+            d_obs_prec + idx,
+            &c->scalars.as<ChainScalars>()->obs_prec, sizeof(double),
+            hipMemcpyDeviceToDevice, h->stream));
+    }
+    hipLaunchKernelGGL(chain_store_scalars_kernel, dim3(1), dim3(64), 0,
+                       h->stream, c->scalars.as<ChainScalars>(), idx,
+                       c->samp_gscale.as<double>(), c->samp_logp.as<double>());
+    if (n_cg_iter) n_cg_iter[idx] = (double)ncg;
+  }
+  BBX_HIP(hipGetLastError());
+  if (gscale && n_sample > 0)
+    BBX_HIP(hipMemcpyAsync(gscale, c->samp_gscale.ptr,
+                           sizeof(double) * (size_t)n_sample,
+                           hipMemcpyDeviceToHost, h->stream));
+  if (logp && n_sample > 0)
+    BBX_HIP(hipMemcpyAsync(logp, c->samp_logp.ptr,
+                           sizeof(double) * (size_t)n_sample,
+                           hipMemcpyDeviceToHost, h->stream));
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  return n_unconverged;
+}
+
+int bbx_chain_run_host(bbx_chain* c, int n_iter, int n_burnin, int thin,
+                       int maxiter, double atol, double* coef, double* lscale,
+                       double* obs_prec, double* gscale, double* logp,
+                       double* n_cg_iter) {
+  BBX_TRY(chain_check(c));
+  if (n_iter < 0 || n_burnin < 0 || thin < 1 || n_burnin > n_iter)
+    return fail(BBX_ERR_INVALID, "bad n_iter / n_burnin / thin");
+  bbx_design* h = c->h;
+  BBX_HIP(hipSetDevice(h->device));
+  const int64_t P = h->P, n = h->n;
+  const int64_t n_sample = (n_iter - n_burnin) / thin;
+  const int64_t n_shrunk = P - c->n_unshrunk;
+  const int64_t op_len = (c->model == BBX_MODEL_LOGIT) ? n : 1;
+  DevMem dc, dl, dp;
+  if (coef) BBX_TRY(dc.alloc(sizeof(double) * (size_t)(n_sample * P + 1)));
+  if (lscale)
+    BBX_TRY(dl.alloc(sizeof(double) * (size_t)(n_sample * n_shrunk + 1)));
+  if (obs_prec)
+    BBX_TRY(dp.alloc(sizeof(double) * (size_t)(n_sample * op_len + 1)));
+  int st = bbx_chain_run(c, n_iter, n_burnin, thin, maxiter, atol,
+                         coef ? dc.as<double>() : nullptr,
+                         lscale ? dl.as<double>() : nullptr,
+                         obs_prec ? dp.as<double>() : nullptr, gscale, logp,
+                         n_cg_iter);
+  if (st < 0) return st;
+  if (coef && n_sample > 0)
+    BBX_HIP(hipMemcpy(coef, dc.ptr, sizeof(double) * (size_t)(n_sample * P),
+                      hipMemcpyDeviceToHost));
+  if (lscale && n_sample * n_shrunk > 0)
+    BBX_HIP(hipMemcpy(lscale, dl.ptr,
+                      sizeof(double) * (size_t)(n_sample * n_shrunk),
+                      hipMemcpyDeviceToHost));
+  if (obs_prec && n_sample > 0)
+    BBX_HIP(hipMemcpy(obs_prec, dp.ptr,
+                      sizeof(double) * (size_t)(n_sample * op_len),
+                      hipMemcpyDeviceToHost));
+  return st;
+}
+
+// ---- stand-alone device samplers (distribution tests)
+
+static int dev_sampler_common(int device, int64_t n_draw) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(BBX_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= count)
+    return fail(BBX_ERR_INVALID, "device index out of range");
+  if (n_draw < 0) return fail(BBX_ERR_INVALID, "n_draw < 0");
+  BBX_HIP(hipSetDevice(device));
+  return BBX_OK;
+}
+
+int bbx_device_polya_gamma(int device, uint64_t seed, int64_t n_draw,
+                           const int32_t* shape, const double* tilt,
+                           double* out) {
+  BBX_TRY(dev_sampler_common(device, n_draw));
+  if (n_draw == 0) return BBX_OK;
+  if (!shape || !tilt || !out) return fail(BBX_ERR_INVALID, "NULL argument");
+  DevMem ds, dt, dout;
+  BBX_TRY(ds.alloc(sizeof(int32_t) * (size_t)n_draw));
+  BBX_TRY(dt.alloc(sizeof(double) * (size_t)n_draw));
+  BBX_TRY(dout.alloc(sizeof(double) * (size_t)n_draw));
+  BBX_HIP(hipMemcpy(ds.ptr, shape, sizeof(int32_t) * (size_t)n_draw,
+                    hipMemcpyHostToDevice));
+  BBX_HIP(hipMemcpy(dt.ptr, tilt, sizeof(double) * (size_t)n_draw,
+                    hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(dev_pg_kernel, dim3(grid_for(n_draw, 4096)), dim3(256), 0,
+                     0, n_draw, seed, ds.as<int32_t>(), dt.as<double>(),
+                     dout.as<double>());
+  BBX_HIP(hipGetLastError());
+  BBX_HIP(hipMemcpy(out, dout.ptr, sizeof(double) * (size_t)n_draw,
+                    hipMemcpyDeviceToHost));
+  return BBX_OK;
+}
+
+int bbx_device_tilted_stable(int device, uint64_t seed, int64_t n_draw,
+                             double char_exp, const double* tilt,
+                             double* out) {
+  BBX_TRY(dev_sampler_common(device, n_draw));
+  if (n_draw == 0) return BBX_OK;
+  if (!tilt || !out) return fail(BBX_ERR_INVALID, "NULL argument");
+  if (!(char_exp > 0.) || !(char_exp < 1.))
+    return fail(BBX_ERR_INVALID, "characteristic exponent must be in (0,1)");
+  DevMem dt, dout;
+  BBX_TRY(dt.alloc(sizeof(double) * (size_t)n_draw));
+  BBX_TRY(dout.alloc(sizeof(double) * (size_t)n_draw));
+  BBX_HIP(hipMemcpy(dt.ptr, tilt, sizeof(double) * (size_t)n_draw,
+                    hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(dev_ts_kernel, dim3(grid_for(n_draw, 4096)), dim3(256), 0,
+                     0, n_draw, seed, char_exp, dt.as<double>(),
+                     dout.as<double>());
+  BBX_HIP(hipGetLastError());
+  BBX_HIP(hipMemcpy(out, dout.ptr, sizeof(double) * (size_t)n_draw,
+                    hipMemcpyDeviceToHost));
+  return BBX_OK;
+}
+
+int bbx_device_gamma(int device, uint64_t seed, int64_t n_draw, double shape,
+                     double* out) {
+  BBX_TRY(dev_sampler_common(device, n_draw));
+  if (n_draw == 0) return BBX_OK;
+  if (!out || !(shape > 0.)) return fail(BBX_ERR_INVALID, "bad argument");
+  DevMem dout;
+  BBX_TRY(dout.alloc(sizeof(double) * (size_t)n_draw));
+  hipLaunchKernelGGL(dev_gamma_kernel, dim3(grid_for(n_draw, 4096)), dim3(256),
+                     0, 0, n_draw, seed, shape, dout.as<double>());
+  BBX_HIP(hipGetLastError());
+  BBX_HIP(hipMemcpy(out, dout.ptr, sizeof(double) * (size_t)n_draw,
+                    hipMemcpyDeviceToHost));
+  return BBX_OK;
+}
+
+}  // extern "C"

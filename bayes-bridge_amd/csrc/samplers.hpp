@@ -1,0 +1,364 @@
+// Scalar samplers of the Gibbs steps that surround the CG draw, written once
+// for host and device: Polya-Gamma (Omega update), exponentially tilted stable
+// (local scales) and Gamma (global scale / observation variance).
+//
+// They are templates over a generator G providing `double uniform()` and
+// `double normal()`.  Instantiated with bbx::Philox they run on the MI355X
+// (distribution parity with the reference); instantiated on the host with
+// NumPy's PCG64 bit generator they consume the stream in exactly the order of
+// the reference's Cython code, which is what the exact-seed parity mode and
+// the CPU tests against the reference rely on (hostrng.cpp).
+//
+// Algorithms follow (same random-number consumption order):
+//   random/polya_gamma/polya_gamma.pyx:94-216  (Devroye alternating series for
+//       the tilted Jacobi law; Polson, Scott & Windle 2013 eqs. 12-13;
+//       Windle's thesis alg. 3 for the truncated inverse Gaussian)
+//   random/tilted_stable/tilted_stable.pyx:136-331 (Hofert 2011 divide &
+//       conquer; Devroye 2009 double rejection)
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BBX_HD __host__ __device__
+#else
+#define BBX_HD
+#endif
+
+namespace bbx {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// log of the standard normal cdf.  The reference vendors Cephes' log_ndtr
+// (random/polya_gamma/scipy_ndtr.c:367): log(ndtr(a)) above -20 and an
+// asymptotic series below; same split here on top of erfc.
+BBX_HD inline double log_norm_cdf(double a) {
+  if (a > 6.) return -0.5 * erfc(a * 0.70710678118654752440);  // log(1-e) ~ -e
+  if (a > -20.) return log(0.5 * erfc(-a * 0.70710678118654752440));
+  const double log_lhs = -0.5 * a * a - log(-a) - 0.91893853320467274178;
+  const double denom_factor = 1.0 / (a * a);
+  double last_total = 0., right_hand_side = 1., numerator = 1.;
+  double denom_cons = 1.;
+  long sign = 1, i = 0;
+  while (fabs(last_total - right_hand_side) > 2.220446049250313e-16) {
+    i += 1;
+    last_total = right_hand_side;
+    sign = -sign;
+    denom_cons *= denom_factor;
+    numerator *= (double)(2 * i - 1);
+    right_hand_side += (double)sign * numerator * denom_cons;
+    if (i > 50) break;
+  }
+  return log_lhs + log(right_hand_side);
+}
+
+// ------------------------------------------------------------ Polya-Gamma
+
+struct PolyaGamma {
+  static constexpr double kCut = 2.0 / kPi;  // inverse-Gaussian | exponential
+  static constexpr int kMaxTerms = 100;
+
+  // n-th coefficient of the alternating series at x (polya_gamma.pyx:131-137).
+  BBX_HD static inline double series_term(int n, double x) {
+    const double h = n + 0.5;
+    double lg = log(kPi * h);
+    if (x <= kCut)
+      lg += -1.5 * log(0.5 * x * kPi) - 2. * h * h / x;
+    else
+      lg += -0.5 * x * kPi * kPi * h * h;
+    return exp(lg);
+  }
+
+  // Probability that the proposal comes from the exponential piece
+  // (polya_gamma.pyx:115-128).
+  BBX_HD static inline double right_mass(double z, double rate) {
+    const double lm_exp = -log(rate) - rate * kCut + log(0.25 * kPi);
+    const double sq = sqrt(kCut);
+    const double lm_ig1 = -z + log_norm_cdf((kCut * z - 1.) / sq);
+    const double lm_ig2 = z + log_norm_cdf(-(kCut * z + 1.) / sq);
+    const double ratio = exp(lm_ig1 - lm_exp) + exp(lm_ig2 - lm_exp);
+    return 1.0 / (1.0 + ratio);
+  }
+
+  template <class G>
+  BBX_HD static inline double trunc_exp(G& g, double scale, double cut) {
+    return cut - scale * log(1.0 - g.uniform());  // polya_gamma.pyx:164-165
+  }
+
+  // chi-square(1) restricted to [cut, inf) (polya_gamma.pyx:169-176).
+  template <class G>
+  BBX_HD static inline double trunc_chisq(G& g, double cut) {
+    for (;;) {
+      const double x = trunc_exp(g, 2., cut);
+      const double ratio = sqrt(0.5 * kPi / x);
+      if (g.uniform() <= ratio) return x;
+    }
+  }
+
+  // Inverse Gaussian(mean, shape 1) (polya_gamma.pyx:200-207).
+  template <class G>
+  BBX_HD static inline double inv_gauss(G& g, double mean) {
+    const double nrm = g.normal();
+    const double v = nrm * nrm;
+    double x = mean + 0.5 * mean *
+                          (mean * v - sqrt(4.0 * mean * v + mean * mean * v * v));
+    if (g.uniform() > mean / (mean + x)) x = mean * mean / x;
+    return x;
+  }
+
+  // Inverse Gaussian(1/z, 1) restricted to (0, cut) (polya_gamma.pyx:179-198).
+  template <class G>
+  BBX_HD static inline double trunc_inv_gauss(G& g, double z, double cut) {
+    const double mean = 1. / z;
+    double x;
+    if (mean > cut) {
+      for (;;) {
+        x = 1.0 / trunc_chisq(g, 0.5 * kPi);
+        if (log(g.uniform()) < -0.5 * x * z * z) break;
+      }
+    } else {
+      for (;;) {
+        x = inv_gauss(g, mean);
+        if (x < cut) break;
+      }
+    }
+    return x;
+  }
+
+  // Tilted Jacobi J*(1, z) (polya_gamma.pyx:86-111,139-162).
+  template <class G>
+  BBX_HD static inline double jacobi(G& g, double z) {
+    const double rate = 0.5 * z * z + 0.125 * kPi * kPi;
+    for (;;) {
+      const double p_right = right_mass(z, rate);
+      double x;
+      if (g.uniform() < p_right)
+        x = trunc_exp(g, 1. / rate, kCut);
+      else
+        x = trunc_inv_gauss(g, z, kCut);
+      const double first = series_term(0, x);
+      const double u = g.uniform() * first;
+      double partial = first;
+      int n_summed = 1;
+      int sign = -1;
+      bool accepted = true;
+      for (;;) {
+        partial += sign * series_term(n_summed, x);
+        n_summed += 1;
+        if (sign == -1) {
+          if (u <= partial) { accepted = true; break; }
+        } else {
+          if (u > partial) { accepted = false; break; }
+          if (n_summed >= kMaxTerms) { accepted = true; break; }
+        }
+        sign = -sign;
+      }
+      if (accepted) return x;
+    }
+  }
+
+  // PG(shape, tilt) for integer shape: sum of PG(1, tilt)
+  // (polya_gamma.pyx:70-73,83-84).
+  template <class G>
+  BBX_HD static inline double draw(G& g, int shape, double tilt) {
+    double acc = 0.;
+    const double z = 0.5 * fabs(tilt);
+    for (int j = 0; j < shape; ++j) acc += 0.25 * jacobi(g, z);
+    return acc;
+  }
+};
+
+// --------------------------------------------- exponentially tilted stable
+
+struct TiltedStable {
+  static constexpr double kMaxExpArg = 709.;
+  static constexpr double kCostThreshold = 2.;  // tilted_stable.pyx:53
+
+  BBX_HD static inline double safe_exp(double x) {  // tilted_stable.pyx:19-26
+    if (x > kMaxExpArg) return INFINITY;
+    if (x < -kMaxExpArg) return 0.;
+    return exp(x);
+  }
+
+  BBX_HD static inline double sinc(double x) {  // tilted_stable.pyx:29-38
+    if (fabs(x) < .01) {
+      const double x2 = x * x;
+      return 1. - x2 / 6. * (1 - x2 / 20.);
+    }
+    return sin(x) / x;
+  }
+
+  // Zolotarev's function A(x)^{1/(1-a)} (tilted_stable.pyx:324-331).
+  BBX_HD static inline double zolotarev(double x, double a) {
+    return pow(pow((1. - a) * sinc((1. - a) * x), (1. - a)) *
+                   pow(a * sinc(a * x), a) / sinc(x),
+               1. / (1. - a));
+  }
+
+  // tilted_stable.pyx:313-322
+  BBX_HD static inline double zolotarev_pdf_pow(double x, double a) {
+    const double denom = pow(sinc(a * x), a) * pow(sinc((1. - a) * x), (1. - a));
+    return sinc(x) / denom;
+  }
+
+  // Untilted positive stable via Kanter/Zolotarev (tilted_stable.pyx:156-163).
+  template <class G>
+  BBX_HD static inline double untilted(G& g, double a) {
+    const double zf = zolotarev(kPi * g.uniform(), a);
+    const double lg = log(g.uniform());
+    return pow(-zf / lg, (1. - a) / a);
+  }
+
+  // Hofert's divide and conquer (tilted_stable.pyx:136-154).
+  template <class G>
+  BBX_HD static inline double divide_conquer(G& g, double a, double tilt) {
+    long parts = (long)floor(pow(tilt, a));
+    if (parts < 1) parts = 1;
+    const double c = pow(1. / parts, 1. / a);
+    double x = 0.;
+    for (long i = 0; i < parts; ++i) {
+      for (;;) {
+        const double s = c * untilted(g, a);
+        const double accept = safe_exp(-tilt * s);
+        if (g.uniform() < accept) { x += s; break; }
+      }
+    }
+    return x;
+  }
+
+  // tilted_stable.pyx:216-241
+  template <class G>
+  BBX_HD static inline double aux2(G& g, double xi, double psi, double gamma) {
+    const double w1 = sqrt(.5 * kPi / gamma) * xi;
+    const double w2 = 2. * sqrt(kPi) * psi;
+    const double w3 = xi * kPi;
+    const double v = g.uniform();
+    double u;
+    if (gamma >= 1) {
+      if (v < w1 / (w1 + w2)) {
+        u = fabs(g.normal()) / sqrt(gamma);
+      } else {
+        const double w = g.uniform();
+        u = kPi * (1. - w * w);
+      }
+    } else {
+      const double w = g.uniform();
+      if (v < w3 / (w2 + w3))
+        u = kPi * w;
+      else
+        u = kPi * (1. - w * w);
+    }
+    return u;
+  }
+
+  // tilted_stable.pyx:243-259
+  BBX_HD static inline double aux2_accept(double u, double xi, double psi,
+                                          double zeta, double z,
+                                          double tilt_pow, double gamma) {
+    double inv = kPi * safe_exp(-tilt_pow * (1. - 1. / (zeta * zeta))) /
+                 ((1. + sqrt(.5 * kPi)) * sqrt(gamma) / zeta + z);
+    double d = 0.;
+    if (u >= 0. && gamma >= 1) d += xi * safe_exp(-gamma * u * u / 2.);
+    if (u > 0. && u < kPi) d += psi / sqrt(kPi - u);
+    if (u >= 0. && u <= kPi && gamma < 1.) d += xi;
+    inv *= d;
+    return 1 / inv;
+  }
+
+  // Devroye's double rejection (tilted_stable.pyx:165-311).
+  template <class G>
+  BBX_HD static inline double double_rejection(G& g, double a, double tilt) {
+    const double tilt_pow = pow(tilt, a);
+    const double odds = (1. - a) / a;
+    for (;;) {
+      // --- auxiliary variable U (tilted_stable.pyx:181-214)
+      const double gamma = tilt_pow * a * (1. - a);
+      const double xi = (1. + sqrt(2. * gamma) * (2. + sqrt(.5 * kPi))) / kPi;
+      const double psi = sqrt(gamma / kPi) * (2. + sqrt(.5 * kPi)) *
+                         safe_exp(-gamma * kPi * kPi / 8.);
+      double u, v, z;
+      for (;;) {
+        u = aux2(g, xi, psi, gamma);
+        if (u > kPi) continue;
+        const double zeta = sqrt(zolotarev_pdf_pow(u, a));
+        z = 1. / (1. - pow(1. + a * zeta / sqrt(gamma), -1. / a));
+        const double ap = aux2_accept(u, xi, psi, zeta, z, tilt_pow, gamma);
+        if (ap > 0.) {
+          v = g.uniform() / ap;
+          if (u < kPi && v <= 1.) break;
+        }
+      }
+      // --- reference variable X | U (tilted_stable.pyx:261-296)
+      const double aa = zolotarev(u, a);
+      const double left = pow(odds / aa, a) * tilt_pow;
+      const double right = left + sqrt(left * a / aa);
+      const double expo_scale = z / aa;
+      const double m_left = (right - left) * sqrt(.5 * kPi);
+      const double m_mid = (right - left);
+      const double m_right = expo_scale;
+      const double m_tot = m_left + m_mid + m_right;
+      const double pick = g.uniform();
+      double nrm = 0., e = 0., x;
+      if (pick < m_left / m_tot) {
+        nrm = g.normal();
+        x = left - (right - left) * fabs(nrm);
+      } else if (pick < (m_left + m_mid) / m_tot) {
+        x = left + (right - left) * g.uniform();
+      } else {
+        e = -log(g.uniform());
+        x = right + e * m_right;
+      }
+      // --- acceptance (tilted_stable.pyx:298-311)
+      double log_accept;
+      if (x < 0) {
+        log_accept = -INFINITY;
+      } else {
+        log_accept = -(aa * (x - left) +
+                       safe_exp(log(tilt_pow) / a - odds * log(left)) *
+                           (pow(left / x, odds) - 1.));
+        if (x < left)
+          log_accept += nrm * nrm / 2.;
+        else if (x > right)
+          log_accept += e;
+      }
+      if (log_accept > log(v)) return pow(x, -odds);
+    }
+  }
+
+  // Method choice of tilted_stable.pyx:99-104.
+  template <class G>
+  BBX_HD static inline double draw(G& g, double a, double tilt) {
+    if (pow(tilt, a) < kCostThreshold) return divide_conquer(g, a, tilt);
+    return double_rejection(g, a, tilt);
+  }
+};
+
+// ------------------------------------------------------------------ Gamma
+
+// Gamma(shape, 1), Marsaglia & Tsang (2000).  Device-only use (the reference
+// draws these two scalars per iteration with np.random.gamma,
+// bayesbridge.py:403,438); distribution parity.
+template <class G>
+BBX_HD inline double gamma_draw(G& g, double shape) {
+  double boost = 1.;
+  if (shape < 1.) {
+    boost = pow(g.uniform(), 1. / shape);
+    shape += 1.;
+  }
+  const double d = shape - 1. / 3.;
+  const double c = 1. / sqrt(9. * d);
+  for (;;) {
+    double x, v;
+    do {
+      x = g.normal();
+      v = 1. + c * x;
+    } while (v <= 0.);
+    v = v * v * v;
+    const double u = g.uniform();
+    if (u < 1. - 0.0331 * (x * x) * (x * x)) return boost * d * v;
+    if (log(u) < 0.5 * x * x + d * (1. - v + log(v))) return boost * d * v;
+  }
+}
+
+}  // namespace bbx

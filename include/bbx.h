@@ -216,6 +216,100 @@ int bbx_design_get_timing(bbx_design* h, int which, int64_t* n_launch,
                           double* total_ms);
 int bbx_design_reset_timing(bbx_design* h);
 
+/* ------------------------------------------- device-resident Gibbs chain */
+
+/*
+ * A whole Gibbs iteration of BayesBridge.gibbs(coef_sampler_type='cg')
+ * (bayesbridge.py:210-240) kept in HBM: beta | rest by the CG sampler above,
+ * Omega | beta (Polya-Gamma for logit, bayesbridge.py:397-410; Gamma for the
+ * linear model's precision), tau | beta (bayesbridge.py:412-448), lambda |
+ * tau, beta (tilted stable, bayesbridge.py:458-478), log-posterior
+ * (bayesbridge.py:480-511), and the running summaries that give the CG warm
+ * start and preconditioner scale (reg_coef_posterior_summarizer.py:3-124).
+ * Random numbers come from Philox4x32-10 keyed by (seed, iteration, element):
+ * distribution parity with the reference, never stream parity.
+ *
+ *   model          BBX_MODEL_LINEAR or BBX_MODEL_LOGIT
+ *   outcome[n]     y (linear) or n_success (logit)          host pointer
+ *   n_trial[n]     logit only; NULL => ones                  host pointer
+ *   sd_unshrunk[n_unshrunk]  prior sd of the unshrunk coefficients
+ *                  (intercept first; +inf = flat prior; bayesbridge.py:26-32)
+ *   bridge_exp, slab_size    prior.py:9-15
+ *   gscale_shape0, gscale_rate0  Gamma prior on tau^-bridge_exp (prior.py:77-81)
+ * The chain borrows `design` (which must outlive it) and its stream.
+ */
+int bbx_chain_create(bbx_design* design, int model, const double* outcome,
+                     const double* n_trial, int n_unshrunk,
+                     const double* sd_unshrunk, double bridge_exp,
+                     double slab_size, double gscale_shape0,
+                     double gscale_rate0, uint64_t seed, bbx_chain** out);
+int bbx_chain_destroy(bbx_chain* c);
+
+/* Markov-chain state, host pointers.  obs_prec has n entries for logit and 1
+ * for linear; lscale has P - n_unshrunk entries; gscale is in the RAW
+ * parametrisation the sampler runs in (prior.py:129-141).  NULL = leave. */
+int bbx_chain_set_state(bbx_chain* c, const double* coef,
+                        const double* obs_prec, const double* lscale,
+                        const double* gscale);
+int bbx_chain_get_state(bbx_chain* c, double* coef, double* obs_prec,
+                        double* lscale, double* gscale);
+/* Running summaries (checkpoint/resume: bayesbridge.py:253-275,
+ * reg_coef_sampler.py:42-58). */
+int bbx_chain_set_summary(bbx_chain* c, const double* mean,
+                          const double* square, int64_t n_averaged);
+int bbx_chain_get_summary(bbx_chain* c, double* mean, double* square,
+                          int64_t* n_averaged);
+/* Omega at its initial value for the current coef: Polya-Gamma mean for logit
+ * (logistic_model.py:80-87), 1/mean(resid^2) for linear
+ * (bayesbridge.py:355-370). */
+int bbx_chain_init_obs_prec(bbx_chain* c);
+/* Iterations done so far (keys the Philox streams; settable for resume). */
+int bbx_chain_get_iteration(bbx_chain* c, int64_t* iteration);
+int bbx_chain_set_iteration(bbx_chain* c, int64_t iteration);
+
+/*
+ * Runs n_iter Gibbs iterations; a sample is kept every `thin` iterations
+ * after `n_burnin` (gibbs_util.py:164-189), n_sample = (n_iter-n_burnin)/thin.
+ *   maxiter, atol   of the CG solve; atol <= 0 => 1e-5*sqrt(P)
+ *                   (reg_coef_sampler.py:95), maxiter <= 0 => 500.
+ *   d_coef[n_sample*P]       DEVICE buffer, sample-major (sample s at s*P), or NULL
+ *   d_lscale[n_sample*(P-n_unshrunk)], d_obs_prec[n_sample*n (logit) |
+ *                   n_sample (linear)]   DEVICE buffers or NULL
+ *   gscale[n_sample], logp[n_sample], n_cg_iter[n_sample]   HOST buffers or NULL
+ * Returns 0, or the number of iterations whose CG solve hit maxiter (> 0), or
+ * < 0 on error.
+ */
+int bbx_chain_run(bbx_chain* c, int n_iter, int n_burnin, int thin,
+                  int maxiter, double atol, double* d_coef, double* d_lscale,
+                  double* d_obs_prec, double* gscale, double* logp,
+                  double* n_cg_iter);
+/* Same with HOST sample buffers for coef/lscale/obs_prec (copied at the end). */
+int bbx_chain_run_host(bbx_chain* c, int n_iter, int n_burnin, int thin,
+                       int maxiter, double atol, double* coef, double* lscale,
+                       double* obs_prec, double* gscale, double* logp,
+                       double* n_cg_iter);
+
+/* The device-side scalar samplers on n_draw inputs (host pointers), exposed
+ * so that their distributions can be tested against the host samplers:
+ * Polya-Gamma(shape_i, tilt_i) and tilted stable(char_exp, tilt_i). */
+int bbx_device_polya_gamma(int device, uint64_t seed, int64_t n_draw,
+                           const int32_t* shape, const double* tilt,
+                           double* out);
+int bbx_device_tilted_stable(int device, uint64_t seed, int64_t n_draw,
+                             double char_exp, const double* tilt, double* out);
+int bbx_device_gamma(int device, uint64_t seed, int64_t n_draw, double shape,
+                     double* out);
+
+/* ----------------------- host-side reference-stream samplers (libbbx_hostrng)
+ * Exported by the separate, HIP-free libbbx_hostrng.so.  `bitgen` is the
+ * address of a NumPy bitgen_t (PCG64(seed).ctypes.bit_generator); the draws
+ * consume it exactly as random/polya_gamma/polya_gamma.pyx:40-74 and
+ * random/tilted_stable/tilted_stable.pyx:65-134 do. */
+int bbx_host_polya_gamma(void* bitgen, int64_t n, const int32_t* shape,
+                         const double* tilt, double* out);
+int bbx_host_tilted_stable(void* bitgen, int64_t n, const double* char_exp,
+                           const double* tilt, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,224 @@
+"""Generates the golden fixtures under tests/golden/ by importing the upstream
+reference (build container only; see ref_import.py).  The fixtures are DATA:
+inputs and the reference's outputs.  Re-run with
+
+    python tests/golden/make_golden.py
+
+Files written (all small .npz/.npy):
+  reference_{linear,logit}_cg_last_sample.npy
+      values of the reference's own regression fixtures
+      tests/regression_tests/saved_outputs/{linear,logit}_cg_samples.npy
+  chain_{linear_dense,logit_sparse}_cg.npz
+      the two 'cg' combos of tests/regression_tests/test_gibb.py:11-90 re-run
+      through the imported reference: data, all 10 samples, and for every
+      Gibbs iteration the inputs/outputs of ConjugateGradientSampler.sample
+      (including the two Gaussian vectors it drew).
+  operator_sparse_100x10.npz, operator_dense_100x10.npz
+      tests/test_design_matrix.py:12-24,49-61 style operator cases.
+  chain_logit_mixed_initcoef.npz
+      tests/gpu_tests/test_gibbs.py:34-44 (helper.simulate_data('logit',
+      seed=1), init={'coef': ones}, seed=1, 10 iterations) on the CPU path.
+  chain_linear_dense_2000x500_summary.npz
+      BASELINE config 1 (simulate_design(2000, 500, format_='dense',
+      seed=111)): summary statistics of a 20-iteration reference run.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import scipy.sparse as sparse
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+warnings.simplefilter('ignore')
+bb, refsim = ref_import.import_reference()
+from bayesbridge import BayesBridge, RegressionModel, RegressionCoefPrior  # noqa
+from bayesbridge.design_matrix import (DenseDesignMatrix,  # noqa: E402
+                                       SparseDesignMatrix)
+from bayesbridge.model import LinearModel, LogisticModel  # noqa: E402
+from bayesbridge.reg_coef_sampler.cg_sampler import \
+    ConjugateGradientSampler  # noqa: E402
+
+REF_SAVED = os.path.join(ref_import.REFERENCE_ROOT, 'tests',
+                         'regression_tests', 'saved_outputs')
+
+
+class Recorder:
+    """Wraps ConjugateGradientSampler.sample to keep what went in and out."""
+
+    def __init__(self):
+        self.records = []
+        self.orig = ConjugateGradientSampler.sample
+
+    def __enter__(self):
+        rec, orig = self.records, self.orig
+
+        def sample(sampler, design, obs_prec, prior_prec_sqrt, z,
+                   coef_cg_init=None, precond_by='prior', coef_scaled_sd=None,
+                   maxiter=None, atol=10e-6, seed=None):
+            before = np.random.get_state()
+            coef, info = orig(sampler, design, obs_prec, prior_prec_sqrt, z,
+                              coef_cg_init=coef_cg_init, precond_by=precond_by,
+                              coef_scaled_sd=coef_scaled_sd, maxiter=maxiter,
+                              atol=atol, seed=seed)
+            after = np.random.get_state()
+            np.random.set_state(before)
+            eta1 = np.random.randn(design.shape[0])      # cg_sampler.py:61-62
+            eta2 = np.random.randn(design.shape[1])
+            np.random.set_state(after)
+            rec.append(dict(
+                obs_prec=np.array(obs_prec, dtype=float) * np.ones(
+                    design.shape[0]),
+                prior_prec_sqrt=np.array(prior_prec_sqrt),
+                z=np.array(z), coef_cg_init=np.array(coef_cg_init),
+                coef_scaled_sd=np.array(coef_scaled_sd), randn_n=eta1,
+                randn_P=eta2, coef=np.array(coef), n_iter=info['n_iter'],
+                maxiter=maxiter, atol=atol,
+                n_unshrunk=sampler.n_coef_wo_shrinkage))
+            return coef, info
+
+        ConjugateGradientSampler.sample = sample
+        return self
+
+    def __exit__(self, *exc):
+        ConjugateGradientSampler.sample = self.orig
+
+    def stacked(self):
+        keys = ('obs_prec', 'prior_prec_sqrt', 'z', 'coef_cg_init',
+                'coef_scaled_sd', 'randn_n', 'randn_P', 'coef')
+        out = {'cg_' + k: np.stack([r[k] for r in self.records])
+               for k in keys}
+        out['cg_n_iter'] = np.array([r['n_iter'] for r in self.records])
+        out['cg_atol'] = np.array([r['atol'] for r in self.records])
+        out['cg_maxiter'] = np.array([r['maxiter'] for r in self.records])
+        out['cg_n_unshrunk'] = np.array(
+            [r['n_unshrunk'] for r in self.records])
+        return out
+
+
+def regression_test_data(model, matrix_format):
+    # tests/regression_tests/test_gibb.py:62-90
+    np.random.seed(1)
+    n, p = 100, 50
+    beta_true = np.zeros(p)
+    beta_true[:4] = 1
+    beta_true[4:15] = 2 ** - np.linspace(0.0, 5, 11)
+    X = np.random.randn(n, p)
+    if model == 'linear':
+        outcome = LinearModel.simulate_outcome(X, beta_true, 2)
+    else:
+        n_trial = np.ones(n, dtype=np.int32)
+        n_success = LogisticModel.simulate_outcome(n_trial, X, beta_true)
+        outcome = (n_success, n_trial)
+    return outcome, X
+
+
+def golden_chain(model, matrix_format):
+    outcome, X = regression_test_data(model, matrix_format)
+    Xin = sparse.csr_matrix(X) if matrix_format == 'sparse' else X.copy()
+    prior = RegressionCoefPrior(sd_for_intercept=2., regularizing_slab_size=1.,
+                                bridge_exponent=.25)
+    bridge = BayesBridge(RegressionModel(outcome, Xin, model), prior)
+    init = {'global_scale': 0.1, 'local_scale': np.ones(X.shape[1])}
+    with Recorder() as rec:
+        samples, info = bridge.gibbs(10, 0, init=init, thin=1,
+                                     coef_sampler_type='cg', seed=0,
+                                     params_to_save='all')
+    saved = np.load(os.path.join(REF_SAVED, model + '_cg_samples.npy'))
+    assert np.allclose(samples['coef'][:, -1], saved, rtol=.001, atol=10e-6)
+    np.save(os.path.join(HERE, 'reference_%s_cg_last_sample.npy' % model),
+            saved)
+    out = rec.stacked()
+    out.update(X=X, coef_samples=samples['coef'],
+               global_scale_samples=samples['global_scale'],
+               local_scale_samples=samples['local_scale'],
+               logp_samples=samples['logp'],
+               obs_prec_samples=samples['obs_prec'],
+               n_cg_iter=info['_reg_coef_sampling_info']['n_cg_iter'],
+               init_coef=info['init']['coef'])
+    if model == 'linear':
+        out['y'] = outcome
+    else:
+        out['n_success'], out['n_trial'] = outcome
+    np.savez_compressed(
+        os.path.join(HERE, 'chain_%s_%s_cg.npz' % (model, matrix_format)),
+        **out)
+    print('chain', model, matrix_format, 'max|last - saved| =',
+          np.abs(samples['coef'][:, -1] - saved).max())
+
+
+def operator_cases():
+    np.random.seed(20)
+    X = refsim.simulate_design(100, 10, binary_frac=.5, format_='sparse')
+    d = SparseDesignMatrix(X, center_predictor=True, add_intercept=True)
+    w, v = (np.random.randn(s) for s in d.shape)
+    np.savez_compressed(
+        os.path.join(HERE, 'operator_sparse_100x10.npz'),
+        X=X.toarray(), v=v, w=w, dot=d.dot(v), Tdot=d.Tdot(w))
+    Xd = refsim.simulate_design(100, 10, binary_frac=.5, format_='dense')
+    dd = DenseDesignMatrix(Xd.copy(), center_predictor=True,
+                           add_intercept=True)
+    w, v = (np.random.randn(s) for s in dd.shape)
+    np.savez_compressed(
+        os.path.join(HERE, 'operator_dense_100x10.npz'),
+        X=Xd, v=v, w=w, dot=dd.dot(v), Tdot=dd.Tdot(w))
+    print('operator cases written')
+
+
+def mixed_logit_initcoef():
+    # tests/helper.py:8-40 + tests/gpu_tests/test_gibbs.py:34-44
+    np.random.seed(1)
+    X = refsim.simulate_design(100, 50, binary_frac=.9)
+    beta = np.random.randn(50)
+    n_trial = 1 + np.random.binomial(np.arange(100) + 1, .5)
+    n_success = LogisticModel.simulate_outcome(n_trial, X, beta)
+    bridge = BayesBridge(RegressionModel((n_success, n_trial), X, 'logit'),
+                         RegressionCoefPrior())
+    init = {'coef': np.ones(bridge.model.n_pred)}
+    with Recorder() as rec:
+        samples, info = bridge.gibbs(n_iter=10, coef_sampler_type='cg',
+                                     init=init, seed=1)
+    out = rec.stacked()
+    Xc = X.tocsr()
+    out.update(X_data=Xc.data, X_indices=Xc.indices, X_indptr=Xc.indptr,
+               X_shape=np.array(Xc.shape), n_success=n_success,
+               n_trial=n_trial, coef_samples=samples['coef'],
+               global_scale_samples=samples['global_scale'],
+               logp_samples=samples['logp'],
+               n_cg_iter=info['_reg_coef_sampling_info']['n_cg_iter'])
+    np.savez_compressed(os.path.join(HERE, 'chain_logit_mixed_initcoef.npz'),
+                        **out)
+    print('mixed logit init-coef chain written, n_cg',
+          info['_reg_coef_sampling_info']['n_cg_iter'])
+
+
+def config1_summary():
+    X = refsim.simulate_design(2000, 500, format_='dense', seed=111)
+    beta = np.zeros(500)
+    beta[:5], beta[5:10], beta[10:15] = 1.5, 1., .5
+    y = refsim.simulate_outcome(X, beta, 'linear', seed=1)
+    bridge = BayesBridge(
+        RegressionModel(y, X.copy(), 'linear'),
+        RegressionCoefPrior(bridge_exponent=.5, regularizing_slab_size=2.))
+    samples, info = bridge.gibbs(20, 0, init={'global_scale': .01},
+                                 coef_sampler_type='cg', seed=111)
+    np.savez_compressed(
+        os.path.join(HERE, 'chain_linear_dense_2000x500_summary.npz'),
+        coef_last=samples['coef'][:, -1],
+        coef_mean_last10=samples['coef'][:, 10:].mean(axis=1),
+        global_scale=samples['global_scale'], logp=samples['logp'],
+        n_cg_iter=info['_reg_coef_sampling_info']['n_cg_iter'],
+        y_head=y[:8], X_head=X[:4, :4])
+    print('config 1 summary written, n_cg',
+          info['_reg_coef_sampling_info']['n_cg_iter'])
+
+
+if __name__ == '__main__':
+    golden_chain('linear', 'dense')
+    golden_chain('logit', 'sparse')
+    operator_cases()
+    mixed_logit_initcoef()
+    config1_summary()
