@@ -99,6 +99,19 @@ class HipDesignMatrix():
                                                       byref(b)))
         return int(a.value), int(b.value)
 
+    def tiled_info(self):
+        """Geometry of the LDS-tiled layout: {'X': {...}, 'Xt': {...}}."""
+        out = {}
+        for which, name in ((0, 'X'), (1, 'Xt')):
+            W, nb, PR, G = c_int(), c_int(), c_int(), c_int()
+            nq, ns = c_int64(), c_int64()
+            _lib.check(self._lib.bbx_design_tiled_info(
+                self._h, which, byref(W), byref(nb), byref(PR), byref(G),
+                byref(nq), byref(ns)))
+            out[name] = dict(W=W.value, n_block=nb.value, PR=PR.value,
+                             G=G.value, n_quad=nq.value, n_slice=ns.value)
+        return out
+
     # -- the operator -------------------------------------------------------
     def dot(self, v):
         """X~ v (sparse_matrix.py:68-101, dense_matrix.py:37-48)."""

@@ -158,8 +158,6 @@ __global__ void all_ones_kernel(int64_t nnz, const double* __restrict__ data,
     if (data[i] != 1.0) *flag = 0;
 }
 
-int build_tiled(bbx_design* h);
-
 // Common tail of the two CSR constructors: the device CSR arrays are in place.
 static int finish_csr(bbx_design* h, int format) {
   // Values that are all exactly 1.0 are dropped (binary designs,
@@ -309,6 +307,7 @@ int bbx_design_destroy(bbx_design* h) {
     (void)hipEventDestroy(pr.b);
   }
   if (h->host_pinned) (void)hipHostFree(h->host_pinned);
+  destroy_tiled(h);
   hipStream_t s = h->stream;
   delete h;  // frees every DevMem
   if (s) (void)hipStreamDestroy(s);
@@ -522,8 +521,18 @@ int bbx_design_storage_bytes(const bbx_design* h, int64_t* bytes) {
   b += (int64_t)(h->t_chunk_row.bytes + h->t_chunk_begin.bytes +
                  h->t_row_chunk_ptr.bytes);
   b += (int64_t)h->dense.bytes;
+  b += tiled_storage_bytes(h);
   if (bytes) *bytes = b;
   return BBX_OK;
+}
+
+int bbx_design_tiled_info(const bbx_design* h, int which, int* W,
+                          int* n_block, int* PR, int* G, int64_t* n_quad,
+                          int64_t* n_slice) {
+  BBX_TRY(check_handle(h));
+  if (!h->sparse || h->format != BBX_FORMAT_TILED)
+    return fail(BBX_ERR_STATE, "operator is not in the tiled format");
+  return tiled_describe(h, which, W, n_block, PR, G, n_quad, n_slice);
 }
 
 int bbx_design_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
@@ -533,6 +542,8 @@ int bbx_design_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
   if (!h->sparse) {
     const int64_t el = h->dense_dtype == BBX_F32 ? 4 : 8;
     db = tb = h->n * h->P * el + 8 * (h->n + h->P);
+  } else if (h->format == BBX_FORMAT_TILED) {
+    BBX_TRY(tiled_matvec_bytes(h, &db, &tb));
   } else {
     // nnz*(b_val+b_idx) + (rows+1)*b_ptr + 8*len(in) + 8*len(out)
     const int64_t bval = h->binary ? 0 : 8;

@@ -104,6 +104,10 @@ struct bbx_design {
   // --- dense layout
   bbx::DevMem dense;  // row-major n x P (intercept column included), f32 or f64
 
+  // --- LDS-tiled layout (BBX_FORMAT_TILED): see spmv_tiled.hip
+  void* tiled = nullptr;           // bbx::TiledPair*
+  bbx::DevMem tiled_gfull;         // p: X^T w before the epilogue
+
   bbx::DevMem offset;  // column means (p), zeros when not centred
 
   // --- persistent work vectors
@@ -184,6 +188,13 @@ int launch_tdot_csr(bbx_design* h, const double* d_w,
 int launch_tdot_finalize(bbx_design* h, const double* d_gfull,
                          const double* d_sumw_part, const TdotEpilogue& ep,
                          double* d_out);
+int build_tiled(bbx_design* h);
+void destroy_tiled(bbx_design* h);
+int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
+                       int64_t* tdot_bytes);
+int64_t tiled_storage_bytes(const bbx_design* h);
+int tiled_describe(const bbx_design* h, int which, int* W, int* n_block,
+                   int* PR, int* G, int64_t* n_quad, int64_t* n_slice);
 int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,
                        uint64_t stream, double* d_out);
 

@@ -131,6 +131,14 @@ int bbx_design_storage_bytes(const bbx_design* h, int64_t* bytes);
 int bbx_design_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
                             int64_t* tdot_bytes);
 
+/* Geometry of the tiled format (BBX_FORMAT_TILED only): which = 0 for X, 1 for
+ * X^T; W = column-block width, n_block = column blocks, PR = rows per panel,
+ * G = column-block groups (partial-sum slabs), n_quad = 512-byte id groups
+ * (4 entries x 64 lanes), n_slice = 64-row slices. */
+int bbx_design_tiled_info(const bbx_design* h, int which, int* W,
+                          int* n_block, int* PR, int* G, int64_t* n_quad,
+                          int64_t* n_slice);
+
 /*
  * out[n] = X~ v,  v[P].  Replaces SparseDesignMatrix.dot / main_dot
  * (sparse_matrix.py:68-101) and DenseDesignMatrix.dot (dense_matrix.py:37-48):

@@ -59,11 +59,12 @@ def _assert_close(c_h, i_h, c_o, i_o):
     assert np.abs(c_h - c_o).max() <= tol * max(scale, 1.)
 
 
+@pytest.mark.parametrize("storage", ['csr', 'tiled'])
 @pytest.mark.parametrize("seed", [0, 1, 2])
-def test_cg_sample_small_mixed(seed):
+def test_cg_sample_small_mixed(seed, storage):
     X = mixed_design(300, 40, binary_frac=.5, seed=seed)
     n, P = X.shape[0], X.shape[1] + 1
-    out = _run_both(X, cg_inputs(n, P, seed=seed))
+    out = _run_both(X, cg_inputs(n, P, seed=seed), storage=storage)
     _assert_close(*out)
 
 
@@ -75,11 +76,12 @@ def test_cg_sample_no_intercept_two_unshrunk():
     _assert_close(*out)
 
 
-def test_cg_sample_binary_medium():
+@pytest.mark.parametrize("storage", ['csr', 'tiled'])
+def test_cg_sample_binary_medium(storage):
     from bayesbridge_amd import simulate
     X = simulate.simulate_binary_csr_fast(20000, 2000, .01, seed=5)
     n, P = X.shape[0], X.shape[1] + 1
-    out = _run_both(X, cg_inputs(n, P, seed=5))
+    out = _run_both(X, cg_inputs(n, P, seed=5), storage=storage)
     _assert_close(*out)
 
 

@@ -39,7 +39,7 @@ def _check(hip, ora, seed=0, tol=1e-11):
     assert np.abs(a - b).max() <= tol * scale
 
 
-STORAGES = ['csr']
+STORAGES = ['csr', 'tiled']
 
 
 @pytest.mark.parametrize("storage", STORAGES)
