@@ -50,6 +50,21 @@ struct SliceMeta {
   uint32_t n_quad;      // groups of 4 entries per lane
 };
 
+// One step of a wave's precomputed schedule: BATCH consecutive quads of one
+// slice.  The schedule of every (workgroup, wave) is laid out in processing
+// order, so the kernel's issue cursor is a single scalar index.
+struct BatchDesc {
+  uint32_t quad0;     // first quad (units of 64 uint2 in the id stream)
+  uint32_t row_slot;  // slice * 64: where the slice's row ids start
+  uint32_t info;      // bits 0-3 count, 8 last-of-slice, 9 tile-first, 10 end
+  uint32_t pad;
+};
+constexpr uint32_t BD_LAST = 1u << 8;
+constexpr uint32_t BD_TILE_FIRST = 1u << 9;
+constexpr uint32_t BD_END = 1u << 10;
+constexpr int BATCH_BIN = 4;   // quads per ring slot, value-free stream
+constexpr int BATCH_VAL = 2;   // quads per ring slot when values are stored
+
 // One orientation (X or X^T) in tiled form, device resident.
 struct TiledMatrix {
   int64_t R = 0, C = 0, nnz = 0;
@@ -58,14 +73,16 @@ struct TiledMatrix {
   int64_t n_slice = 0, n_quad = 0, n_tile = 0;
   DevMem ids;        // uint2[n_quad * 64]
   DevMem vals;       // double[n_quad * 64 * 4] when has_vals
-  DevMem slices;     // SliceMeta[n_slice]
+  DevMem descs;      // BatchDesc[n_desc]: per-wave schedules
+  DevMem wave_desc;  // int32[n_panel * G * 16]: first descriptor of each wave
+  int64_t n_desc = 0;
   DevMem rowids;     // uint16[n_slice * 64] panel-local row of each lane
   DevMem tiles;      // TileDesc[n_tile]
   DevMem wg_tiles;   // int32[n_panel * G + 1]
   DevMem slab;       // double[G * R] partial sums when G > 1 (or Tdot)
   int64_t stream_bytes() const {
     return (int64_t)n_quad * 64 * 8 * (has_vals ? 5 : 1) +
-           (int64_t)n_slice * (sizeof(SliceMeta) + 128) +
+           (int64_t)n_slice * 128 + (int64_t)n_desc * (int64_t)sizeof(BatchDesc) +
            (int64_t)n_tile * (int64_t)sizeof(TileDesc);
   }
 };
@@ -76,24 +93,74 @@ struct TiledPair {
 
 // ------------------------------------------------------------------ kernel
 
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// Adds the 4 gathered entries of one quad to the two running sums.
+template <bool VALS>
+__device__ __forceinline__ void quad_accumulate(const double* __restrict__ xs,
+                                                v2u e, v2d va, v2d vb,
+                                                double& s0, double& s1) {
+  if (VALS) {
+    s0 += va.x * xs[e.x & 0xFFFFu] + vb.x * xs[e.y & 0xFFFFu];
+    s1 += va.y * xs[e.x >> 16] + vb.y * xs[e.y >> 16];
+  } else {
+    s0 += xs[e.x & 0xFFFFu] + xs[e.y & 0xFFFFu];
+    s1 += xs[e.x >> 16] + xs[e.y >> 16];
+  }
+}
+
+// The id/value/row-id stream loads are issued through inline asm so that
+// hipcc does not count them: with compiler-visible loads it drains the whole
+// register ring with `s_waitcnt vmcnt(0)` at every loop join (checked in the
+// .s), which serialises HBM latency with the LDS gathers.  The waits are
+// counted by hand instead (cdna_hip_programming.md 5.7, form (ii)): every ISSUE
+// step queues exactly LOADS_PER_STEP vector-memory operations, so before
+// consuming a ring slot at most (RING-1)*LOADS_PER_STEP younger ones may still
+// be in flight.  Unknown extra compiler loads can only make the wait stricter.
+__device__ __forceinline__ void asm_load_x2(v2u& dst, unsigned off,
+                                            const void* base) {
+  asm volatile("global_load_dwordx2 %0, %1, %2"
+               : "=v"(dst)
+               : "v"(off), "s"(base)
+               : "memory");
+}
+__device__ __forceinline__ void asm_load_d2(v2d& dst, unsigned off,
+                                            const void* base) {
+  asm volatile("global_load_dwordx4 %0, %1, %2"
+               : "=v"(dst)
+               : "v"(off), "s"(base)
+               : "memory");
+}
+__device__ __forceinline__ void asm_load_u16(unsigned& dst, unsigned off,
+                                             const void* base) {
+  asm volatile("global_load_ushort %0, %1, %2"
+               : "=v"(dst)
+               : "v"(off), "s"(base)
+               : "memory");
+}
+
+constexpr int FILL_UNROLL = (TILE_W_MAX + TILE_THREADS - 1) / TILE_THREADS;
+
 template <bool VALS>
 __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
     int64_t R, int64_t C, int W, int PR, int G,
     const int32_t* __restrict__ wg_tiles, const TileDesc* __restrict__ tiles,
-    const SliceMeta* __restrict__ slices, const uint16_t* __restrict__ rowids,
+    const int32_t* __restrict__ wave_desc,
+    const BatchDesc* __restrict__ descs, const uint16_t* __restrict__ rowids,
     const uint2* __restrict__ ids, const double* __restrict__ vals,
     const double* __restrict__ x,
     // epilogue (direct mode, G == 1 and out != nullptr):
     //   out[r] = rowscale[r] * (c0 - sum(c_part) + acc)
     const double* __restrict__ c_part, const double* x0_ptr,
     const double* __restrict__ rowscale, double* __restrict__ out,
-    double* __restrict__ slab) {
+    double* __restrict__ slab, int ablate) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* xs = lds;               // W + 8 doubles; xs[W] == 0 (padding target)
   double* acc = lds + (W + 8);    // PR doubles
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
-  const int wave = tid / WAVE;
+  const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int panel = blockIdx.x / G;
   const int group = blockIdx.x - panel * G;
   const int64_t row0 = (int64_t)panel * PR;
@@ -102,64 +169,169 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
   for (int r = tid; r < PR; r += TILE_THREADS) acc[r] = 0.;
   if (tid < 8) xs[W + tid] = 0.;
 
-  const int t_begin = wg_tiles[blockIdx.x], t_end = wg_tiles[blockIdx.x + 1];
-  for (int t = t_begin; t < t_end; ++t) {
-    const TileDesc td = tiles[t];
-    const int64_t col0 = (int64_t)td.col_block * W;
-    const int cols_here = (int)((C - col0 < W) ? (C - col0) : W);
-    __syncthreads();  // previous tile's gathers are done
-    for (int j = tid; j < W; j += TILE_THREADS)
-      xs[j] = (j < cols_here) ? x[col0 + j] : 0.;
-    __syncthreads();
-    for (int s = td.slice_begin + wave; s < td.slice_end; s += TILE_WAVES) {
-      const SliceMeta sm = slices[s];
-      const uint16_t rid = rowids[(int64_t)s * WAVE + lane];
-      const uint2* __restrict__ p = ids + (int64_t)sm.first_quad * WAVE + lane;
-      const double* __restrict__ pv =
-          VALS ? vals + ((int64_t)sm.first_quad * WAVE + lane) * 4 : nullptr;
-      double s0 = 0., s1 = 0.;
-      uint32_t q = 0;
-      for (; q + 4 <= sm.n_quad; q += 4) {
-        const uint2 a = p[(q + 0) * WAVE];
-        const uint2 b = p[(q + 1) * WAVE];
-        const uint2 c = p[(q + 2) * WAVE];
-        const uint2 d = p[(q + 3) * WAVE];
-        if (VALS) {
-          const double* v = pv + (int64_t)q * WAVE * 4;
+  constexpr int BATCH = VALS ? BATCH_VAL : BATCH_BIN;  // quads per ring slot
+  constexpr int RING = VALS ? 3 : 4;   // slots: RING-1 batches in flight
+  constexpr int LOADS_PER_STEP = BATCH * (VALS ? 3 : 1) + 1;
+  constexpr int WAIT_COUNT = (RING - 1) * LOADS_PER_STEP;
+  static_assert(WAIT_COUNT < 64, "vmcnt is a 6-bit field");
+
+  // Each wave walks its own precomputed schedule (BatchDesc stream) through a
+  // ring of RING register slots: while one batch is gathered from LDS the next
+  // RING-1 are in flight from HBM, across slice AND tile boundaries.  The
+  // schedule marks where the wave enters a new tile; there every wave of the
+  // workgroup meets at a barrier and the vector slice in LDS is replaced.
+  int t = wg_tiles[blockIdx.x] - 1;   // tile being processed (advanced at switch)
+  // Issue cursor.  The wave's descriptors are fetched 64 at a time (one per
+  // lane) and read back with v_readlane, so that no memory latency sits
+  // between two ISSUE steps; the next block of 64 is prefetched.
+  int blk = wave_desc[blockIdx.x * TILE_WAVES + wave];
+  int pos = 0;
+  const uint4* __restrict__ desc4 = reinterpret_cast<const uint4*>(descs);
+  uint4 dcur = desc4[blk + lane];
+  uint4 dnxt = desc4[blk + WAVE + lane];
+  // Retire every compiler-visible load before the ring starts (see ISSUE).
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+  v2u e[RING][BATCH];
+  v2d eva[RING][BATCH], evb[RING][BATCH];
+  unsigned rid[RING];
+  unsigned info[RING];
+  double s0 = 0., s1 = 0.;
+
+#define BBX_ISSUE(K)                                                          \
+  do {                                                                        \
+    const unsigned d_quad0 = (unsigned)__builtin_amdgcn_readlane((int)dcur.x, pos); \
+    const unsigned d_row = (unsigned)__builtin_amdgcn_readlane((int)dcur.y, pos);   \
+    const unsigned inf = (unsigned)__builtin_amdgcn_readlane((int)dcur.z, pos);     \
+    const int cntk = (int)(inf & 15u);                                        \
+    const int left = cntk > 0 ? cntk : 1;                                     \
+    const unsigned quad0 = cntk > 0 ? d_quad0 : 0u;                           \
+    _Pragma("unroll") for (int u = 0; u < BATCH; ++u) {                       \
+      const unsigned uu = (unsigned)((u < left) ? u : left - 1);              \
+      const unsigned slot = (quad0 + uu) * WAVE + lane;                       \
+      asm_load_x2(e[K][u], slot * 8u, ids);                                   \
+      if (VALS) {                                                             \
+        asm_load_d2(eva[K][u], slot * 32u, vals);                             \
+        asm_load_d2(evb[K][u], slot * 32u + 16u, vals);                       \
+      }                                                                       \
+    }                                                                         \
+    asm_load_u16(rid[K], ((cntk > 0 ? d_row : 0u) + lane) * 2u, rowids);      \
+    info[K] = inf;                                                            \
+    if (!(inf & BD_END)) {                                                    \
+      ++pos;                                                                  \
+      if (pos == WAVE) {                                                      \
+        pos = 0;                                                              \
+        blk += WAVE;                                                          \
+        dcur = dnxt;                                                          \
+        dnxt = desc4[blk + WAVE + lane];                                      \
+        /* retire this (compiler-visible) load here, once per 64 batches: */  \
+        /* left pending it makes hipcc guard every later register write   */  \
+        /* in the loop with vmcnt(0), which drains the ring (seen in .s)  */  \
+        __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) only */               \
+      }                                                                       \
+    }                                                                         \
+  } while (0)
+
+// Wait until slot K's loads have landed (all later ISSUE steps may still be
+// in flight) and make its registers opaque to the scheduler at this point.
+#define BBX_WAIT(K)                                                           \
+  do {                                                                        \
+    if (VALS) {                                                               \
+      asm volatile("s_waitcnt vmcnt(%8)"                                      \
+                   : "+v"(e[K][0]), "+v"(e[K][BATCH - 1]), "+v"(rid[K]),      \
+                     "+v"(eva[K][0]), "+v"(evb[K][0]),                        \
+                     "+v"(eva[K][BATCH - 1]), "+v"(evb[K][BATCH - 1]),        \
+                     "+v"(s0)                                                 \
+                   : "n"(WAIT_COUNT)                                          \
+                   : "memory");                                               \
+    } else {                                                                  \
+      asm volatile("s_waitcnt vmcnt(%5)"                                      \
+                   : "+v"(e[K][0]), "+v"(e[K][1 % BATCH]),                    \
+                     "+v"(e[K][2 % BATCH]), "+v"(e[K][3 % BATCH]),            \
+                     "+v"(rid[K])                                             \
+                   : "n"(WAIT_COUNT)                                          \
+                   : "memory");                                               \
+    }                                                                         \
+  } while (0)
+
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const uint2 e = (u == 0) ? a : (u == 1) ? b : (u == 2) ? c : d;
-            const double4 vv =
-                *reinterpret_cast<const double4*>(v + (int64_t)u * WAVE * 4);
-            s0 += vv.x * xs[e.x & 0xFFFFu] + vv.z * xs[e.y & 0xFFFFu];
-            s1 += vv.y * xs[e.x >> 16] + vv.w * xs[e.y >> 16];
+  for (int k = 0; k < RING; ++k) BBX_ISSUE(k);
+  bool done = false;
+  while (!done) {
+#pragma unroll
+    for (int k = 0; k < RING; ++k) {
+      if (!done) {
+        const unsigned inf = info[k];
+        if (inf & BD_END) {
+          done = true;
+        } else {
+          if (inf & BD_TILE_FIRST) {
+            // ---- enter the next tile: replace the vector slice in LDS
+            ++t;
+            const TileDesc td = tiles[t];
+            const int64_t col0 = (int64_t)td.col_block * W;
+            const int cols_here = (int)((C - col0 < W) ? (C - col0) : W);
+            double fv[FILL_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FILL_UNROLL; ++u) {
+              const int j = tid + u * TILE_THREADS;
+              fv[u] = (j < cols_here && !(ablate & 2)) ? x[col0 + j] : 0.;
+            }
+            __syncthreads();  // every wave is done with the previous slice
+            // one explicit wait for the slice values on every path, so that no
+            // compiler-visible load is left "maybe pending" inside the loop
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+#pragma unroll
+            for (int u = 0; u < FILL_UNROLL; ++u) {
+              const int j = tid + u * TILE_THREADS;
+              if (j < W) xs[j] = fv[u];
+            }
+            __syncthreads();
           }
-        } else {
-          s0 += xs[a.x & 0xFFFFu] + xs[a.y & 0xFFFFu];
-          s1 += xs[a.x >> 16] + xs[a.y >> 16];
-          s0 += xs[b.x & 0xFFFFu] + xs[b.y & 0xFFFFu];
-          s1 += xs[b.x >> 16] + xs[b.y >> 16];
-          s0 += xs[c.x & 0xFFFFu] + xs[c.y & 0xFFFFu];
-          s1 += xs[c.x >> 16] + xs[c.y >> 16];
-          s0 += xs[d.x & 0xFFFFu] + xs[d.y & 0xFFFFu];
-          s1 += xs[d.x >> 16] + xs[d.y >> 16];
+          const int cntk = (int)(inf & 15u);
+          if (cntk > 0) {
+            BBX_WAIT(k);
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+              if (u < cntk) {
+                if (ablate & 1)
+                  s0 += (double)(e[k][u].x ^ e[k][u].y);
+                else
+                  quad_accumulate<VALS>(xs, e[k][u], eva[k][u], evb[k][u], s0,
+                                        s1);
+              }
+            if (inf & BD_LAST) {
+              const unsigned rr = rid[k];
+              if (rr != NO_ROW) acc[rr] += s0 + s1;
+              s0 = 0.;
+              s1 = 0.;
+            }
+          }
+          BBX_ISSUE(k);
         }
       }
-      for (; q < sm.n_quad; ++q) {
-        const uint2 a = p[q * WAVE];
-        if (VALS) {
-          const double4 vv =
-              *reinterpret_cast<const double4*>(pv + (int64_t)q * WAVE * 4);
-          s0 += vv.x * xs[a.x & 0xFFFFu] + vv.z * xs[a.y & 0xFFFFu];
-          s1 += vv.y * xs[a.x >> 16] + vv.w * xs[a.y >> 16];
-        } else {
-          s0 += xs[a.x & 0xFFFFu] + xs[a.y & 0xFFFFu];
-          s1 += xs[a.x >> 16] + xs[a.y >> 16];
-        }
-      }
-      if (rid != NO_ROW) acc[rid] += s0 + s1;
     }
   }
+  // Drain the dummy loads still in flight; naming every slot keeps the
+  // destination registers allocated until the data has landed.
+#pragma unroll
+  for (int k = 0; k < RING; ++k) {
+    if (VALS) {
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(e[k][0]), "+v"(e[k][BATCH - 1]), "+v"(rid[k]),
+                     "+v"(eva[k][0]), "+v"(evb[k][0]), "+v"(eva[k][BATCH - 1]),
+                     "+v"(evb[k][BATCH - 1])
+                   :
+                   : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(e[k][0]), "+v"(e[k][1 % BATCH]),
+                     "+v"(e[k][2 % BATCH]), "+v"(e[k][3 % BATCH]), "+v"(rid[k])
+                   :
+                   : "memory");
+    }
+  }
+#undef BBX_ISSUE
+#undef BBX_WAIT
   __syncthreads();
   if (out) {
     // direct epilogue: c = x0 - sum(c_part), summed once in a fixed order
@@ -228,7 +400,63 @@ struct PanelBuild {
   std::vector<uint16_t> rowids;
   std::vector<TileDesc> tiles;    // slice ids local to the panel
   std::vector<int32_t> group_tile_count;
+  std::vector<BatchDesc> descs;   // quad0/row_slot local to the panel
+  std::vector<int32_t> wave_desc; // [G * TILE_WAVES] local start of each wave
 };
+
+// Per-wave schedules of one panel: for every workgroup (group of column
+// blocks) and wave, the batches of its slices in processing order.  Slices of
+// a tile are dealt to the 16 waves in snake order; they are sorted by
+// decreasing length, so this balances the waves.
+static void build_schedules(PanelBuild& pb, int G, int batch) {
+  pb.wave_desc.assign((size_t)G * TILE_WAVES, 0);
+  size_t tile_cursor = 0;
+  for (int g = 0; g < G; ++g) {
+    const size_t t0 = tile_cursor, t1 = tile_cursor + pb.group_tile_count[g];
+    tile_cursor = t1;
+    for (int w = 0; w < TILE_WAVES; ++w) {
+      pb.wave_desc[(size_t)g * TILE_WAVES + w] = (int32_t)pb.descs.size();
+      for (size_t t = t0; t < t1; ++t) {
+        const TileDesc& td = pb.tiles[t];
+        const int n_sl = td.slice_end - td.slice_begin;
+        bool first = true;
+        for (int round = 0; round * TILE_WAVES < n_sl; ++round) {
+          const int pos = (round & 1) ? (TILE_WAVES - 1 - w) : w;
+          const int idx = round * TILE_WAVES + pos;
+          if (idx >= n_sl) continue;
+          const int sl = td.slice_begin + idx;
+          const SliceMeta& sm = pb.slices[(size_t)sl];
+          for (uint32_t q0 = 0; q0 < sm.n_quad; q0 += (uint32_t)batch) {
+            BatchDesc d;
+            d.quad0 = sm.first_quad + q0;
+            d.row_slot = (uint32_t)sl * WAVE;
+            const uint32_t left = sm.n_quad - q0;
+            d.info = left < (uint32_t)batch ? left : (uint32_t)batch;
+            if (left <= (uint32_t)batch) d.info |= BD_LAST;
+            if (first) d.info |= BD_TILE_FIRST;
+            d.pad = 0;
+            first = false;
+            pb.descs.push_back(d);
+          }
+        }
+        if (first) {  // no slice of this tile for this wave: barrier marker
+          BatchDesc d;
+          d.quad0 = 0;
+          d.row_slot = 0;
+          d.info = BD_TILE_FIRST;
+          d.pad = 0;
+          pb.descs.push_back(d);
+        }
+      }
+      BatchDesc endd;
+      endd.quad0 = 0;
+      endd.row_slot = 0;
+      endd.info = BD_END;
+      endd.pad = 0;
+      pb.descs.push_back(endd);
+    }
+  }
+}
 
 static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
                         const int32_t* colidx, const double* vals, int W,
@@ -322,6 +550,7 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
     pb.tiles.push_back(td);
     pb.group_tile_count[cb / blocks_per_group] += 1;
   }
+  build_schedules(pb, G, vals ? BATCH_VAL : BATCH_BIN);
 }
 
 // Picks (PR, G): panels x groups of column blocks ~ one or two waves of
@@ -401,32 +630,40 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
   for (auto& th : pool) th.join();
 
   // concatenate with offset fix-ups
-  size_t tot_ids = 0, tot_slices = 0, tot_tiles = 0;
+  size_t tot_ids = 0, tot_slices = 0, tot_tiles = 0, tot_descs = 0;
   for (auto& pb : pbs) {
     tot_ids += pb.ids.size();
     tot_slices += pb.slices.size();
     tot_tiles += pb.tiles.size();
+    tot_descs += pb.descs.size();
   }
   if (tot_ids / WAVE >= ((size_t)1 << 32))
     return fail(BBX_ERR_INVALID, "matrix too large for the tiled format");
   std::vector<uint2> ids(tot_ids);
   std::vector<double> vv(m.has_vals ? tot_ids * 4 : 0);
-  std::vector<SliceMeta> slices(tot_slices);
+  std::vector<BatchDesc> descs(tot_descs);
+  std::vector<int32_t> wave_desc((size_t)m.n_panel * m.G * TILE_WAVES, 0);
   std::vector<uint16_t> rowids(tot_slices * WAVE);
   std::vector<TileDesc> tiles(tot_tiles);
   std::vector<int32_t> wg_tiles((size_t)m.n_panel * m.G + 1, 0);
-  size_t id_off = 0, sl_off = 0, ti_off = 0;
+  size_t id_off = 0, sl_off = 0, ti_off = 0, de_off = 0;
   for (int p = 0; p < m.n_panel; ++p) {
     PanelBuild& pb = pbs[(size_t)p];
     if (!pb.ids.empty())
       memcpy(&ids[id_off], pb.ids.data(), pb.ids.size() * sizeof(uint2));
     if (m.has_vals && !pb.vals.empty())
       memcpy(&vv[id_off * 4], pb.vals.data(), pb.vals.size() * sizeof(double));
-    for (size_t s = 0; s < pb.slices.size(); ++s) {
-      SliceMeta sm = pb.slices[s];
-      sm.first_quad += (uint32_t)(id_off / WAVE);
-      slices[sl_off + s] = sm;
+    for (size_t k = 0; k < pb.descs.size(); ++k) {
+      BatchDesc d = pb.descs[k];
+      if (d.info & 15u) {
+        d.quad0 += (uint32_t)(id_off / WAVE);
+        d.row_slot += (uint32_t)(sl_off * WAVE);
+      }
+      descs[de_off + k] = d;
     }
+    for (size_t k = 0; k < pb.wave_desc.size(); ++k)
+      wave_desc[(size_t)p * m.G * TILE_WAVES + k] =
+          pb.wave_desc[k] + (int32_t)de_off;
     if (!pb.rowids.empty())
       memcpy(&rowids[sl_off * WAVE], pb.rowids.data(),
              pb.rowids.size() * sizeof(uint16_t));
@@ -444,6 +681,7 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
     id_off += pb.ids.size();
     sl_off += pb.slices.size();
     ti_off += pb.tiles.size();
+    de_off += pb.descs.size();
     std::vector<uint2>().swap(pb.ids);
     std::vector<double>().swap(pb.vals);
   }
@@ -454,7 +692,23 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
   BBX_TRY(upload(m.ids, ids.data(), ids.size() * sizeof(uint2)));
   if (m.has_vals)
     BBX_TRY(upload(m.vals, vv.data(), vv.size() * sizeof(double)));
-  BBX_TRY(upload(m.slices, slices.data(), slices.size() * sizeof(SliceMeta)));
+  m.n_desc = (int64_t)tot_descs;
+  // the kernel addresses the streams with 32-bit byte offsets
+  if ((uint64_t)tot_ids * (m.has_vals ? 32u : 8u) >= ((uint64_t)1 << 32))
+    return fail(BBX_ERR_INVALID, "matrix too large for the tiled format");
+  if (tot_slices * WAVE >= ((size_t)1 << 31) || tot_descs >= ((size_t)1 << 31))
+    return fail(BBX_ERR_INVALID, "matrix too large for the tiled format");
+  {  // the kernel prefetches descriptors in blocks of 64: keep reads in bounds
+    BatchDesc endd;
+    endd.quad0 = 0;
+    endd.row_slot = 0;
+    endd.info = BD_END;
+    endd.pad = 0;
+    descs.resize(descs.size() + 2 * WAVE, endd);
+  }
+  BBX_TRY(upload(m.descs, descs.data(), descs.size() * sizeof(BatchDesc)));
+  BBX_TRY(upload(m.wave_desc, wave_desc.data(),
+                 wave_desc.size() * sizeof(int32_t)));
   BBX_TRY(upload(m.rowids, rowids.data(), rowids.size() * sizeof(uint16_t)));
   BBX_TRY(upload(m.tiles, tiles.data(), tiles.size() * sizeof(TileDesc)));
   BBX_TRY(upload(m.wg_tiles, wg_tiles.data(),
@@ -532,20 +786,22 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                         const double* rowscale, double* out, double* slab) {
   const unsigned grid = (unsigned)(m.n_panel * m.G);
   const size_t lb = lds_bytes(m);
+  static const int ablate = getenv("BBX_ABLATE") ? atoi(getenv("BBX_ABLATE")) : 0;
   if (m.has_vals)
     hipLaunchKernelGGL(tiled_spmv_kernel<true>, dim3(grid), dim3(TILE_THREADS),
                        lb, h->stream, m.R, m.C, m.W, m.PR, m.G,
                        m.wg_tiles.as<int32_t>(), m.tiles.as<TileDesc>(),
-                       m.slices.as<SliceMeta>(), m.rowids.as<uint16_t>(),
-                       m.ids.as<uint2>(), m.vals.as<double>(), x, c_part, x0_ptr,
-                       rowscale, out, slab);
+                       m.wave_desc.as<int32_t>(), m.descs.as<BatchDesc>(),
+                       m.rowids.as<uint16_t>(), m.ids.as<uint2>(),
+                       m.vals.as<double>(), x, c_part, x0_ptr, rowscale, out,
+                       slab, ablate);
   else
     hipLaunchKernelGGL(tiled_spmv_kernel<false>, dim3(grid),
                        dim3(TILE_THREADS), lb, h->stream, m.R, m.C, m.W, m.PR,
                        m.G, m.wg_tiles.as<int32_t>(), m.tiles.as<TileDesc>(),
-                       m.slices.as<SliceMeta>(), m.rowids.as<uint16_t>(),
-                       m.ids.as<uint2>(), nullptr, x, c_part, x0_ptr, rowscale,
-                       out, slab);
+                       m.wave_desc.as<int32_t>(), m.descs.as<BatchDesc>(),
+                       m.rowids.as<uint16_t>(), m.ids.as<uint2>(), nullptr, x,
+                       c_part, x0_ptr, rowscale, out, slab, ablate);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }

@@ -31,6 +31,8 @@ design = HipSparseDesignMatrix.from_device_csr(
     add_intercept=True, device=0, storage=storage)
 print("design built in %.1fs, storage %.1f MB, format %s" % (
     time.time() - t0, design.storage_bytes / 1e6, design.storage_format))
+if design.storage_format == 'tiled':
+    print("tiled geometry:", design.tiled_info())
 lib = _lib.load()
 P = p + 1
 v = torch.randn(P, dtype=torch.float64, device='cuda')
