@@ -180,7 +180,7 @@ static int finish_csr(bbx_design* h, int format) {
     h->binary = true;
   }
   BBX_TRY(build_transpose_csr(h));
-  if (format == BBX_FORMAT_AUTO) format = BBX_FORMAT_CSR;
+  if (format == BBX_FORMAT_AUTO) format = BBX_FORMAT_TILED;
   h->format = format;
   if (format == BBX_FORMAT_TILED) BBX_TRY(build_tiled(h));
   return BBX_OK;

@@ -12,16 +12,23 @@
 //     vector (W doubles) fits in LDS next to PR row accumulators;
 //   * rows are cut into panels of PR rows; tile = (panel, column block);
 //   * inside a tile the non-empty rows are sorted by their entry count and
-//     grouped 64 at a time into slices (one wavefront each, lane = row), stored
-//     "sliced ELL": [quad q][lane][4] block-local uint16 column ids, padded to
+//     grouped 128 at a time into slices (one wavefront each, two rows per
+//     lane), stored "sliced ELL": [step q][lane][row A: 4 ids | row B: 4 ids]
+//     block-local uint16 column ids = one 16-byte load per lane and step
+//     (8-byte loads reach only ~0.6x the HBM rate of 16-byte ones), padded to
 //     a multiple of 4 entries with an id that points at a 0.0 in LDS;
+//   * a row whose segment in some tile is much longer than the others' (the
+//     column counts of simulate_data.py designs are heavy-tailed) is split into
+//     chunks of <= T entries that sort next to rows of that length; every
+//     chunk past the first owns an extra LDS accumulator that the epilogue
+//     folds into the row in a fixed order (no atomics, bitwise reproducible);
 //   * values are stored only when some entry differs from 1.0 (binary designs
 //     of simulate_data.py:100-117 never read values; the unwired prototype
 //     design_matrix/cython_matmal/binary_matmul.pyx:21-25 had the same idea).
 //
 // One workgroup (1024 threads, 16 waves, one per CU) owns a row panel and a
 // group of column blocks: it fills the vector slice, streams the tile's ids
-// with coalesced 512-byte wave loads (the only HBM traffic that scales with
+// with coalesced 1 KiB wave loads (the only HBM traffic that scales with
 // nnz: 2 bytes per entry), adds lane-private sums into LDS accumulators, and
 // writes the panel once.  No atomics: every sum has a fixed order.
 #include <algorithm>
@@ -45,25 +52,27 @@ struct TileDesc {
   int32_t pad;
 };
 
+constexpr int SLICE_ROWS = 2 * WAVE;  // two rows per lane
+
 struct SliceMeta {
-  uint32_t first_quad;  // offset into the id stream in units of 64 uint2
-  uint32_t n_quad;      // groups of 4 entries per lane
+  uint32_t first_quad;  // offset into the id stream in units of 64 uint4
+  uint32_t n_quad;      // steps: 4 entries of row A + 4 of row B per lane
 };
 
 // One step of a wave's precomputed schedule: BATCH consecutive quads of one
 // slice.  The schedule of every (workgroup, wave) is laid out in processing
 // order, so the kernel's issue cursor is a single scalar index.
 struct BatchDesc {
-  uint32_t quad0;     // first quad (units of 64 uint2 in the id stream)
-  uint32_t row_slot;  // slice * 64: where the slice's row ids start
+  uint32_t quad0;     // first step (units of 64 uint4 in the id stream)
+  uint32_t row_slot;  // slice * 64: where the slice's row-id pairs start
   uint32_t info;      // bits 0-3 count, 8 last-of-slice, 9 tile-first, 10 end
   uint32_t pad;
 };
 constexpr uint32_t BD_LAST = 1u << 8;
 constexpr uint32_t BD_TILE_FIRST = 1u << 9;
 constexpr uint32_t BD_END = 1u << 10;
-constexpr int BATCH_BIN = 4;   // quads per ring slot, value-free stream
-constexpr int BATCH_VAL = 2;   // quads per ring slot when values are stored
+constexpr int BATCH_BIN = 2;   // steps per ring slot, value-free stream
+constexpr int BATCH_VAL = 1;   // steps per ring slot when values are stored
 
 // One orientation (X or X^T) in tiled form, device resident.
 struct TiledMatrix {
@@ -71,20 +80,29 @@ struct TiledMatrix {
   int W = 0, n_block = 0, PR = 0, n_panel = 0, G = 0;
   bool has_vals = false;
   int64_t n_slice = 0, n_quad = 0, n_tile = 0;
-  DevMem ids;        // uint2[n_quad * 64]
-  DevMem vals;       // double[n_quad * 64 * 4] when has_vals
+  DevMem ids;        // uint4[n_quad * 64]
+  DevMem vals;       // double[n_quad * 64 * 8] when has_vals
   DevMem descs;      // BatchDesc[n_desc]: per-wave schedules
   DevMem wave_desc;  // int32[n_panel * G * 16]: first descriptor of each wave
   int64_t n_desc = 0;
-  DevMem rowids;     // uint16[n_slice * 64] panel-local row of each lane
+  DevMem rowids;     // uint32[n_slice * 64]: panel-local rows A | B << 16
   DevMem tiles;      // TileDesc[n_tile]
   DevMem wg_tiles;   // int32[n_panel * G + 1]
+  DevMem folds;      // FoldDesc[n_fold]
+  DevMem panel_fold; // int32[n_panel + 1]
+  int n_extra = 0;   // extra accumulators per panel (row splitting)
+  int split_T = 0;   // smallest split threshold used by any panel (0 = none)
   DevMem slab;       // double[G * R] partial sums when G > 1 (or Tdot)
   int64_t stream_bytes() const {
-    return (int64_t)n_quad * 64 * 8 * (has_vals ? 5 : 1) +
-           (int64_t)n_slice * 128 + (int64_t)n_desc * (int64_t)sizeof(BatchDesc) +
+    return (int64_t)n_quad * 64 * 16 * (has_vals ? 5 : 1) +
+           (int64_t)n_slice * 256 + (int64_t)n_desc * (int64_t)sizeof(BatchDesc) +
            (int64_t)n_tile * (int64_t)sizeof(TileDesc);
   }
+};
+
+// Row r of a panel was split: acc[r] += acc[first .. first+count) at the end.
+struct FoldDesc {
+  uint16_t row, first, count, pad;
 };
 
 struct TiledPair {
@@ -93,20 +111,26 @@ struct TiledPair {
 
 // ------------------------------------------------------------------ kernel
 
-typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-// Adds the 4 gathered entries of one quad to the two running sums.
+// One step of one lane: 4 entries of its row A (e.x, e.y) and 4 of its row B
+// (e.z, e.w), gathered from the vector slice in LDS.
 template <bool VALS>
-__device__ __forceinline__ void quad_accumulate(const double* __restrict__ xs,
-                                                v2u e, v2d va, v2d vb,
-                                                double& s0, double& s1) {
+__device__ __forceinline__ void step_accumulate(const double* __restrict__ xs,
+                                                v4u e, const v2d* v,
+                                                double& a0, double& a1,
+                                                double& b0, double& b1) {
   if (VALS) {
-    s0 += va.x * xs[e.x & 0xFFFFu] + vb.x * xs[e.y & 0xFFFFu];
-    s1 += va.y * xs[e.x >> 16] + vb.y * xs[e.y >> 16];
+    a0 += v[0].x * xs[e.x & 0xFFFFu] + v[1].x * xs[e.y & 0xFFFFu];
+    a1 += v[0].y * xs[e.x >> 16] + v[1].y * xs[e.y >> 16];
+    b0 += v[2].x * xs[e.z & 0xFFFFu] + v[3].x * xs[e.w & 0xFFFFu];
+    b1 += v[2].y * xs[e.z >> 16] + v[3].y * xs[e.w >> 16];
   } else {
-    s0 += xs[e.x & 0xFFFFu] + xs[e.y & 0xFFFFu];
-    s1 += xs[e.x >> 16] + xs[e.y >> 16];
+    a0 += xs[e.x & 0xFFFFu] + xs[e.y & 0xFFFFu];
+    a1 += xs[e.x >> 16] + xs[e.y >> 16];
+    b0 += xs[e.z & 0xFFFFu] + xs[e.w & 0xFFFFu];
+    b1 += xs[e.z >> 16] + xs[e.w >> 16];
   }
 }
 
@@ -118,9 +142,9 @@ __device__ __forceinline__ void quad_accumulate(const double* __restrict__ xs,
 // step queues exactly LOADS_PER_STEP vector-memory operations, so before
 // consuming a ring slot at most (RING-1)*LOADS_PER_STEP younger ones may still
 // be in flight.  Unknown extra compiler loads can only make the wait stricter.
-__device__ __forceinline__ void asm_load_x2(v2u& dst, unsigned off,
+__device__ __forceinline__ void asm_load_x4(v4u& dst, unsigned off,
                                             const void* base) {
-  asm volatile("global_load_dwordx2 %0, %1, %2"
+  asm volatile("global_load_dwordx4 %0, %1, %2"
                : "=v"(dst)
                : "v"(off), "s"(base)
                : "memory");
@@ -132,9 +156,9 @@ __device__ __forceinline__ void asm_load_d2(v2d& dst, unsigned off,
                : "v"(off), "s"(base)
                : "memory");
 }
-__device__ __forceinline__ void asm_load_u16(unsigned& dst, unsigned off,
+__device__ __forceinline__ void asm_load_u32(unsigned& dst, unsigned off,
                                              const void* base) {
-  asm volatile("global_load_ushort %0, %1, %2"
+  asm volatile("global_load_dword %0, %1, %2"
                : "=v"(dst)
                : "v"(off), "s"(base)
                : "memory");
@@ -147,17 +171,19 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
     int64_t R, int64_t C, int W, int PR, int G,
     const int32_t* __restrict__ wg_tiles, const TileDesc* __restrict__ tiles,
     const int32_t* __restrict__ wave_desc,
-    const BatchDesc* __restrict__ descs, const uint16_t* __restrict__ rowids,
-    const uint2* __restrict__ ids, const double* __restrict__ vals,
+    const BatchDesc* __restrict__ descs, const uint32_t* __restrict__ rowids,
+    const uint4* __restrict__ ids, const double* __restrict__ vals,
     const double* __restrict__ x,
     // epilogue (direct mode, G == 1 and out != nullptr):
     //   out[r] = rowscale[r] * (c0 - sum(c_part) + acc)
     const double* __restrict__ c_part, const double* x0_ptr,
     const double* __restrict__ rowscale, double* __restrict__ out,
-    double* __restrict__ slab, int ablate) {
+    double* __restrict__ slab, int n_acc,
+    const int32_t* __restrict__ panel_fold, const FoldDesc* __restrict__ folds,
+    int ablate) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* xs = lds;               // W + 8 doubles; xs[W] == 0 (padding target)
-  double* acc = lds + (W + 8);    // PR doubles
+  double* acc = lds + (W + 8);    // n_acc = PR + extra doubles
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
@@ -166,12 +192,13 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
   const int64_t row0 = (int64_t)panel * PR;
   const int rows_here = (int)((R - row0 < PR) ? (R - row0) : PR);
 
-  for (int r = tid; r < PR; r += TILE_THREADS) acc[r] = 0.;
+  for (int r = tid; r < n_acc; r += TILE_THREADS) acc[r] = 0.;
   if (tid < 8) xs[W + tid] = 0.;
 
-  constexpr int BATCH = VALS ? BATCH_VAL : BATCH_BIN;  // quads per ring slot
+  constexpr int BATCH = VALS ? BATCH_VAL : BATCH_BIN;  // steps per ring slot
   constexpr int RING = VALS ? 3 : 4;   // slots: RING-1 batches in flight
-  constexpr int LOADS_PER_STEP = BATCH * (VALS ? 3 : 1) + 1;
+  constexpr int NV = VALS ? 4 : 1;     // 16-byte value loads per step
+  constexpr int LOADS_PER_STEP = BATCH * (VALS ? 5 : 1) + 1;
   constexpr int WAIT_COUNT = (RING - 1) * LOADS_PER_STEP;
   static_assert(WAIT_COUNT < 64, "vmcnt is a 6-bit field");
 
@@ -191,30 +218,33 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
   uint4 dnxt = desc4[blk + WAVE + lane];
   // Retire every compiler-visible load before the ring starts (see ISSUE).
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
-  v2u e[RING][BATCH];
-  v2d eva[RING][BATCH], evb[RING][BATCH];
+  v4u e[RING][BATCH];
+  v2d ev[RING][BATCH][NV];
   unsigned rid[RING];
   unsigned info[RING];
-  double s0 = 0., s1 = 0.;
+  double a0 = 0., a1 = 0., b0 = 0., b1 = 0.;
 
 #define BBX_ISSUE(K)                                                          \
   do {                                                                        \
-    const unsigned d_quad0 = (unsigned)__builtin_amdgcn_readlane((int)dcur.x, pos); \
-    const unsigned d_row = (unsigned)__builtin_amdgcn_readlane((int)dcur.y, pos);   \
-    const unsigned inf = (unsigned)__builtin_amdgcn_readlane((int)dcur.z, pos);     \
+    const unsigned d_quad0 =                                                  \
+        (unsigned)__builtin_amdgcn_readlane((int)dcur.x, pos);                \
+    const unsigned d_row =                                                    \
+        (unsigned)__builtin_amdgcn_readlane((int)dcur.y, pos);                \
+    const unsigned inf =                                                      \
+        (unsigned)__builtin_amdgcn_readlane((int)dcur.z, pos);                \
     const int cntk = (int)(inf & 15u);                                        \
     const int left = cntk > 0 ? cntk : 1;                                     \
     const unsigned quad0 = cntk > 0 ? d_quad0 : 0u;                           \
     _Pragma("unroll") for (int u = 0; u < BATCH; ++u) {                       \
       const unsigned uu = (unsigned)((u < left) ? u : left - 1);              \
       const unsigned slot = (quad0 + uu) * WAVE + lane;                       \
-      asm_load_x2(e[K][u], slot * 8u, ids);                                   \
+      asm_load_x4(e[K][u], slot * 16u, ids);                                  \
       if (VALS) {                                                             \
-        asm_load_d2(eva[K][u], slot * 32u, vals);                             \
-        asm_load_d2(evb[K][u], slot * 32u + 16u, vals);                       \
+        _Pragma("unroll") for (int j = 0; j < NV; ++j)                        \
+            asm_load_d2(ev[K][u][j], slot * 64u + 16u * j, vals);             \
       }                                                                       \
     }                                                                         \
-    asm_load_u16(rid[K], ((cntk > 0 ? d_row : 0u) + lane) * 2u, rowids);      \
+    asm_load_u32(rid[K], ((cntk > 0 ? d_row : 0u) + lane) * 4u, rowids);      \
     info[K] = inf;                                                            \
     if (!(inf & BD_END)) {                                                    \
       ++pos;                                                                  \
@@ -236,18 +266,14 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
 #define BBX_WAIT(K)                                                           \
   do {                                                                        \
     if (VALS) {                                                               \
-      asm volatile("s_waitcnt vmcnt(%8)"                                      \
-                   : "+v"(e[K][0]), "+v"(e[K][BATCH - 1]), "+v"(rid[K]),      \
-                     "+v"(eva[K][0]), "+v"(evb[K][0]),                        \
-                     "+v"(eva[K][BATCH - 1]), "+v"(evb[K][BATCH - 1]),        \
-                     "+v"(s0)                                                 \
+      asm volatile("s_waitcnt vmcnt(%6)"                                      \
+                   : "+v"(e[K][0]), "+v"(rid[K]), "+v"(ev[K][0][0]),          \
+                     "+v"(ev[K][0][1]), "+v"(ev[K][0][2]), "+v"(ev[K][0][3])  \
                    : "n"(WAIT_COUNT)                                          \
                    : "memory");                                               \
     } else {                                                                  \
-      asm volatile("s_waitcnt vmcnt(%5)"                                      \
-                   : "+v"(e[K][0]), "+v"(e[K][1 % BATCH]),                    \
-                     "+v"(e[K][2 % BATCH]), "+v"(e[K][3 % BATCH]),            \
-                     "+v"(rid[K])                                             \
+      asm volatile("s_waitcnt vmcnt(%3)"                                      \
+                   : "+v"(e[K][0]), "+v"(e[K][BATCH - 1]), "+v"(rid[K])       \
                    : "n"(WAIT_COUNT)                                          \
                    : "memory");                                               \
     }                                                                         \
@@ -294,16 +320,16 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
             for (int u = 0; u < BATCH; ++u)
               if (u < cntk) {
                 if (ablate & 1)
-                  s0 += (double)(e[k][u].x ^ e[k][u].y);
+                  a0 += (double)(e[k][u].x ^ e[k][u].y ^ e[k][u].z ^ e[k][u].w);
                 else
-                  quad_accumulate<VALS>(xs, e[k][u], eva[k][u], evb[k][u], s0,
-                                        s1);
+                  step_accumulate<VALS>(xs, e[k][u], ev[k][u], a0, a1, b0, b1);
               }
             if (inf & BD_LAST) {
               const unsigned rr = rid[k];
-              if (rr != NO_ROW) acc[rr] += s0 + s1;
-              s0 = 0.;
-              s1 = 0.;
+              const unsigned ra = rr & 0xFFFFu, rb = rr >> 16;
+              if (ra != NO_ROW) acc[ra] += a0 + a1;
+              if (rb != NO_ROW) acc[rb] += b0 + b1;
+              a0 = a1 = b0 = b1 = 0.;
             }
           }
           BBX_ISSUE(k);
@@ -317,15 +343,13 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
   for (int k = 0; k < RING; ++k) {
     if (VALS) {
       asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(e[k][0]), "+v"(e[k][BATCH - 1]), "+v"(rid[k]),
-                     "+v"(eva[k][0]), "+v"(evb[k][0]), "+v"(eva[k][BATCH - 1]),
-                     "+v"(evb[k][BATCH - 1])
+                   : "+v"(e[k][0]), "+v"(rid[k]), "+v"(ev[k][0][0]),
+                     "+v"(ev[k][0][1]), "+v"(ev[k][0][2]), "+v"(ev[k][0][3])
                    :
                    : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(e[k][0]), "+v"(e[k][1 % BATCH]),
-                     "+v"(e[k][2 % BATCH]), "+v"(e[k][3 % BATCH]), "+v"(rid[k])
+                   : "+v"(e[k][0]), "+v"(e[k][BATCH - 1]), "+v"(rid[k])
                    :
                    : "memory");
     }
@@ -333,6 +357,16 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
 #undef BBX_ISSUE
 #undef BBX_WAIT
   __syncthreads();
+  {  // fold the chunk accumulators of split rows, fixed order
+    const int f0 = panel_fold[panel], f1 = panel_fold[panel + 1];
+    for (int f = f0 + tid; f < f1; f += TILE_THREADS) {
+      const FoldDesc fd = folds[f];
+      double v = acc[fd.row];
+      for (int c = 0; c < fd.count; ++c) v += acc[fd.first + c];
+      acc[fd.row] = v;
+    }
+    if (f1 > f0) __syncthreads();
+  }
   if (out) {
     // direct epilogue: c = x0 - sum(c_part), summed once in a fixed order
     if (tid < WAVE) {
@@ -394,12 +428,14 @@ __global__ __launch_bounds__(256) void tiled_slab_sum_kernel(
 // ----------------------------------------------------------------- builder
 
 struct PanelBuild {
-  std::vector<uint2> ids;
+  std::vector<uint4> ids;
   std::vector<double> vals;
   std::vector<SliceMeta> slices;  // first_quad local to the panel
-  std::vector<uint16_t> rowids;
+  std::vector<uint32_t> rowids;
   std::vector<TileDesc> tiles;    // slice ids local to the panel
   std::vector<int32_t> group_tile_count;
+  std::vector<FoldDesc> folds;    // split rows of this panel
+  int split_T = 0;
   std::vector<BatchDesc> descs;   // quad0/row_slot local to the panel
   std::vector<int32_t> wave_desc; // [G * TILE_WAVES] local start of each wave
 };
@@ -458,51 +494,131 @@ static void build_schedules(PanelBuild& pb, int G, int batch) {
   }
 }
 
+struct VRow {
+  int32_t begin;  // first entry (index into colidx)
+  int32_t len;
+  uint16_t slot;  // accumulator slot in LDS (row, or extra slot of a chunk)
+};
+
 static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
                         const int32_t* colidx, const double* vals, int W,
-                        int n_block, int PR, int G, int panel,
-                        PanelBuild& pb) {
+                        int n_block, int PR, int G, int extra_budget,
+                        int panel, PanelBuild& pb) {
   const int64_t row0 = (int64_t)panel * PR;
   const int rows_here = (int)std::min<int64_t>(PR, R - row0);
-  std::vector<int32_t> cursor(rows_here), seg_begin(rows_here),
-      seg_len(rows_here);
-  for (int r = 0; r < rows_here; ++r) cursor[r] = rowptr[row0 + r];
+  // pass 1: segment of every row in every column block
+  std::vector<int32_t> seg_begin((size_t)rows_here * n_block),
+      seg_len((size_t)rows_here * n_block);
+  std::vector<int32_t> max_seg(rows_here, 0);
+  for (int r = 0; r < rows_here; ++r) {
+    int32_t k = rowptr[row0 + r];
+    const int32_t e = rowptr[row0 + r + 1];
+    for (int cb = 0; cb < n_block; ++cb) {
+      const int64_t col_end = std::min<int64_t>((int64_t)(cb + 1) * W, C);
+      const int32_t b = k;
+      while (k < e && colidx[k] < col_end) ++k;
+      seg_begin[(size_t)cb * rows_here + r] = b;
+      seg_len[(size_t)cb * rows_here + r] = k - b;
+      if (k - b > max_seg[r]) max_seg[r] = k - b;
+    }
+  }
+  // split threshold T: the smallest one whose extra accumulators fit
+  auto extras_for = [&](int T) {
+    int64_t ex = 0;
+    for (int r = 0; r < rows_here; ++r)
+      if (max_seg[r] > T) ex += (max_seg[r] + T - 1) / T - 1;
+    return ex;
+  };
+  int T = 0;  // 0 = no splitting
+  {
+    int longest = 0;
+    for (int r = 0; r < rows_here; ++r) longest = std::max(longest, max_seg[r]);
+    // never split below 3x the mean non-empty segment: balanced matrices
+    // (e.g. the rows of X) gain nothing and would only get more slices
+    int64_t seg_sum = 0, seg_cnt = 0;
+    for (int32_t v : seg_len)
+      if (v > 0) {
+        seg_sum += v;
+        ++seg_cnt;
+      }
+    int t_min = 32;
+    if (seg_cnt > 0) t_min = std::max<int>(t_min, (int)(3 * seg_sum / seg_cnt));
+    if (extra_budget > 0 && longest > t_min) {
+      int lo = t_min, hi = longest;  // extras_for(hi) == 0
+      while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (extras_for(mid) <= extra_budget) hi = mid; else lo = mid + 1;
+      }
+      T = lo;
+      if (T >= longest) T = 0;
+    }
+  }
+  pb.split_T = T;
+  // extra slots of the split rows
+  std::vector<int32_t> extra_first(rows_here, -1);
+  int n_extra = 0;
+  if (T > 0)
+    for (int r = 0; r < rows_here; ++r)
+      if (max_seg[r] > T) {
+        const int k = (max_seg[r] + T - 1) / T;
+        extra_first[r] = PR + n_extra;
+        FoldDesc fd;
+        fd.row = (uint16_t)r;
+        fd.first = (uint16_t)(PR + n_extra);
+        fd.count = (uint16_t)(k - 1);
+        fd.pad = 0;
+        pb.folds.push_back(fd);
+        n_extra += k - 1;
+      }
+  // pass 2: tiles
   pb.group_tile_count.assign(G, 0);
   const int blocks_per_group = (n_block + G - 1) / G;
-  std::vector<int> order;
+  std::vector<VRow> vrows, sorted;
   std::vector<int> bucket;
   for (int cb = 0; cb < n_block; ++cb) {
-    const int64_t col_end = std::min<int64_t>((int64_t)(cb + 1) * W, C);
     const int64_t col0 = (int64_t)cb * W;
+    vrows.clear();
     int max_len = 0;
     for (int r = 0; r < rows_here; ++r) {
-      const int32_t e = rowptr[row0 + r + 1];
-      int32_t k = cursor[r];
-      seg_begin[r] = k;
-      while (k < e && colidx[k] < col_end) ++k;
-      seg_len[r] = k - cursor[r];
-      cursor[r] = k;
-      if (seg_len[r] > max_len) max_len = seg_len[r];
-    }
-    // rows with entries, by decreasing count (counting sort, stable)
-    bucket.assign((size_t)max_len + 2, 0);
-    int n_rows = 0;
-    for (int r = 0; r < rows_here; ++r)
-      if (seg_len[r] > 0) {
-        bucket[max_len - seg_len[r] + 1] += 1;
-        ++n_rows;
+      const int32_t b = seg_begin[(size_t)cb * rows_here + r];
+      const int32_t len = seg_len[(size_t)cb * rows_here + r];
+      if (len == 0) continue;
+      if (T > 0 && len > T) {
+        const int k = (len + T - 1) / T;
+        const int base = len / k, rem = len % k;
+        int32_t at = b;
+        for (int c = 0; c < k; ++c) {
+          VRow v;
+          v.begin = at;
+          v.len = base + (c < rem ? 1 : 0);
+          v.slot = (uint16_t)(c == 0 ? r : extra_first[r] + c - 1);
+          at += v.len;
+          vrows.push_back(v);
+          max_len = std::max(max_len, v.len);
+        }
+      } else {
+        VRow v;
+        v.begin = b;
+        v.len = len;
+        v.slot = (uint16_t)r;
+        vrows.push_back(v);
+        max_len = std::max(max_len, len);
       }
+    }
+    // by decreasing length (counting sort, stable)
+    const int n_rows = (int)vrows.size();
+    bucket.assign((size_t)max_len + 2, 0);
+    for (const VRow& v : vrows) bucket[max_len - v.len + 1] += 1;
     for (int b = 1; b <= max_len + 1; ++b) bucket[b] += bucket[b - 1];
-    order.assign(n_rows, 0);
-    for (int r = 0; r < rows_here; ++r)
-      if (seg_len[r] > 0) order[bucket[max_len - seg_len[r]]++] = r;
+    sorted.resize(vrows.size());
+    for (const VRow& v : vrows) sorted[bucket[max_len - v.len]++] = v;
     TileDesc td;
     td.col_block = cb;
     td.slice_begin = (int32_t)pb.slices.size();
     td.pad = 0;
-    for (int base = 0; base < n_rows; base += WAVE) {
-      const int lanes = std::min(WAVE, n_rows - base);
-      const int len = seg_len[order[base]];  // longest row of the slice
+    for (int base = 0; base < n_rows; base += SLICE_ROWS) {
+      const int rows_in = std::min(SLICE_ROWS, n_rows - base);
+      const int len = sorted[base].len;  // longest row of the slice
       const uint32_t nq = (uint32_t)((len + 3) / 4);
       SliceMeta sm;
       sm.first_quad = (uint32_t)(pb.ids.size() / WAVE);
@@ -510,39 +626,36 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
       pb.slices.push_back(sm);
       const size_t id0 = pb.ids.size();
       pb.ids.resize(id0 + (size_t)nq * WAVE);
-      if (vals) pb.vals.resize((id0 + (size_t)nq * WAVE) * 4, 0.);
+      if (vals) pb.vals.resize((id0 + (size_t)nq * WAVE) * 8, 0.);
       for (int l = 0; l < WAVE; ++l) {
-        if (l < lanes) {
-          const int r = order[base + l];
-          pb.rowids.push_back((uint16_t)r);
-          const int32_t b = seg_begin[r];
-          const int n_ent = seg_len[r];
-          for (uint32_t q = 0; q < nq; ++q) {
-            uint16_t e[4];
+        // lane l owns sorted rows base + l (A) and base + 64 + l (B)
+        const VRow* vr[2] = {nullptr, nullptr};
+        if (l < rows_in) vr[0] = &sorted[base + l];
+        if (WAVE + l < rows_in) vr[1] = &sorted[base + WAVE + l];
+        pb.rowids.push_back((uint32_t)(vr[0] ? vr[0]->slot : NO_ROW) |
+                            ((uint32_t)(vr[1] ? vr[1]->slot : NO_ROW) << 16));
+        for (uint32_t q = 0; q < nq; ++q) {
+          uint16_t e[8];
+          for (int half = 0; half < 2; ++half) {
+            const VRow* v = vr[half];
             for (int u = 0; u < 4; ++u) {
               const int k = (int)q * 4 + u;
-              if (k < n_ent) {
-                e[u] = (uint16_t)(colidx[b + k] - col0);
+              if (v && k < v->len) {
+                e[half * 4 + u] = (uint16_t)(colidx[v->begin + k] - col0);
                 if (vals)
-                  pb.vals[((id0 + (size_t)q * WAVE + l) * 4) + u] =
-                      vals[b + k];
+                  pb.vals[(id0 + (size_t)q * WAVE + l) * 8 + half * 4 + u] =
+                      vals[v->begin + k];
               } else {
-                e[u] = (uint16_t)W;  // xs[W] == 0
+                e[half * 4 + u] = (uint16_t)W;  // xs[W] == 0
               }
             }
-            uint2 packed;
-            packed.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
-            packed.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
-            pb.ids[id0 + (size_t)q * WAVE + l] = packed;
           }
-        } else {
-          pb.rowids.push_back(NO_ROW);
-          for (uint32_t q = 0; q < nq; ++q) {
-            uint2 packed;
-            packed.x = (uint32_t)W | ((uint32_t)W << 16);
-            packed.y = packed.x;
-            pb.ids[id0 + (size_t)q * WAVE + l] = packed;
-          }
+          uint4 packed;
+          packed.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+          packed.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+          packed.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
+          packed.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
+          pb.ids[id0 + (size_t)q * WAVE + l] = packed;
         }
       }
     }
@@ -553,26 +666,31 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
   build_schedules(pb, G, vals ? BATCH_VAL : BATCH_BIN);
 }
 
-// Picks (PR, G): panels x groups of column blocks ~ one or two waves of
-// workgroups over the 256 CUs while keeping the LDS refills (W*8 bytes per
-// tile, from L2) small next to the tile's id stream (2 bytes per entry).
+// Picks (PR, G): row panels x groups of column blocks.  One workgroup runs per
+// CU (it owns the CU's LDS), so the launch should be a single round of <= 256
+// workgroups of equal work.  Cost model fitted on MI355X (profiles/,
+// DESIGN.md): a tile costs ~4.3 us of fixed time (slice refill from L2, two
+// barriers, pipeline ramp) plus ~24 ps per stored entry streamed.
 static void choose_shape(int64_t R, int64_t C, int64_t nnz, int n_block, int W,
                          int* PR_out, int* G_out) {
   double best = 1e300;
   int best_pr = 256, best_g = 1;
-  const int prs[] = {4096, 2048, 1024, 512, 256};
-  for (int pr : prs) {
-    if (pr > 256 && (int64_t)pr > R * 2) continue;
+  const int lds_rows = (int)((160 * 1024 - 2048) / 8) - (W + 8);
+  int pr_cap = TILE_PR_MAX;
+  if (lds_rows - 256 < pr_cap) pr_cap = lds_rows - 256;  // room for extras
+  if (pr_cap < 128) pr_cap = 128;
+  for (int pr = 128; pr <= pr_cap; pr += 128) {
     const int64_t n_panel = (R + pr - 1) / pr;
     for (int g = 1; g <= n_block; ++g) {
       const int bpg = (n_block + g - 1) / g;
       if ((n_block + bpg - 1) / bpg != g) continue;  // not a distinct split
       const double n_wg = (double)n_panel * g;
       const double rounds = std::ceil(n_wg / 256.);
-      const double tile_nnz = (double)nnz / ((double)n_panel * n_block);
-      const double per_tile = W * 8. / 48. + tile_nnz * 2. / 8. + 400.;
-      double cost = rounds * bpg * per_tile + 2000.;
-      if (g > 1) cost += (double)R * g * 16. / (256. * 16.);
+      const double rows = (double)std::min<int64_t>(pr, R);
+      const double tile_nnz = (double)nnz * rows / (double)R / n_block;
+      const double per_tile = 4.3 + tile_nnz * 24e-6;            // us
+      double cost = rounds * bpg * per_tile + 6.;
+      if (g > 1) cost += (double)R * g * 16. / 4e6;              // slab pass
       if (cost < best) {
         best = cost;
         best_pr = pr;
@@ -614,6 +732,13 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
     m.G = (m.n_block + bpg - 1) / bpg;
   }
   m.n_panel = (int)((R + m.PR - 1) / m.PR);
+  // LDS left after the vector slice and the row accumulators pays for the
+  // extra accumulators of split rows (2 KB stay free for static LDS).
+  int extra_budget =
+      (int)((160 * 1024 - 2048) / 8) - (m.W + 8) - m.PR;
+  if (extra_budget > 2048) extra_budget = 2048;
+  if (extra_budget < 0) extra_budget = 0;
+  if (const char* e = getenv("BBX_TILED_EXTRA")) extra_budget = atoi(e);
 
   std::vector<PanelBuild> pbs((size_t)m.n_panel);
   unsigned n_thr = std::thread::hardware_concurrency();
@@ -624,8 +749,8 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
   for (unsigned t = 0; t < n_thr; ++t)
     pool.emplace_back([&, t]() {
       for (int p = (int)t; p < m.n_panel; p += (int)n_thr)
-        build_panel(R, C, rowptr, colidx, vals, m.W, m.n_block, m.PR, m.G, p,
-                    pbs[(size_t)p]);
+        build_panel(R, C, rowptr, colidx, vals, m.W, m.n_block, m.PR, m.G,
+                    extra_budget, p, pbs[(size_t)p]);
     });
   for (auto& th : pool) th.join();
 
@@ -639,20 +764,33 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
   }
   if (tot_ids / WAVE >= ((size_t)1 << 32))
     return fail(BBX_ERR_INVALID, "matrix too large for the tiled format");
-  std::vector<uint2> ids(tot_ids);
-  std::vector<double> vv(m.has_vals ? tot_ids * 4 : 0);
+  std::vector<uint4> ids(tot_ids);
+  std::vector<double> vv(m.has_vals ? tot_ids * 8 : 0);
   std::vector<BatchDesc> descs(tot_descs);
   std::vector<int32_t> wave_desc((size_t)m.n_panel * m.G * TILE_WAVES, 0);
-  std::vector<uint16_t> rowids(tot_slices * WAVE);
+  std::vector<uint32_t> rowids(tot_slices * WAVE);
   std::vector<TileDesc> tiles(tot_tiles);
   std::vector<int32_t> wg_tiles((size_t)m.n_panel * m.G + 1, 0);
+  std::vector<FoldDesc> folds;
+  std::vector<int32_t> panel_fold((size_t)m.n_panel + 1, 0);
+  m.n_extra = 0;
+  m.split_T = 0;
   size_t id_off = 0, sl_off = 0, ti_off = 0, de_off = 0;
   for (int p = 0; p < m.n_panel; ++p) {
     PanelBuild& pb = pbs[(size_t)p];
+    panel_fold[(size_t)p] = (int32_t)folds.size();
+    int extra_here = 0;
+    for (const FoldDesc& fd : pb.folds) {
+      folds.push_back(fd);
+      extra_here += fd.count;
+    }
+    if (extra_here > m.n_extra) m.n_extra = extra_here;
+    if (pb.split_T > 0 && (m.split_T == 0 || pb.split_T < m.split_T))
+      m.split_T = pb.split_T;
     if (!pb.ids.empty())
-      memcpy(&ids[id_off], pb.ids.data(), pb.ids.size() * sizeof(uint2));
+      memcpy(&ids[id_off], pb.ids.data(), pb.ids.size() * sizeof(uint4));
     if (m.has_vals && !pb.vals.empty())
-      memcpy(&vv[id_off * 4], pb.vals.data(), pb.vals.size() * sizeof(double));
+      memcpy(&vv[id_off * 8], pb.vals.data(), pb.vals.size() * sizeof(double));
     for (size_t k = 0; k < pb.descs.size(); ++k) {
       BatchDesc d = pb.descs[k];
       if (d.info & 15u) {
@@ -666,7 +804,7 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
           pb.wave_desc[k] + (int32_t)de_off;
     if (!pb.rowids.empty())
       memcpy(&rowids[sl_off * WAVE], pb.rowids.data(),
-             pb.rowids.size() * sizeof(uint16_t));
+             pb.rowids.size() * sizeof(uint32_t));
     for (size_t t = 0; t < pb.tiles.size(); ++t) {
       TileDesc td = pb.tiles[t];
       td.slice_begin += (int32_t)sl_off;
@@ -682,19 +820,23 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
     sl_off += pb.slices.size();
     ti_off += pb.tiles.size();
     de_off += pb.descs.size();
-    std::vector<uint2>().swap(pb.ids);
+    std::vector<uint4>().swap(pb.ids);
     std::vector<double>().swap(pb.vals);
   }
   wg_tiles[(size_t)m.n_panel * m.G] = (int32_t)ti_off;
+  panel_fold[(size_t)m.n_panel] = (int32_t)folds.size();
+  BBX_TRY(upload(m.folds, folds.data(), folds.size() * sizeof(FoldDesc)));
+  BBX_TRY(upload(m.panel_fold, panel_fold.data(),
+                 panel_fold.size() * sizeof(int32_t)));
   m.n_quad = (int64_t)(tot_ids / WAVE);
   m.n_slice = (int64_t)tot_slices;
   m.n_tile = (int64_t)tot_tiles;
-  BBX_TRY(upload(m.ids, ids.data(), ids.size() * sizeof(uint2)));
+  BBX_TRY(upload(m.ids, ids.data(), ids.size() * sizeof(uint4)));
   if (m.has_vals)
     BBX_TRY(upload(m.vals, vv.data(), vv.size() * sizeof(double)));
   m.n_desc = (int64_t)tot_descs;
   // the kernel addresses the streams with 32-bit byte offsets
-  if ((uint64_t)tot_ids * (m.has_vals ? 32u : 8u) >= ((uint64_t)1 << 32))
+  if ((uint64_t)tot_ids * (m.has_vals ? 64u : 16u) >= ((uint64_t)1 << 32))
     return fail(BBX_ERR_INVALID, "matrix too large for the tiled format");
   if (tot_slices * WAVE >= ((size_t)1 << 31) || tot_descs >= ((size_t)1 << 31))
     return fail(BBX_ERR_INVALID, "matrix too large for the tiled format");
@@ -709,7 +851,7 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
   BBX_TRY(upload(m.descs, descs.data(), descs.size() * sizeof(BatchDesc)));
   BBX_TRY(upload(m.wave_desc, wave_desc.data(),
                  wave_desc.size() * sizeof(int32_t)));
-  BBX_TRY(upload(m.rowids, rowids.data(), rowids.size() * sizeof(uint16_t)));
+  BBX_TRY(upload(m.rowids, rowids.data(), rowids.size() * sizeof(uint32_t)));
   BBX_TRY(upload(m.tiles, tiles.data(), tiles.size() * sizeof(TileDesc)));
   BBX_TRY(upload(m.wg_tiles, wg_tiles.data(),
                  wg_tiles.size() * sizeof(int32_t)));
@@ -718,7 +860,7 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
 }
 
 static size_t lds_bytes(const TiledMatrix& m) {
-  return sizeof(double) * ((size_t)m.W + 8 + (size_t)m.PR);
+  return sizeof(double) * ((size_t)m.W + 8 + (size_t)m.PR + (size_t)m.n_extra);
 }
 
 void destroy_tiled(bbx_design* h) {
@@ -792,16 +934,19 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                        lb, h->stream, m.R, m.C, m.W, m.PR, m.G,
                        m.wg_tiles.as<int32_t>(), m.tiles.as<TileDesc>(),
                        m.wave_desc.as<int32_t>(), m.descs.as<BatchDesc>(),
-                       m.rowids.as<uint16_t>(), m.ids.as<uint2>(),
+                       m.rowids.as<uint32_t>(), m.ids.as<uint4>(),
                        m.vals.as<double>(), x, c_part, x0_ptr, rowscale, out,
-                       slab, ablate);
+                       slab, m.PR + m.n_extra, m.panel_fold.as<int32_t>(),
+                       m.folds.as<FoldDesc>(), ablate);
   else
     hipLaunchKernelGGL(tiled_spmv_kernel<false>, dim3(grid),
                        dim3(TILE_THREADS), lb, h->stream, m.R, m.C, m.W, m.PR,
                        m.G, m.wg_tiles.as<int32_t>(), m.tiles.as<TileDesc>(),
                        m.wave_desc.as<int32_t>(), m.descs.as<BatchDesc>(),
-                       m.rowids.as<uint16_t>(), m.ids.as<uint2>(), nullptr, x,
-                       c_part, x0_ptr, rowscale, out, slab, ablate);
+                       m.rowids.as<uint32_t>(), m.ids.as<uint4>(), nullptr, x,
+                       c_part, x0_ptr, rowscale, out, slab, m.PR + m.n_extra,
+                       m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),
+                       ablate);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }
