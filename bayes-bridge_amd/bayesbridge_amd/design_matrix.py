@@ -175,8 +175,11 @@ class HipDesignMatrix():
         self._count_offset = [int(count[0]), int(count[1])]
 
     # -- profiling ----------------------------------------------------------
-    def set_timing(self, enabled=True):
-        _lib.check(self._lib.bbx_design_set_timing(self._h, int(enabled)))
+    def set_timing(self, enabled=True, every=1):
+        """HIP-event timing of the dot/Tdot launches; `every=N` samples one
+        launch in N."""
+        _lib.check(self._lib.bbx_design_set_timing(
+            self._h, int(every) if enabled else 0))
 
     def reset_timing(self):
         _lib.check(self._lib.bbx_design_reset_timing(self._h))

@@ -40,6 +40,8 @@ void DevMem::release() {
 
 int timer_begin(bbx_design* h, int which) {
   if (!h->timer.enabled) return BBX_OK;
+  h->timer.armed[which] = (h->timer.seen[which]++ % h->timer.period) == 0;
+  if (!h->timer.armed[which]) return BBX_OK;
   KernelTimer::Pair pr;
   if (!h->timer.pool.empty()) {
     pr = h->timer.pool.back();
@@ -54,7 +56,7 @@ int timer_begin(bbx_design* h, int which) {
 }
 
 int timer_end(bbx_design* h, int which) {
-  if (!h->timer.enabled) return BBX_OK;
+  if (!h->timer.enabled || !h->timer.armed[which]) return BBX_OK;
   BBX_HIP(hipEventRecord(h->timer.pending[which].back().b, h->stream));
   return BBX_OK;
 }
@@ -82,7 +84,8 @@ int launch_tdot_dense(bbx_design* h, const double* d_w,
                       const double* d_sumw_part, const TdotEpilogue& ep,
                       double* d_out);
 int launch_dot_tiled(bbx_design* h, const double* d_v,
-                     const double* d_rowscale, double* d_t);
+                     const double* d_rowscale, double* d_t,
+                     double* d_sum_part, int* sum_done);
 int launch_tdot_tiled(bbx_design* h, const double* d_w,
                       const double* d_sumw_part, const TdotEpilogue& ep,
                       double* d_out);
@@ -90,14 +93,16 @@ int launch_tdot_tiled(bbx_design* h, const double* d_w,
 int launch_dot(bbx_design* h, const double* d_v, const double* d_rowscale,
                double* d_t, double* d_sum_part) {
   h->n_dot += 1;
+  int sum_done = 0;
   if (!h->sparse) {
     BBX_TRY(launch_dot_dense(h, d_v, d_rowscale, d_t));
   } else if (h->format == BBX_FORMAT_TILED) {
-    BBX_TRY(launch_dot_tiled(h, d_v, d_rowscale, d_t));
+    BBX_TRY(launch_dot_tiled(h, d_v, d_rowscale, d_t, d_sum_part, &sum_done));
   } else {
     BBX_TRY(launch_dot_csr(h, d_v, d_rowscale, d_t));
   }
-  if (d_sum_part) BBX_TRY(launch_sum_n(h, d_t, h->n, d_sum_part));
+  if (d_sum_part && !sum_done)
+    BBX_TRY(launch_sum_n(h, d_t, h->n, d_sum_part));
   return BBX_OK;
 }
 
@@ -488,6 +493,8 @@ int bbx_design_set_timing(bbx_design* h, int enabled) {
   BBX_HIP(hipSetDevice(h->device));
   if (!enabled && h->timer.enabled) BBX_TRY(timer_collect(h));
   h->timer.enabled = enabled != 0;
+  h->timer.period = enabled > 1 ? enabled : 1;
+  h->timer.seen[0] = h->timer.seen[1] = 0;
   return BBX_OK;
 }
 

@@ -67,6 +67,9 @@ struct CGState {
 
 struct KernelTimer {
   bool enabled = false;
+  int period = 1;          // time every period-th launch of each family
+  int64_t seen[2] = {0, 0};
+  bool armed[2] = {false, false};
   struct Pair {
     hipEvent_t a, b;
   };
@@ -106,7 +109,6 @@ struct bbx_design {
 
   // --- LDS-tiled layout (BBX_FORMAT_TILED): see spmv_tiled.hip
   void* tiled = nullptr;           // bbx::TiledPair*
-  bbx::DevMem tiled_gfull;         // p: X^T w before the epilogue
 
   bbx::DevMem offset;  // column means (p), zeros when not centred
 
@@ -185,7 +187,7 @@ int launch_dot_csr(bbx_design* h, const double* d_v, const double* d_rowscale,
 int launch_tdot_csr(bbx_design* h, const double* d_w,
                     const double* d_sumw_part, const TdotEpilogue& ep,
                     double* d_out);
-int launch_tdot_finalize(bbx_design* h, const double* d_gfull,
+int launch_tdot_finalize(bbx_design* h, const double* d_gfull, int n_slab,
                          const double* d_sumw_part, const TdotEpilogue& ep,
                          double* d_out);
 int build_tiled(bbx_design* h);

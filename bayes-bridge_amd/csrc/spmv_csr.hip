@@ -118,12 +118,13 @@ __device__ inline double block_sum_256(double x) {
 
 // Adds the chunk partials of each row of X^T in chunk order, applies the
 // intercept/centring correction and one of the CG epilogues.  Grid = NPART.
-// `gfull` != nullptr means the main product is already complete per row (the
-// tiled and dense paths); then row_chunk_ptr/partial are unused.
+// `gfull` != nullptr means the main product comes as n_slab partial slabs of
+// p entries each (the tiled and dense paths), added here in slab order; then
+// row_chunk_ptr/partial are unused.
 __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
     int64_t p, int intercept, const int32_t* __restrict__ row_chunk_ptr,
     const double* __restrict__ partial, const double* __restrict__ gfull,
-    const double* __restrict__ offset, const double* __restrict__ sumw_part,
+    int n_slab, const double* __restrict__ offset, const double* __restrict__ sumw_part,
     int mode, const double* __restrict__ s, const double* __restrict__ d,
     const double* __restrict__ x, const double* __restrict__ z,
     const double* __restrict__ phi, const double* __restrict__ eta2,
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
     } else {
       const int64_t j = jj - intercept;
       if (gfull) {
-        g = gfull[j];
+        g = 0.;
+        for (int k = 0; k < n_slab; ++k) g += gfull[(int64_t)k * p + j];
       } else {
         g = 0.;
         const int32_t cb = row_chunk_ptr[j], ce = row_chunk_ptr[j + 1];
@@ -214,13 +216,13 @@ int launch_dot_csr(bbx_design* h, const double* d_v, const double* d_rowscale,
   return BBX_OK;
 }
 
-int launch_tdot_finalize(bbx_design* h, const double* d_gfull,
+int launch_tdot_finalize(bbx_design* h, const double* d_gfull, int n_slab,
                          const double* d_sumw_part, const TdotEpilogue& ep,
                          double* d_out) {
   hipLaunchKernelGGL(tdot_finalize_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
                      h->stream, h->p, h->intercept,
                      h->t_row_chunk_ptr.as<int32_t>(),
-                     h->t_partial.as<double>(), d_gfull,
+                     h->t_partial.as<double>(), d_gfull, n_slab,
                      h->offset.as<double>(), d_sumw_part, ep.mode, ep.s, ep.d,
                      ep.x, ep.z, ep.phi, ep.eta2, d_out, ep.dot_part);
   BBX_HIP(hipGetLastError());
@@ -252,7 +254,7 @@ int launch_tdot_csr(bbx_design* h, const double* d_w,
   }
   BBX_TRY(timer_end(h, 1));
   BBX_HIP(hipGetLastError());
-  return launch_tdot_finalize(h, nullptr, d_sumw_part, ep, d_out);
+  return launch_tdot_finalize(h, nullptr, 0, d_sumw_part, ep, d_out);
 }
 
 // ------------------------------------------------------ transpose at set-up

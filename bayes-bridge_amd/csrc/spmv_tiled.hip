@@ -180,7 +180,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
     const double* __restrict__ rowscale, double* __restrict__ out,
     double* __restrict__ slab, int n_acc,
     const int32_t* __restrict__ panel_fold, const FoldDesc* __restrict__ folds,
-    int ablate) {
+    double* __restrict__ out_sum_part, int ablate) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* xs = lds;               // W + 8 doubles; xs[W] == 0 (padding target)
   double* acc = lds + (W + 8);    // n_acc = PR + extra doubles
@@ -381,10 +381,30 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
     }
     __syncthreads();
     const double c = xs[0];
+    double tsum = 0.;
     for (int r = tid; r < rows_here; r += TILE_THREADS) {
       double v = c + acc[r];
       if (rowscale) v *= rowscale[row0 + r];
       out[row0 + r] = v;
+      tsum += v;
+    }
+    if (out_sum_part) {
+      // partial sum of this panel's outputs (feeds the intercept / centring
+      // terms of the following Tdot); fixed order: lanes, then waves
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1)
+        tsum += __shfl_down(tsum, off, WAVE);
+      __syncthreads();
+      if (lane == 0) xs[wave] = tsum;
+      __syncthreads();
+      if (tid == 0) {
+        double tot = 0.;
+        for (int wv = 0; wv < TILE_WAVES; ++wv) tot += xs[wv];
+        out_sum_part[blockIdx.x] = tot;
+      }
+      // consumers add NPART slots: the first workgroup clears the unused ones
+      if (blockIdx.x == 0 && (int)gridDim.x + tid < NPART)
+        out_sum_part[gridDim.x + tid] = 0.;
     }
   } else {
     double* dst = slab + (int64_t)group * R + row0;
@@ -410,18 +430,6 @@ __global__ __launch_bounds__(256) void tiled_dot_finalize_kernel(
     double v = c + a;
     if (rowscale) v *= rowscale[r];
     out[r] = v;
-  }
-}
-
-// gfull[r] = sum_g slab[g][r]   (Tdot: feeds tdot_finalize_kernel)
-__global__ __launch_bounds__(256) void tiled_slab_sum_kernel(
-    int64_t R, int G, const double* __restrict__ slab,
-    double* __restrict__ gfull) {
-  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < R;
-       r += (int64_t)gridDim.x * 256) {
-    double a = 0.;
-    for (int g = 0; g < G; ++g) a += slab[(int64_t)g * R + r];
-    gfull[r] = a;
   }
 }
 
@@ -901,7 +909,6 @@ int build_tiled(bbx_design* h) {
                       hipMemcpyDeviceToHost));
   BBX_TRY(build_one(tp->xt, p, n, nnz, rowptr.data(), colidx.data(),
                     h->binary ? nullptr : vals.data()));
-  BBX_TRY(h->tiled_gfull.alloc(sizeof(double) * (size_t)p));
   for (const TiledMatrix* m : {&tp->x, &tp->xt}) {
     const size_t lb = lds_bytes(*m);
     if (lb > 160 * 1024)
@@ -925,7 +932,8 @@ int build_tiled(bbx_design* h) {
 
 static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                         const double* c_part, const double* x0_ptr,
-                        const double* rowscale, double* out, double* slab) {
+                        const double* rowscale, double* out, double* slab,
+                        double* out_sum_part) {
   const unsigned grid = (unsigned)(m.n_panel * m.G);
   const size_t lb = lds_bytes(m);
   static const int ablate = getenv("BBX_ABLATE") ? atoi(getenv("BBX_ABLATE")) : 0;
@@ -937,7 +945,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                        m.rowids.as<uint32_t>(), m.ids.as<uint4>(),
                        m.vals.as<double>(), x, c_part, x0_ptr, rowscale, out,
                        slab, m.PR + m.n_extra, m.panel_fold.as<int32_t>(),
-                       m.folds.as<FoldDesc>(), ablate);
+                       m.folds.as<FoldDesc>(), out_sum_part, ablate);
   else
     hipLaunchKernelGGL(tiled_spmv_kernel<false>, dim3(grid),
                        dim3(TILE_THREADS), lb, h->stream, m.R, m.C, m.W, m.PR,
@@ -946,24 +954,33 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                        m.rowids.as<uint32_t>(), m.ids.as<uint4>(), nullptr, x,
                        c_part, x0_ptr, rowscale, out, slab, m.PR + m.n_extra,
                        m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),
-                       ablate);
+                       out_sum_part, ablate);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }
 
+// Returns 1 through *sum_done when the partial sums of the output were
+// produced by the kernel itself (no separate reduction pass needed).
 int launch_dot_tiled(bbx_design* h, const double* d_v,
-                     const double* d_rowscale, double* d_t) {
+                     const double* d_rowscale, double* d_t,
+                     double* d_sum_part, int* sum_done) {
   TiledPair* tp = static_cast<TiledPair*>(h->tiled);
   const TiledMatrix& m = tp->x;
   const double* x = d_v + h->intercept;
   const double* x0 = h->intercept ? d_v : nullptr;
+  if (sum_done) *sum_done = 0;
   BBX_TRY(timer_begin(h, 0));
   if (m.G == 1) {
+    double* fused = nullptr;
+    if (d_sum_part && m.n_panel <= NPART) {
+      fused = d_sum_part;
+      if (sum_done) *sum_done = 1;
+    }
     BBX_TRY(launch_tiled(h, m, x, part_slot(h, PS_C), x0, d_rowscale, d_t,
-                         nullptr));
+                         nullptr, fused));
   } else {
     BBX_TRY(launch_tiled(h, m, x, nullptr, nullptr, nullptr, nullptr,
-                         m.slab.as<double>()));
+                         m.slab.as<double>(), nullptr));
     hipLaunchKernelGGL(tiled_dot_finalize_kernel, dim3(1024), dim3(256), 0,
                        h->stream, m.R, m.G, m.slab.as<double>(),
                        part_slot(h, PS_C), x0, d_rowscale, d_t);
@@ -980,17 +997,11 @@ int launch_tdot_tiled(bbx_design* h, const double* d_w,
   const TiledMatrix& m = tp->xt;
   BBX_TRY(timer_begin(h, 1));
   BBX_TRY(launch_tiled(h, m, d_w, nullptr, nullptr, nullptr, nullptr,
-                       m.slab.as<double>()));
-  const double* gfull = m.slab.as<double>();
-  if (m.G > 1) {
-    hipLaunchKernelGGL(tiled_slab_sum_kernel, dim3(NPART), dim3(256), 0,
-                       h->stream, m.R, m.G, m.slab.as<double>(),
-                       h->tiled_gfull.as<double>());
-    BBX_HIP(hipGetLastError());
-    gfull = h->tiled_gfull.as<double>();
-  }
+                       m.slab.as<double>(), nullptr));
   BBX_TRY(timer_end(h, 1));
-  return launch_tdot_finalize(h, gfull, d_sumw_part, ep, d_out);
+  // the epilogue kernel adds the G partial slabs in group order
+  return launch_tdot_finalize(h, m.slab.as<double>(), m.G, d_sumw_part, ep,
+                              d_out);
 }
 
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,

@@ -184,7 +184,9 @@ def main():
 
     d_coef = torch.empty((max(K, 1), P), dtype=torch.float64, device=device)
     gs, lp, ncg = np.zeros(max(K, 1)), np.zeros(max(K, 1)), np.zeros(max(K, 1))
-    design.set_timing(True)
+    # HIP events around one dot/Tdot launch in 16 (timing every launch costs
+    # ~10% of the iteration; DESIGN.md "Measurement")
+    design.set_timing(True, every=16)
     design.reset_timing()
     chains.barrier()
     torch.cuda.synchronize()

@@ -214,8 +214,11 @@ int bbx_design_reset_matvec_count(bbx_design* h);
 
 /* ------------------------------------------------ kernel timing (profiling) */
 
-/* When enabled, HIP events are recorded on the handle's stream around every
- * dot / Tdot kernel launch (also those inside the CG loop and the chain). */
+/* enabled = 1: HIP events are recorded on the handle's stream around every
+ * dot / Tdot kernel launch (also those inside the CG loop and the chain);
+ * enabled = N > 1: around every N-th launch of each family only (an event pair
+ * costs a few microseconds of stream time, ~10% of a Gibbs iteration when
+ * every launch is timed); 0: off. */
 int bbx_design_set_timing(bbx_design* h, int enabled);
 /* Resolves all pending event pairs (synchronises the stream) and returns the
  * number of timed launches and their summed device time per kernel family:
