@@ -133,6 +133,8 @@ class BayesBridge():
                 "To merge the outputs from previous and new MCMC runs, you "
                 "have to supply the optional argument `prev_samples`.")
         init = prev_mcmc_info['_markov_chain_state']
+        if '_markov_chain_state_raw' in prev_mcmc_info:
+            init = {'_raw': prev_mcmc_info['_markov_chain_state_raw']}
         new_samples, new_mcmc_info = self.gibbs(
             n_add_iter, 0, prev_mcmc_info['thin'], init=init,
             params_to_save=prev_mcmc_info['saved_params'],
@@ -178,6 +180,13 @@ class BayesBridge():
                 _resume_from)
         samples, sampling_info, state, init_used, optim_info, extra = out
         coef, obs_prec, lscale, gscale = state
+        # exact (raw-parametrisation) state: resuming from it is bitwise
+        # equivalent to not having stopped; the user-facing state below goes
+        # through the 'coef_magnitude' rescaling and back, which is not.
+        raw_state = {'coef': np.array(coef, copy=True),
+                     'obs_prec': np.array(obs_prec, copy=True),
+                     'local_scale': np.array(lscale, copy=True),
+                     'global_scale': float(gscale)}
         runtime = time.time() - start_time
         if self.prior._gscale_paramet == 'coef_magnitude':  # bayesbridge.py:244-251
             gscale, lscale = self.prior.adjust_scale(
@@ -203,6 +212,7 @@ class BayesBridge():
             '_markov_chain_state': {
                 'coef': coef, 'local_scale': lscale, 'global_scale': gscale,
                 'obs_prec': obs_prec},
+            '_markov_chain_state_raw': raw_state,
         }
         mcmc_info.update(extra)
         return samples, mcmc_info
@@ -246,6 +256,17 @@ class BayesBridge():
                           sampler):
         """initialize_chain (bayesbridge.py:279-353), parameterised by the
         update functions of the active mode."""
+        if isinstance(init, dict) and '_raw' in init:
+            raw = init['_raw']
+            obs = raw['obs_prec']
+            obs_prec = np.array(obs, dtype=np.float64, copy=True) \
+                if np.ndim(obs) > 0 else float(obs)
+            coef = np.array(raw['coef'], dtype=np.float64, copy=True)
+            lscale = np.array(raw['local_scale'], dtype=np.float64, copy=True)
+            gscale = float(raw['global_scale'])
+            return (coef, obs_prec, lscale, gscale,
+                    {'coef': coef, 'obs_prec': obs_prec,
+                     'local_scale': lscale, 'global_scale': gscale}, None)
         for key in init:
             if key not in ('coef', 'local_scale', 'global_scale', 'obs_prec',
                            'logp'):

@@ -105,7 +105,11 @@ struct bbx_design {
   bbx::DevMem t_partial;                    // per chunk partial sum
 
   // --- dense layout
-  bbx::DevMem dense;  // row-major n x P (intercept column included), f32 or f64
+  bbx::DevMem dense;  // row-major n x dense_ld (intercept column included,
+                      // centred, zero padded), f32 or f64
+  bbx::DevMem dense_slab;  // Tdot partial sums [dense_chunks][dense_ld]
+  int64_t dense_ld = 0;
+  int dense_chunks = 1;
 
   // --- LDS-tiled layout (BBX_FORMAT_TILED): see spmv_tiled.hip
   void* tiled = nullptr;           // bbx::TiledPair*
@@ -133,7 +137,8 @@ enum PartSlot {
   PS_SUMW = 1,  // sum of the current Tdot input
   PS_PQ = 2,    // p.q
   PS_RR = 3,    // r.r
-  PS_MISC = 4,
+  PS_MISC = 4,  // 4, 5, 6: scratch triples
+  PS_ZERO = 7,  // never written: NPART zeros
   PS_COUNT = 8
 };
 
@@ -190,6 +195,8 @@ int launch_tdot_csr(bbx_design* h, const double* d_w,
 int launch_tdot_finalize(bbx_design* h, const double* d_gfull, int n_slab,
                          const double* d_sumw_part, const TdotEpilogue& ep,
                          double* d_out);
+int launch_tdot_finalize_dense(bbx_design* h, const TdotEpilogue& ep,
+                               double* d_out);
 int build_tiled(bbx_design* h);
 void destroy_tiled(bbx_design* h);
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,

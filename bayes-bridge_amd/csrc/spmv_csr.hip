@@ -124,7 +124,8 @@ __device__ inline double block_sum_256(double x) {
 __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
     int64_t p, int intercept, const int32_t* __restrict__ row_chunk_ptr,
     const double* __restrict__ partial, const double* __restrict__ gfull,
-    int n_slab, const double* __restrict__ offset, const double* __restrict__ sumw_part,
+    int n_slab, int64_t slab_stride, const double* __restrict__ offset,
+    const double* __restrict__ sumw_part,
     int mode, const double* __restrict__ s, const double* __restrict__ d,
     const double* __restrict__ x, const double* __restrict__ z,
     const double* __restrict__ phi, const double* __restrict__ eta2,
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
       const int64_t j = jj - intercept;
       if (gfull) {
         g = 0.;
-        for (int k = 0; k < n_slab; ++k) g += gfull[(int64_t)k * p + j];
+        for (int k = 0; k < n_slab; ++k) g += gfull[(int64_t)k * slab_stride + j];
       } else {
         g = 0.;
         const int32_t cb = row_chunk_ptr[j], ce = row_chunk_ptr[j + 1];
@@ -222,9 +223,23 @@ int launch_tdot_finalize(bbx_design* h, const double* d_gfull, int n_slab,
   hipLaunchKernelGGL(tdot_finalize_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
                      h->stream, h->p, h->intercept,
                      h->t_row_chunk_ptr.as<int32_t>(),
-                     h->t_partial.as<double>(), d_gfull, n_slab,
+                     h->t_partial.as<double>(), d_gfull, n_slab, h->p,
                      h->offset.as<double>(), d_sumw_part, ep.mode, ep.s, ep.d,
                      ep.x, ep.z, ep.phi, ep.eta2, d_out, ep.dot_part);
+  BBX_HIP(hipGetLastError());
+  return BBX_OK;
+}
+
+// Dense operator: intercept column and centring are part of the matrix, so the
+// epilogue sees a plain P-column product (intercept 0, offset 0, sum(w) 0).
+int launch_tdot_finalize_dense(bbx_design* h, const TdotEpilogue& ep,
+                               double* d_out) {
+  hipLaunchKernelGGL(tdot_finalize_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
+                     h->stream, h->P, 0, nullptr, nullptr,
+                     h->dense_slab.as<double>(), h->dense_chunks, h->dense_ld,
+                     h->offset.as<double>(), part_slot(h, PS_ZERO), ep.mode,
+                     ep.s, ep.d, ep.x, ep.z, ep.phi, ep.eta2, d_out,
+                     ep.dot_part);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }

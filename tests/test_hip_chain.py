@@ -1,0 +1,183 @@
+"""GPU: the device-resident chain (Philox draws) and its scalar samplers.
+Distribution parity with the reference, checked against closed forms and
+against the host samplers that are themselves bit-pinned to the reference
+(tests/test_oracle_vs_reference.py)."""
+import ctypes
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sparse
+from scipy import stats
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev_pg(seed, shape, tilt):
+    from bayesbridge_amd import _lib
+    lib = _lib.load()
+    out = np.empty(len(tilt))
+    shape = np.ascontiguousarray(shape, dtype=np.int32)
+    tilt = np.ascontiguousarray(tilt, dtype=np.float64)
+    _lib.check(lib.bbx_device_polya_gamma(
+        0, seed, len(tilt), shape.ctypes.data_as(ctypes.c_void_p),
+        tilt.ctypes.data_as(ctypes.c_void_p),
+        out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+def _dev_ts(seed, a, tilt):
+    from bayesbridge_amd import _lib
+    lib = _lib.load()
+    out = np.empty(len(tilt))
+    tilt = np.ascontiguousarray(tilt, dtype=np.float64)
+    _lib.check(lib.bbx_device_tilted_stable(
+        0, seed, len(tilt), float(a), tilt.ctypes.data_as(ctypes.c_void_p),
+        out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+def test_device_polya_gamma_moments_and_ks():
+    n = 200000
+    for b, c in [(1, 0.), (1, 1.5), (3, -4.), (1, 25.)]:
+        x = _dev_pg(11, np.full(n, b), np.full(n, c))
+        assert np.all(x > 0)
+        if c == 0.:
+            mean, var = b / 4., b / 24.
+        else:                                  # Polson, Scott & Windle (2013)
+            mean = b / (2 * c) * np.tanh(c / 2)
+            var = b * (np.sinh(c) - c) / (4 * c ** 3 * np.cosh(c / 2) ** 2)
+        assert abs(x.mean() - mean) < 6 * np.sqrt(var / n)
+        assert abs(x.var() - var) < .03 * var
+    # two-sample KS against the host sampler on the reference's stream
+    from bayesbridge_amd.hostrng import ReferenceRandom
+    host = ReferenceRandom(3)
+    tilt = np.full(50000, 1.2)
+    a = _dev_pg(5, np.ones(50000, dtype=np.int32), tilt)
+    b_ = host.polya_gamma(np.ones(50000, dtype=np.int32), tilt)
+    assert stats.ks_2samp(a, b_).pvalue > 1e-3
+    # same seed => same draws; other seed => other draws
+    assert np.array_equal(a, _dev_pg(5, np.ones(50000, dtype=np.int32), tilt))
+    assert not np.array_equal(a, _dev_pg(6, np.ones(50000, dtype=np.int32),
+                                         tilt))
+
+
+def test_device_tilted_stable_laplace_transform_and_ks():
+    # X ~ exp(-lam x) f_a(x) / E, f_a positive stable with E exp(-s S) =
+    # exp(-s^a):  E exp(-s X) = exp(-((s + lam)^a - lam^a))
+    n = 200000
+    for a, lam in [(.25, .5), (.25, 30.), (.5, 4.), (.125, 200.)]:
+        x = _dev_ts(9, a, np.full(n, lam))
+        assert np.all(x > 0) and np.all(np.isfinite(x))
+        for s in (.3, 2.):
+            want = np.exp(-((s + lam) ** a - lam ** a))
+            got = np.exp(-s * x)
+            assert abs(got.mean() - want) < 6 * got.std() / np.sqrt(n)
+    from bayesbridge_amd.hostrng import ReferenceRandom
+    host = ReferenceRandom(4)
+    tl = np.full(50000, 3.)
+    assert stats.ks_2samp(_dev_ts(2, .25, tl),
+                          host.tilted_stable(.25, tl)).pvalue > 1e-3
+
+
+def test_device_gamma_moments():
+    from bayesbridge_amd import _lib
+    lib = _lib.load()
+    for shape in (.4, 3., 2.5e5):
+        out = np.empty(100000)
+        _lib.check(lib.bbx_device_gamma(0, 7, out.size, shape,
+                                        out.ctypes.data_as(ctypes.c_void_p)))
+        assert abs(out.mean() - shape) < 6 * np.sqrt(shape / out.size)
+        assert abs(out.var() - shape) < .05 * shape
+
+
+def _problem(n=3000, p=200, seed=3, model='logit'):
+    from bayesbridge_amd import simulate
+    X = simulate.simulate_design_csr(n, p, binary_frac=.8,
+                                     binary_pred_freq=.1, seed=seed)
+    beta = np.zeros(p)
+    beta[:5], beta[5:10] = 1.5, -1.
+    y = simulate.simulate_outcome(X, beta, model, seed=seed + 1)
+    return X, y, beta
+
+
+@pytest.mark.parametrize("model", ['logit', 'linear'])
+def test_device_chain_is_reproducible_and_resumable(model):
+    from bayesbridge_amd import BayesBridge, RegressionCoefPrior, \
+        RegressionModel
+    X, y, _ = _problem(model=model)
+    prior = RegressionCoefPrior(bridge_exponent=.5, regularizing_slab_size=2.)
+    init = {'global_scale': .05, 'coef': np.zeros(X.shape[1] + 1)}
+
+    def run(n_iter, seed):
+        b = BayesBridge(RegressionModel(y, X, model), prior)
+        return b, b.gibbs(n_iter, init=dict(init), seed=seed,
+                          params_to_save='all')
+    _, (s1, i1) = run(8, 21)
+    _, (s2, _) = run(8, 21)
+    _, (s3, _) = run(8, 22)
+    assert np.array_equal(s1['coef'], s2['coef'])           # bitwise
+    assert not np.array_equal(s1['coef'], s3['coef'])
+    assert np.all(np.isfinite(s1['coef'])) and np.all(np.isfinite(s1['logp']))
+    assert s1['coef'].shape == (X.shape[1] + 1, 8)
+    assert s1['local_scale'].shape == (X.shape[1], 8)
+    assert np.all(i1['_reg_coef_sampling_info']['n_cg_iter'] > 0)
+    # 4 + resume 4 == 8 straight (Philox counters are keyed by iteration)
+    b, (sa, ia) = run(4, 21)
+    sb, ib = BayesBridge(RegressionModel(y, X, model), prior).gibbs_resume(
+        ia, 4, merge=True, prev_samples=sa)
+    assert np.array_equal(sb['coef'], s1['coef'])
+    assert np.allclose(sb['global_scale'], s1['global_scale'], rtol=1e-12)
+
+
+def test_device_chain_agrees_with_reference_stream_chain():
+    """Same posterior, different random streams: posterior means of the large
+    coefficients and of log tau agree within Monte Carlo error."""
+    from bayesbridge_amd import BayesBridge, RegressionCoefPrior, \
+        RegressionModel
+    X, y, beta = _problem(n=2000, p=60, seed=5)
+    prior = RegressionCoefPrior(bridge_exponent=.5, regularizing_slab_size=2.)
+    init = {'global_scale': .05, 'coef': np.zeros(X.shape[1] + 1)}
+    n_iter, burn = 600, 150
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sd, _ = BayesBridge(RegressionModel(y, X, 'logit'), prior).gibbs(
+            n_iter, n_burnin=burn, init=dict(init), seed=1)
+        sr, _ = BayesBridge(RegressionModel(y, X, 'logit'), prior).gibbs(
+            n_iter, n_burnin=burn, init=dict(init), seed=1,
+            options={'rng': 'reference'})
+    md, mr = sd['coef'].mean(axis=1), sr['coef'].mean(axis=1)
+    sdv = sr['coef'].std(axis=1)
+    big = np.abs(mr) > .3
+    assert big.sum() >= 5
+    # effective sample size is well below n_iter - burn: allow 0.5 posterior sd
+    assert np.all(np.abs(md - mr)[big] < .5 * sdv[big] + .02)
+    lg_d, lg_r = np.log(sd['global_scale']), np.log(sr['global_scale'])
+    assert abs(lg_d.mean() - lg_r.mean()) < .5 * lg_r.std() + .1
+
+
+def test_dense_linear_chain_config1_summary(golden_dir):
+    """BASELINE config 1 (dense 2000x500 linear, cg): the reference's 20
+    iterations are summarised in the fixture; the exact-seed mode reproduces
+    them, the device mode lands in the same region."""
+    import os
+    from bayesbridge_amd import BayesBridge, RegressionCoefPrior, \
+        RegressionModel, simulate
+    g = np.load(os.path.join(golden_dir,
+                             'chain_linear_dense_2000x500_summary.npz'))
+    np.random.seed(111)
+    X = np.random.randn(2000, 500)    # simulate_design(..., 'dense', seed=111)
+    assert np.allclose(X[:4, :4], g['X_head'])
+    beta = simulate.demo_beta(500)
+    y = simulate.simulate_outcome(X, beta, 'linear', seed=1)
+    assert np.allclose(y[:8], g['y_head'])
+    prior = RegressionCoefPrior(bridge_exponent=.5, regularizing_slab_size=2.)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        s, info = BayesBridge(RegressionModel(y, X, 'linear'), prior).gibbs(
+            20, 0, init={'global_scale': .01}, coef_sampler_type='cg',
+            seed=111, options={'rng': 'reference'})
+    assert np.allclose(s['coef'][:, -1], g['coef_last'], atol=1e-4)
+    assert np.allclose(s['global_scale'], g['global_scale'], rtol=1e-3)
+    assert np.abs(info['_reg_coef_sampling_info']['n_cg_iter']
+                  - g['n_cg_iter']).max() <= 3

@@ -1,0 +1,170 @@
+"""GPU parity against the committed golden vectors (captured from the imported
+reference, tests/golden/make_golden.py): operator outputs, every recorded call
+of the reference's ConjugateGradientSampler.sample, and whole chains in the
+exact-seed ('reference' rng) mode of the driver.
+
+Tolerances: operator 1e-5 (tests/test_design_matrix.py:8-9) and 1e-11 relative
+against the stored f64 outputs; CG draws 1e-6*max(1,|coef|) with equal
+iteration counts (see test_hip_cg_sampler.py; when ||r|| hovers at the
+threshold the stopping iteration can move by up to 2 -- in the golden logit
+chain, iteration 5 has ||r|| = 8.6e-5, 8.9e-5 at steps 11, 12 against atol =
+7.1e-5, and a 1e-15 relative perturbation of Omega moves the CPU oracle itself
+from 13 to 11 iterations -- then 1e-5); chains atol=1e-5 on every
+coefficient sample, the reference's CPU-vs-GPU bound
+(tests/gpu_tests/test_gibbs.py:44), and rtol=1e-3/atol=1e-5 against its saved
+regression vectors (tests/regression_tests/test_gibb.py:109)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sparse
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("storage", ['csr', 'tiled'])
+def test_sparse_operator_fixture(golden_dir, storage):
+    from bayesbridge_amd import HipSparseDesignMatrix
+    g = _load(golden_dir, 'operator_sparse_100x10.npz')
+    d = HipSparseDesignMatrix(sparse.csr_matrix(g['X']), center_predictor=True,
+                              add_intercept=True, storage=storage)
+    assert np.abs(d.dot(g['v']) - g['dot']).max() <= 1e-12
+    assert np.abs(d.Tdot(g['w']) - g['Tdot']).max() <= 1e-11
+
+
+@pytest.mark.parametrize("dtype,tol", [('float64', 1e-11), ('float32', 5e-5)])
+def test_dense_operator_fixture(golden_dir, dtype, tol):
+    from bayesbridge_amd import HipDenseDesignMatrix
+    g = _load(golden_dir, 'operator_dense_100x10.npz')
+    X = g['X'].copy()
+    d = HipDenseDesignMatrix(X, center_predictor=True, add_intercept=True,
+                             storage_dtype=dtype)
+    assert np.array_equal(X, g['X'])     # the caller's array is not centred
+    assert d.shape == (100, 11) and not d.is_sparse
+    assert np.abs(d.dot(g['v']) - g['dot']).max() <= tol * 10
+    assert np.abs(d.Tdot(g['w']) - g['Tdot']).max() <= tol * 100
+
+
+def _replay(design, g, tol=1e-6):
+    from bayesbridge_amd import HipCGSampler
+
+    class _Replay:
+        def __init__(self, vecs): self.vecs = list(vecs)
+        def __call__(self, size): return self.vecs.pop(0)
+    orig = np.random.randn
+    try:
+        for it in range(g['cg_coef'].shape[0]):
+            np.random.randn = _Replay([g['cg_randn_n'][it],
+                                       g['cg_randn_P'][it]])
+            coef, info = HipCGSampler(int(g['cg_n_unshrunk'][it])).sample(
+                design, g['cg_obs_prec'][it], g['cg_prior_prec_sqrt'][it],
+                g['cg_z'][it], coef_cg_init=g['cg_coef_cg_init'][it],
+                precond_by='prior', coef_scaled_sd=g['cg_coef_scaled_sd'][it],
+                maxiter=int(g['cg_maxiter'][it]), atol=float(g['cg_atol'][it]))
+            assert info['converged']
+            assert abs(info['n_iter'] - int(g['cg_n_iter'][it])) <= 2
+            ref = g['cg_coef'][it]
+            bound = tol if info['n_iter'] == int(g['cg_n_iter'][it]) else 1e-5
+            assert np.abs(coef - ref).max() <= bound * max(1., np.abs(ref).max())
+    finally:
+        np.random.randn = orig
+
+
+@pytest.mark.parametrize("storage", ['csr', 'tiled'])
+def test_cg_sampler_replays_reference_logit_sparse(golden_dir, storage):
+    from bayesbridge_amd import HipSparseDesignMatrix
+    g = _load(golden_dir, 'chain_logit_sparse_cg.npz')
+    d = HipSparseDesignMatrix(sparse.csr_matrix(g['X']), center_predictor=True,
+                              add_intercept=True, storage=storage)
+    _replay(d, g)
+
+
+def test_cg_sampler_replays_reference_linear_dense(golden_dir):
+    from bayesbridge_amd import HipDenseDesignMatrix
+    g = _load(golden_dir, 'chain_linear_dense_cg.npz')
+    d = HipDenseDesignMatrix(g['X'], center_predictor=True, add_intercept=True)
+    _replay(d, g)
+
+
+def _bridge(outcome, X, model, **prior_kw):
+    from bayesbridge_amd import BayesBridge, RegressionCoefPrior, \
+        RegressionModel
+    return BayesBridge(RegressionModel(outcome, X, model),
+                       RegressionCoefPrior(**prior_kw))
+
+
+@pytest.mark.parametrize("model,fmt", [('linear', 'dense'),
+                                       ('logit', 'sparse')])
+def test_reference_rng_chain_reproduces_golden(golden_dir, model, fmt):
+    """tests/regression_tests/test_gibb.py:26-58 through the HIP backend:
+    init without coef => L-BFGS mode search over HIP dot/Tdot, then 10 Gibbs
+    iterations on the reference's random streams."""
+    g = _load(golden_dir, 'chain_%s_%s_cg.npz' % (model, fmt))
+    saved = _load(golden_dir, 'reference_%s_cg_last_sample.npy' % model)
+    X = sparse.csr_matrix(g['X']) if fmt == 'sparse' else g['X'].copy()
+    outcome = g['y'] if model == 'linear' else (g['n_success'], g['n_trial'])
+    bridge = _bridge(outcome, X, model, sd_for_intercept=2.,
+                     regularizing_slab_size=1., bridge_exponent=.25)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        samples, info = bridge.gibbs(
+            10, 0, init={'global_scale': .1, 'local_scale': np.ones(50)},
+            thin=1, coef_sampler_type='cg', seed=0, params_to_save='all',
+            options={'rng': 'reference'})
+    assert samples['coef'].shape == (51, 10)
+    assert np.allclose(samples['coef'][:, -1], saved, rtol=.001, atol=10e-6)
+    assert np.allclose(samples['coef'], g['coef_samples'], atol=1e-5)
+    assert np.allclose(samples['global_scale'], g['global_scale_samples'],
+                       rtol=1e-4)
+    assert np.allclose(samples['logp'], g['logp_samples'], rtol=1e-5)
+    assert np.abs(info['_reg_coef_sampling_info']['n_cg_iter']
+                  - g['n_cg_iter']).max() <= 2
+    assert info['_init_optim_info']['is_success']
+
+
+def test_reference_rng_chain_initcoef_mixed(golden_dir):
+    """tests/gpu_tests/test_gibbs.py:34-44: same seed, init={'coef': ones}."""
+    g = _load(golden_dir, 'chain_logit_mixed_initcoef.npz')
+    X = sparse.csr_matrix((g['X_data'], g['X_indices'], g['X_indptr']),
+                          shape=tuple(g['X_shape']))
+    bridge = _bridge((g['n_success'], g['n_trial']), X, 'logit')
+    samples, info = bridge.gibbs(
+        n_iter=10, coef_sampler_type='cg', init={'coef': np.ones(51)}, seed=1,
+        options={'rng': 'reference'})
+    assert np.allclose(samples['coef'], g['coef_samples'], atol=1e-5)
+    assert info['options']['coef_sampler_type'] == 'cg'
+    # default sampler is 'cg'; others are rejected (test_gibbs.py:47-58)
+    _, info1 = bridge.gibbs(n_iter=1, options={'rng': 'reference'})
+    assert info1['options']['coef_sampler_type'] == 'cg'
+    for bad in ('cholesky', 'hmc'):
+        with pytest.raises(ValueError):
+            bridge.gibbs(n_iter=1, coef_sampler_type=bad)
+
+
+def test_reference_rng_resume_equals_straight_run(golden_dir):
+    """gibbs(5) + gibbs_resume(5) == gibbs(10) (test_gibb.py:41-58 does this
+    for the Cholesky sampler)."""
+    g = _load(golden_dir, 'chain_logit_sparse_cg.npz')
+    X = sparse.csr_matrix(g['X'])
+    outcome = (g['n_success'], g['n_trial'])
+    kw = dict(sd_for_intercept=2., regularizing_slab_size=1.,
+              bridge_exponent=.25)
+    init = {'global_scale': .1, 'local_scale': np.ones(50)}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        full, _ = _bridge(outcome, X, 'logit', **kw).gibbs(
+            10, init=dict(init), seed=0, coef_sampler_type='cg',
+            options={'rng': 'reference'})
+        first, info = _bridge(outcome, X, 'logit', **kw).gibbs(
+            5, init=dict(init), seed=0, coef_sampler_type='cg',
+            options={'rng': 'reference'})
+        merged, info2 = _bridge(outcome, X, 'logit', **kw).gibbs_resume(
+            info, 5, merge=True, prev_samples=first)
+    assert merged['coef'].shape == (51, 10)
+    assert np.allclose(merged['coef'], full['coef'], atol=1e-12)
+    assert info2['n_iter'] == 10
