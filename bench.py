@@ -114,6 +114,26 @@ def cpu_baseline(torch, prob, state, n_iters, seed):
                 host_cores=os.cpu_count())
 
 
+def committed_traffic(design, which, cfg):
+    """HBM bytes per launch of the dominant kernel from the committed PMC
+    passes (profiles/r01_spmv_profile.json; FETCH_SIZE doubled per the gfx950
+    correction + WRITE_SIZE), matched by launch grid; None when no profile of
+    this workload/geometry is committed."""
+    if cfg != "config3" or design.storage_format != "tiled":
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_spmv_profile.json")
+    if not os.path.exists(path):
+        return None
+    info = design.tiled_info()["X" if which == "dot" else "Xt"]
+    n, P = design.shape
+    rows = n if which == "dot" else P - 1
+    n_wg = -(-rows // info["PR"]) * info["G"]
+    with open(path) as fh:
+        prof = json.load(fh)
+    entry = prof.get("hbm_traffic", {}).get("grid=%d" % n_wg)
+    return int(entry["total_bytes"]) if entry else None
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -215,9 +235,10 @@ def main():
                              gbs=b / avg_ms / 1e6 if avg_ms > 0 else 0.)
         dom = "dot" if timing["dot"][1] >= timing["tdot"][1] else "tdot"
         ach = per[dom]["gbs"]
+        traffic = committed_traffic(design, dom, args.config)
         roofline = dict(
             bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
-            unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+            unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
             kernel=dom + " (" + design.storage_format + ")",
             avg_launch_ms=round(per[dom]["avg_ms"], 5),
             algorithmic_bytes_per_launch=per[dom]["bytes"],
