@@ -15,10 +15,13 @@ struct Philox {
   uint32_t out[4];
   int have;  // unread 32-bit words in out
 
-  __host__ __device__ Philox(uint64_t seed, uint64_t stream, uint64_t index) {
+  // `trial` selects one of 4096 independent sub-streams of an element (the
+  // speculative rejection samplers give every candidate proposal its own).
+  __host__ __device__ Philox(uint64_t seed, uint64_t stream, uint64_t index,
+                             uint32_t trial = 0) {
     key[0] = (uint32_t)seed;
     key[1] = (uint32_t)(seed >> 32);
-    ctr[0] = 0;  // draw counter
+    ctr[0] = trial << 20;  // low 20 bits: draw counter
     ctr[1] = (uint32_t)stream;
     ctr[2] = (uint32_t)index;
     ctr[3] = (uint32_t)(index >> 32) ^ ((uint32_t)(stream >> 32) << 16);
@@ -50,7 +53,7 @@ struct Philox {
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
     have = 4;
-    ctr[0] += 1;  // 2^32 blocks of 4 words per (seed, stream, index)
+    ctr[0] += 1;  // 2^20 blocks of 4 words per (seed, stream, index, trial)
   }
 
   __host__ __device__ inline uint32_t next_u32() {

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
   if (tid < 8) xs[W + tid] = 0.;
 
   constexpr int BATCH = VALS ? BATCH_VAL : BATCH_BIN;  // steps per ring slot
-  constexpr int RING = VALS ? 3 : 4;   // slots: RING-1 batches in flight
+  constexpr int RING = VALS ? 2 : 4;   // slots: RING-1 batches in flight
   constexpr int NV = VALS ? 4 : 1;     // 16-byte value loads per step
   constexpr int LOADS_PER_STEP = BATCH * (VALS ? 5 : 1) + 1;
   constexpr int WAIT_COUNT = (RING - 1) * LOADS_PER_STEP;
@@ -449,26 +449,43 @@ struct PanelBuild {
 };
 
 // Per-wave schedules of one panel: for every workgroup (group of column
-// blocks) and wave, the batches of its slices in processing order.  Slices of
-// a tile are dealt to the 16 waves in snake order; they are sorted by
-// decreasing length, so this balances the waves.
+// blocks) and wave, the batches of its slices in processing order.  Inside a
+// tile the slices (sorted by decreasing length) go one by one to the wave with
+// the least work so far (longest-processing-time rule), which keeps the 16
+// waves of a workgroup within one slice of each other at the tile barrier.
 static void build_schedules(PanelBuild& pb, int G, int batch) {
   pb.wave_desc.assign((size_t)G * TILE_WAVES, 0);
   size_t tile_cursor = 0;
+  std::vector<std::vector<int>> deal(TILE_WAVES);
   for (int g = 0; g < G; ++g) {
     const size_t t0 = tile_cursor, t1 = tile_cursor + pb.group_tile_count[g];
     tile_cursor = t1;
+    // deal[t - t0][w] = slices of tile t handled by wave w
+    std::vector<std::vector<std::vector<int>>> tile_deal(t1 - t0);
+    for (size_t t = t0; t < t1; ++t) {
+      const TileDesc& td = pb.tiles[t];
+      std::vector<std::vector<int>>& dl = tile_deal[t - t0];
+      dl.assign(TILE_WAVES, std::vector<int>());
+      int64_t load[TILE_WAVES];
+      for (int w = 0; w < TILE_WAVES; ++w) load[w] = 0;
+      for (int sl = td.slice_begin; sl < td.slice_end; ++sl) {
+        // rotate the tie-break with the tile index so that no wave is
+        // systematically first
+        int best = (int)((t + (size_t)sl) % TILE_WAVES);
+        for (int k = 0; k < TILE_WAVES; ++k) {
+          const int w = (int)((t + (size_t)k) % TILE_WAVES);
+          if (load[w] < load[best]) best = w;
+        }
+        dl[best].push_back(sl);
+        // cost: steps plus a per-slice overhead (row ids, flush)
+        load[best] += (int64_t)pb.slices[(size_t)sl].n_quad + 2;
+      }
+    }
     for (int w = 0; w < TILE_WAVES; ++w) {
       pb.wave_desc[(size_t)g * TILE_WAVES + w] = (int32_t)pb.descs.size();
       for (size_t t = t0; t < t1; ++t) {
-        const TileDesc& td = pb.tiles[t];
-        const int n_sl = td.slice_end - td.slice_begin;
         bool first = true;
-        for (int round = 0; round * TILE_WAVES < n_sl; ++round) {
-          const int pos = (round & 1) ? (TILE_WAVES - 1 - w) : w;
-          const int idx = round * TILE_WAVES + pos;
-          if (idx >= n_sl) continue;
-          const int sl = td.slice_begin + idx;
+        for (int sl : tile_deal[t - t0][w]) {
           const SliceMeta& sm = pb.slices[(size_t)sl];
           for (uint32_t q0 = 0; q0 < sm.n_quad; q0 += (uint32_t)batch) {
             BatchDesc d;
