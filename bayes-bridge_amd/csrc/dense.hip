@@ -30,28 +30,46 @@ struct Vec4<double> {
 };
 
 // out[i] = rowscale[i] * sum_j X[i, j] v[j]
+// The vector (ld doubles, <= 64 KB at P = 8001) is staged in LDS once per
+// workgroup and reused for every row it handles; one wavefront per row streams
+// the row with 16-byte lane loads, four in flight.
 template <typename T>
 __global__ __launch_bounds__(256) void dense_dot_kernel(
     int64_t n, int64_t P, int64_t ld, const T* __restrict__ X,
     const double* __restrict__ v, const double* __restrict__ rowscale,
     double* __restrict__ out) {
   using V4 = typename Vec4<T>::type;
+  extern __shared__ __attribute__((aligned(16))) double vs[];
+  for (int64_t j = threadIdx.x; j < ld; j += 256) vs[j] = (j < P) ? v[j] : 0.;
+  __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave0 = (int64_t)blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
   const int64_t n_wave = (int64_t)gridDim.x * (256 / WAVE);
+  const int64_t nq = ld / 4;
+  const double4* __restrict__ v4 = reinterpret_cast<const double4*>(vs);
   for (int64_t row = wave0; row < n; row += n_wave) {
     const V4* __restrict__ xr = reinterpret_cast<const V4*>(X + row * ld);
     double a0 = 0., a1 = 0.;
-    for (int64_t q = lane; q * 4 < P; q += WAVE) {
-      const V4 x = xr[q];
-      const int64_t j = q * 4;
-      // the padding columns [P, ld) hold zeros; guard v, which has P entries
-      const double v0 = v[j];
-      const double v1 = (j + 1 < P) ? v[j + 1] : 0.;
-      const double v2 = (j + 2 < P) ? v[j + 2] : 0.;
-      const double v3 = (j + 3 < P) ? v[j + 3] : 0.;
-      a0 += (double)x.x * v0 + (double)x.z * v2;
-      a1 += (double)x.y * v1 + (double)x.w * v3;
+    int64_t q = lane;
+    for (; q + 3 * WAVE < nq; q += 4 * WAVE) {
+      const V4 x0 = xr[q], x1 = xr[q + WAVE], x2 = xr[q + 2 * WAVE],
+               x3 = xr[q + 3 * WAVE];
+      const double4 w0 = v4[q], w1 = v4[q + WAVE], w2 = v4[q + 2 * WAVE],
+                    w3 = v4[q + 3 * WAVE];
+      a0 += (double)x0.x * w0.x + (double)x0.z * w0.z;
+      a1 += (double)x0.y * w0.y + (double)x0.w * w0.w;
+      a0 += (double)x1.x * w1.x + (double)x1.z * w1.z;
+      a1 += (double)x1.y * w1.y + (double)x1.w * w1.w;
+      a0 += (double)x2.x * w2.x + (double)x2.z * w2.z;
+      a1 += (double)x2.y * w2.y + (double)x2.w * w2.w;
+      a0 += (double)x3.x * w3.x + (double)x3.z * w3.z;
+      a1 += (double)x3.y * w3.y + (double)x3.w * w3.w;
+    }
+    for (; q < nq; q += WAVE) {
+      const V4 x0 = xr[q];
+      const double4 w0 = v4[q];
+      a0 += (double)x0.x * w0.x + (double)x0.z * w0.z;
+      a1 += (double)x0.y * w0.y + (double)x0.w * w0.w;
     }
     double a = a0 + a1;
 #pragma unroll
@@ -132,16 +150,19 @@ __global__ __launch_bounds__(256) void dense_ingest_kernel(
 int launch_dot_dense(bbx_design* h, const double* d_v,
                      const double* d_rowscale, double* d_t) {
   int64_t nb = (h->n + 3) / 4;
-  if (nb > 8192) nb = 8192;
+  if (nb > 1024) nb = 1024;   // 4 rows in flight per block, vector staged once
   if (nb < 1) nb = 1;
+  const size_t lds = sizeof(double) * (size_t)h->dense_ld;
+  if (lds > 150 * 1024)
+    return fail(BBX_ERR_INVALID, "dense operator: more than 19200 columns");
   BBX_TRY(timer_begin(h, 0));
   if (h->dense_dtype == BBX_F32)
     hipLaunchKernelGGL(dense_dot_kernel<float>, dim3((unsigned)nb), dim3(256),
-                       0, h->stream, h->n, h->P, h->dense_ld,
+                       lds, h->stream, h->n, h->P, h->dense_ld,
                        h->dense.as<float>(), d_v, d_rowscale, d_t);
   else
     hipLaunchKernelGGL(dense_dot_kernel<double>, dim3((unsigned)nb), dim3(256),
-                       0, h->stream, h->n, h->P, h->dense_ld,
+                       lds, h->stream, h->n, h->P, h->dense_ld,
                        h->dense.as<double>(), d_v, d_rowscale, d_t);
   BBX_TRY(timer_end(h, 0));
   BBX_HIP(hipGetLastError());
@@ -254,6 +275,12 @@ static int create_dense_common(int64_t n, int64_t p, const void* X,
                          (const double*)src, off, h->dense.as<double>());
     BBX_HIP(hipGetLastError());
     BBX_HIP(hipStreamSynchronize(h->stream));
+    BBX_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&dense_dot_kernel<float>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    BBX_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&dense_dot_kernel<double>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return BBX_OK;
   };
   int st = body();
