@@ -141,8 +141,18 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
     } else {
       const int64_t j = jj - intercept;
       if (gfull) {
+        // partial slabs, added in slab order; loads issued 8 at a time
         g = 0.;
-        for (int k = 0; k < n_slab; ++k) g += gfull[(int64_t)k * slab_stride + j];
+        int k = 0;
+        for (; k + 8 <= n_slab; k += 8) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            v[u] = gfull[(int64_t)(k + u) * slab_stride + j];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) g += v[u];
+        }
+        for (; k < n_slab; ++k) g += gfull[(int64_t)k * slab_stride + j];
       } else {
         g = 0.;
         const int32_t cb = row_chunk_ptr[j], ce = row_chunk_ptr[j + 1];
