@@ -115,12 +115,34 @@ int launch_tdot(bbx_design* h, const double* d_w, const double* d_sumw_part,
   return launch_tdot_csr(h, d_w, d_sumw_part, ep, d_out);
 }
 
+int launch_tdot_main_csr(bbx_design* h, const double* d_w, TdotSource* src);
+int launch_tdot_main_tiled(bbx_design* h, const double* d_w, TdotSource* src);
+int launch_tdot_main_dense(bbx_design* h, const double* d_w, TdotSource* src);
+
+int launch_tdot_main(bbx_design* h, const double* d_w,
+                     const double* d_sumw_part, TdotSource* src) {
+  h->n_tdot += 1;
+  *src = TdotSource();
+  if (!h->sparse) {
+    BBX_TRY(launch_tdot_main_dense(h, d_w, src));
+  } else if (h->format == BBX_FORMAT_TILED) {
+    BBX_TRY(launch_tdot_main_tiled(h, d_w, src));
+    src->sumw_part = d_sumw_part;
+  } else {
+    BBX_TRY(launch_tdot_main_csr(h, d_w, src));
+    src->sumw_part = d_sumw_part;
+  }
+  return BBX_OK;
+}
+
 int design_alloc_work(bbx_design* h) {
   for (auto& m : h->w_n) BBX_TRY(m.alloc(sizeof(double) * (size_t)h->n));
   for (auto& m : h->w_P) BBX_TRY(m.alloc(sizeof(double) * (size_t)h->P));
   BBX_TRY(h->part.alloc(sizeof(double) * NPART * PS_COUNT));
   BBX_HIP(hipMemset(h->part.ptr, 0, sizeof(double) * NPART * PS_COUNT));
   BBX_TRY(h->cg_state.alloc(sizeof(CGState)));
+  BBX_TRY(h->cg_gran.alloc(sizeof(uint64_t) * 1024 + 64));
+  BBX_HIP(hipMemset(h->cg_gran.ptr, 0, sizeof(uint64_t) * 1024 + 64));
   BBX_TRY(h->stage_n.alloc(sizeof(double) * (size_t)h->n * 2));
   BBX_TRY(h->stage_P.alloc(sizeof(double) * (size_t)h->P * 6));
   BBX_HIP(hipHostMalloc(&h->host_pinned, 256, hipHostMallocDefault));

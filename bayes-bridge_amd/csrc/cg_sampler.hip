@@ -34,6 +34,9 @@ int launch_cg_update(bbx_design* h, int k, CGState* st, const double* pq_part,
                      double* rr_part);
 int launch_cg_finish(bbx_design* h, const double* s, const double* x,
                      double* coef);
+int launch_cg_fused(bbx_design* h, const TdotSource& src, int k, int last,
+                    CGState* st, const double* s, const double* d, double* pvec,
+                    double* x, double* r, double* sp, double* c_part);
 
 __global__ __launch_bounds__(256) void fill_normal_kernel(
     int64_t len, uint64_t seed, uint64_t stream, double* __restrict__ out) {
@@ -140,11 +143,58 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
   // the pinned buffer is reused for the read-back below
   BBX_HIP(hipStreamSynchronize(h->stream));
 
+  // Opt-in (BBX_CG_FUSED=1): measured on MI355X at 1M x 50k the single fused
+  // vector launch with its two in-launch reductions is ~5 us per CG iteration
+  // SLOWER than the three small launches it replaces (147 vs 142 us), so the
+  // plain sequence stays the default.
+  static const bool use_fused =
+      getenv("BBX_CG_FUSED") && atoi(getenv("BBX_CG_FUSED")) == 1;
+  const bool fused =
+      use_fused && h->P <= (int64_t)NPART * VEC_BLOCK * 4;  // FUSED_EMAX
   int k = 0;
   bool done = false;
   // Enqueue close to the previous solve's iteration count before the first
   // poll, then poll every other iteration.
   int next_poll = h->last_cg_iter > 2 ? h->last_cg_iter - 1 : 1;
+  if (fused) {
+    // direction(0) on its own; afterwards ONE vector launch per iteration does
+    // the Tdot epilogue, the update and the next direction (vecops.hip).
+    if (maxiter > 0)
+      BBX_TRY(launch_cg_direction(h, 0, st, part_slot(h, PS_RR), r, pvec, s, sp,
+                                  part_slot(h, PS_C)));
+    double* t = h->w_n[0].as<double>();
+    while (k < maxiter) {
+      const int stop = (next_poll < maxiter) ? next_poll : maxiter;
+      for (; k < stop; ++k) {
+        BBX_TRY(launch_dot(h, sp, d_omega, t, part_slot(h, PS_SUMW)));
+        TdotSource src;
+        BBX_TRY(launch_tdot_main(h, t, part_slot(h, PS_SUMW), &src));
+        const int st_l = launch_cg_fused(h, src, k, k + 1 == maxiter ? 1 : 0, st,
+                                         s, d, pvec, x, r, sp,
+                                         part_slot(h, PS_C));
+        if (st_l < 0) return st_l;
+      }
+      if (k >= maxiter) break;
+      BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState),
+                             hipMemcpyDeviceToHost, h->stream));
+      BBX_HIP(hipStreamSynchronize(h->stream));
+      if (host_st->done) break;
+      next_poll = k + 2;
+    }
+    {  // a bounded spin that gave up leaves its epoch in the timeout word
+      unsigned tmo = 0;
+      BBX_HIP(hipMemcpyAsync(&tmo, (char*)h->cg_gran.ptr + sizeof(uint64_t) * 1024,
+                             sizeof(unsigned), hipMemcpyDeviceToHost,
+                             h->stream));
+      BBX_HIP(hipStreamSynchronize(h->stream));
+      if (tmo != 0) {
+        BBX_HIP(hipMemsetAsync((char*)h->cg_gran.ptr + sizeof(uint64_t) * 1024,
+                               0, sizeof(unsigned), h->stream));
+        return fail(BBX_ERR_HIP,
+                    "fused CG step: cross-workgroup exchange timed out");
+      }
+    }
+  } else {
   while (!done) {
     const int stop = (next_poll < maxiter) ? next_poll : maxiter;
     for (; k < stop; ++k) {
@@ -172,6 +222,7 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
                              part_slot(h, PS_RR)));
     ++k;
     next_poll = k + 2;
+  }
   }
   BBX_TRY(launch_cg_finish(h, s, x, d_coef));
   BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,

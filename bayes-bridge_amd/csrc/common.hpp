@@ -121,6 +121,8 @@ struct bbx_design {
   bbx::DevMem w_P[10];    // P-length CG vectors
   bbx::DevMem part;       // NPART-length partial-sum slots (several)
   bbx::DevMem cg_state;   // CGState
+  bbx::DevMem cg_gran;    // 2 x 512 exchange granules + timeout word (fused CG)
+  unsigned cg_epoch = 0;  // last epoch used by the fused CG kernel
   bbx::DevMem stage_n, stage_P;  // staging for the host-pointer entry points
   void* host_pinned = nullptr;   // small pinned buffer for flag read-back
 
@@ -168,6 +170,23 @@ struct TdotEpilogue {
   const double* eta2 = nullptr;
   double* dot_part = nullptr;  // TD_OPER: partials of x.out ; TD_RHS: of out.out
 };
+// Where the raw main product X_main^T w of the last Tdot launch can be read
+// from (per orientation/format), for epilogues that run in a later kernel.
+struct TdotSource {
+  const double* gfull = nullptr;        // n_slab slabs of `stride` doubles, or
+  int n_slab = 0;
+  int64_t stride = 0;
+  const int32_t* row_chunk_ptr = nullptr;  // CSR layout: chunk partials per row
+  const double* partial = nullptr;
+  const double* offset = nullptr;       // centring (p_eff entries)
+  const double* sumw_part = nullptr;    // NPART partials of sum(w)
+  int64_t p_eff = 0;                    // columns of the main block
+  int intercept = 0;                    // 1: entry 0 of the result is sum(w)
+};
+// Runs only the main kernel of a Tdot (no epilogue) and says where g lives.
+int launch_tdot_main(bbx_design* h, const double* d_w,
+                     const double* d_sumw_part, TdotSource* src);
+
 // out[P] = epilogue([sum w ; X_main^T w - sum(w) offset]).  `sumw_part` holds
 // the NPART partials of sum(w).
 int launch_tdot(bbx_design* h, const double* d_w, const double* d_sumw_part,

@@ -169,9 +169,7 @@ int launch_dot_dense(bbx_design* h, const double* d_v,
   return BBX_OK;
 }
 
-int launch_tdot_dense(bbx_design* h, const double* d_w,
-                      const double* /*d_sumw_part*/, const TdotEpilogue& ep,
-                      double* d_out) {
+static int launch_tdot_slabs_dense(bbx_design* h, const double* d_w) {
   const int64_t ld = h->dense_ld;
   const int chunks = h->dense_chunks;
   const int64_t rows_per_chunk = (h->n + chunks - 1) / chunks;
@@ -187,9 +185,28 @@ int launch_tdot_dense(bbx_design* h, const double* d_w,
                        h->dense.as<double>(), d_w, h->dense_slab.as<double>());
   BBX_TRY(timer_end(h, 1));
   BBX_HIP(hipGetLastError());
+  return BBX_OK;
+}
+
+int launch_tdot_dense(bbx_design* h, const double* d_w,
+                      const double* /*d_sumw_part*/, const TdotEpilogue& ep,
+                      double* d_out) {
+  BBX_TRY(launch_tdot_slabs_dense(h, d_w));
   // The intercept column and the centring live in the matrix itself, so the
   // common epilogue runs with intercept = 0, offset = 0, sum(w) unused.
   return launch_tdot_finalize_dense(h, ep, d_out);
+}
+
+int launch_tdot_main_dense(bbx_design* h, const double* d_w, TdotSource* src) {
+  BBX_TRY(launch_tdot_slabs_dense(h, d_w));
+  src->gfull = h->dense_slab.as<double>();
+  src->n_slab = h->dense_chunks;
+  src->stride = h->dense_ld;
+  src->offset = h->offset.as<double>();   // zeros (length P)
+  src->sumw_part = part_slot(h, PS_ZERO);
+  src->p_eff = h->P;
+  src->intercept = 0;
+  return BBX_OK;
 }
 
 static int create_dense_common(int64_t n, int64_t p, const void* X,

@@ -254,9 +254,7 @@ int launch_tdot_finalize_dense(bbx_design* h, const TdotEpilogue& ep,
   return BBX_OK;
 }
 
-int launch_tdot_csr(bbx_design* h, const double* d_w,
-                    const double* d_sumw_part, const TdotEpilogue& ep,
-                    double* d_out) {
+static int launch_tdot_chunks_csr(bbx_design* h, const double* d_w) {
   BBX_TRY(timer_begin(h, 1));
   if (h->n_tchunk > 0) {
     const int64_t nb = (h->n_tchunk + 3) / 4;
@@ -279,7 +277,24 @@ int launch_tdot_csr(bbx_design* h, const double* d_w,
   }
   BBX_TRY(timer_end(h, 1));
   BBX_HIP(hipGetLastError());
+  return BBX_OK;
+}
+
+int launch_tdot_csr(bbx_design* h, const double* d_w,
+                    const double* d_sumw_part, const TdotEpilogue& ep,
+                    double* d_out) {
+  BBX_TRY(launch_tdot_chunks_csr(h, d_w));
   return launch_tdot_finalize(h, nullptr, 0, d_sumw_part, ep, d_out);
+}
+
+int launch_tdot_main_csr(bbx_design* h, const double* d_w, TdotSource* src) {
+  BBX_TRY(launch_tdot_chunks_csr(h, d_w));
+  src->row_chunk_ptr = h->t_row_chunk_ptr.as<int32_t>();
+  src->partial = h->t_partial.as<double>();
+  src->offset = h->offset.as<double>();
+  src->p_eff = h->p;
+  src->intercept = h->intercept;
+  return BBX_OK;
 }
 
 // ------------------------------------------------------ transpose at set-up

@@ -1021,6 +1021,23 @@ int launch_tdot_tiled(bbx_design* h, const double* d_w,
                               d_out);
 }
 
+int launch_tdot_main_tiled(bbx_design* h, const double* d_w,
+                           TdotSource* src) {
+  TiledPair* tp = static_cast<TiledPair*>(h->tiled);
+  const TiledMatrix& m = tp->xt;
+  BBX_TRY(timer_begin(h, 1));
+  BBX_TRY(launch_tiled(h, m, d_w, nullptr, nullptr, nullptr, nullptr,
+                       m.slab.as<double>(), nullptr));
+  BBX_TRY(timer_end(h, 1));
+  src->gfull = m.slab.as<double>();
+  src->n_slab = m.G;
+  src->stride = h->p;
+  src->offset = h->offset.as<double>();
+  src->p_eff = h->p;
+  src->intercept = h->intercept;
+  return BBX_OK;
+}
+
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
                        int64_t* tdot_bytes) {
   const TiledPair* tp = static_cast<const TiledPair*>(h->tiled);

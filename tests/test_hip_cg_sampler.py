@@ -119,3 +119,30 @@ def test_cg_zero_warm_start_and_device_rng():
                           inp['z'], device_rng_seed=124, **kw)
     assert np.array_equal(a, b)
     assert not np.array_equal(a, c)
+
+
+def test_fused_vector_step_matches_plain_sequence(monkeypatch):
+    """BBX_CG_FUSED=1 swaps the three P-vector launches of a CG iteration for
+    one launch with in-launch reductions (vecops.hip); same draw."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle
+from helpers import cg_inputs, mixed_design
+from test_hip_cg_sampler import _run_both, _assert_close
+X = mixed_design(3000, 300, binary_frac=.7, seed=9)
+out = _run_both(X, cg_inputs(3000, 301, seed=9), storage='tiled')
+_assert_close(*out)
+print('FUSED_OK', out[1]['n_iter'])
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                    'bayes-bridge_amd'),
+       os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BBX_CG_FUSED='1')
+    res = subprocess.run([sys.executable, '-c', code], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert 'FUSED_OK' in res.stdout
