@@ -22,7 +22,10 @@ def init_process_group_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # RCCL needs one distinct GPU per rank; with fewer devices than
+            # ranks (dry runs on a 1-GPU box) fall back to gloo
+            backend = "nccl" if (torch.cuda.is_available() and
+                                 torch.cuda.device_count() >= world) else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -47,6 +50,8 @@ def gather_chain_samples(local, dst=0):
     world = dist.get_world_size()
     rank = dist.get_rank()
     local = local.contiguous()
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        local = local.cpu()
     if rank == dst:
         bucket = [torch.empty_like(local) for _ in range(world)]
         dist.gather(local, gather_list=bucket, dst=dst)

@@ -144,8 +144,10 @@ def main():
     rank, world, local_rank = chains.init_process_group_from_env()
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
-    torch.cuda.set_device(local_rank)
-    device = "cuda:%d" % local_rank
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)   # == local_rank on a full node
+    torch.cuda.set_device(dev_index)
+    device = "cuda:%d" % dev_index
     lib = _lib.load()
 
     prob = build_problem(torch, args.config, args.seed, device)
@@ -154,7 +156,7 @@ def main():
     design = HipSparseDesignMatrix.from_device_csr(
         n, p, nnz, prob["indptr"].data_ptr(), prob["indices"].data_ptr(),
         None, prob["offset"].data_ptr(), add_intercept=True,
-        device=local_rank, storage=args.storage)
+        device=dev_index, storage=args.storage)
     P = p + 1
 
     # chain: prior and init of the reference demo (demo.ipynb cells 7, 9)
@@ -269,6 +271,7 @@ def main():
                 "mean_n_cg_iter_warmup": round(float(ncg_w[:W].mean()), 2)
                 if W > 0 else None,
                 "parallelism": "chains=%d" % world,
+                "devices": min(world, n_dev),
             },
             "roofline": roofline,
         }

@@ -1,0 +1,45 @@
+"""CPU (hipcc cross-compile, ~30 s): the LDS-tiled kernel issues its stream
+loads through inline asm with hand-counted waits, so the compiler must not
+spill or use scratch there (a spilled register that is the destination of an
+in-flight asm load would be silent corruption), and the 1024-thread workgroup
+must fit the 128-VGPR budget."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_tiled_kernels_do_not_spill(tmp_path):
+    src = os.path.join(ROOT, "bayes-bridge_amd", "csrc", "spmv_tiled.hip")
+    out = subprocess.run(
+        [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950",
+         "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o",
+         str(tmp_path / "t.o")],
+        capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    # "remark: Function Name: <mangled>" then one "remark:     <key>: <value>"
+    # line per resource
+    current, table = None, {}
+    for line in out.stderr.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            current = m.group(1)
+            table[current] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z][A-Za-z ]*?(?: \[[^\]]*\])?): (\d+)", line)
+        if m and current:
+            table[current][m.group(1)] = int(m.group(2))
+    tiled = {k: v for k, v in table.items() if "tiled_spmv_kernel" in k}
+    assert len(tiled) == 2     # value-free and valued instantiations
+    for name, res in tiled.items():
+        assert res["VGPRs"] <= 128, (name, res)
+        assert res["VGPRs Spill"] == 0, (name, res)
+        assert res["SGPRs Spill"] == 0, (name, res)
+        assert res["ScratchSize [bytes/lane]"] == 0, (name, res)
