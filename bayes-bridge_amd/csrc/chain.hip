@@ -293,27 +293,118 @@ __global__ __launch_bounds__(256) void chain_gscale_kernel(
 }
 
 // lambda_j | tau, beta_j (bayesbridge.py:458-478).
-__global__ __launch_bounds__(256) void chain_lscale_kernel(
+//
+// lambda_j^-2 / 2 is an exponentially tilted stable variate sampled by
+// rejection (tilted_stable.pyx:99-104: plain rejection when tilt^a < 2,
+// Devroye's double rejection otherwise).  One proposal is a few thousand
+// dependent f64 instructions, and with one lane per coefficient a wavefront
+// runs as long as its unluckiest lane (~10 proposals; 0.39 ms at p = 5e4).
+// Here a 256-thread block owns 256 coefficients and works in rounds: the
+// still-pending coefficients are compacted in LDS and the lanes they leave idle
+// evaluate further candidate proposals of the same coefficients, each on its
+// own Philox sub-stream (seed, iteration, j, candidate number).  A coefficient
+// takes its lowest-numbered accepted candidate, which is exactly what
+// proposing candidates 0, 1, 2, ... one after the other would return, so the
+// draw depends on neither the round structure nor the scheduling.
+constexpr int TS_BLOCK = 256;
+constexpr int TS_MAX_COPIES = 16;   // candidates per coefficient and round
+constexpr unsigned TS_MAX_TRIAL = 4095u;  // Philox sub-stream budget
+
+template <class Store>
+__device__ inline void tilted_stable_block(int64_t base, int64_t count,
+                                           double a, uint64_t seed,
+                                           uint64_t stream,
+                                           const double* s_tilt, Store store) {
+  // s_tilt[i]: tilt of local item i (< count <= TS_BLOCK), already in LDS
+  __shared__ int s_pending[TS_BLOCK];
+  __shared__ int s_next[TS_BLOCK];
+  __shared__ unsigned s_tried[TS_BLOCK];   // candidates already evaluated
+  __shared__ int s_winner[TS_BLOCK];       // lowest accepted copy this round
+  __shared__ int s_m, s_m_next;
+  const int tid = threadIdx.x;
+  const double odds = (1. - a) / a;
+  if (tid < count) {
+    s_pending[tid] = tid;
+    s_tried[tid] = 0u;
+  }
+  if (tid == 0) s_m = (int)count;
+  __syncthreads();
+  for (;;) {
+    const int m = s_m;
+    if (m == 0) break;
+    int copies = TS_BLOCK / m;
+    if (copies > TS_MAX_COPIES) copies = TS_MAX_COPIES;
+    const int q = tid % m, c = tid / m;
+    const bool active = c < copies;
+    const int item = s_pending[q];
+    if (tid < m) s_winner[s_pending[tid]] = 0x7fffffff;
+    if (tid == 0) s_m_next = 0;
+    __syncthreads();
+    bool ok = false;
+    double val = 0.;
+    if (active) {
+      const double tilt = s_tilt[item];
+      const double tilt_pow = pos_pow(tilt, a);
+      unsigned trial = s_tried[item] + (unsigned)c;
+      if (trial > TS_MAX_TRIAL) trial = TS_MAX_TRIAL;
+      Philox rng(seed, stream, (uint64_t)(base + item), trial);
+      if (tilt_pow < TiltedStable::kCostThreshold) {
+        // tilt^a < 2 => a single part, c = 1 (tilted_stable.pyx:138-140)
+        ok = TiltedStable::dc_trial(rng, a, tilt, 1., val);
+      } else {
+        double x;
+        ok = TiltedStable::dr_trial(rng, a, tilt_pow, x);
+        val = pos_pow(x, -odds);
+      }
+      if (trial >= TS_MAX_TRIAL) ok = true;  // budget exhausted: keep it
+      if (ok) atomicMin(&s_winner[item], c);
+    }
+    __syncthreads();
+    if (active && ok && s_winner[item] == c) store(item, val);
+    if (tid < m) {
+      const int it = s_pending[tid];
+      if (s_winner[it] == 0x7fffffff) {
+        s_tried[it] += (unsigned)copies;
+        s_next[atomicAdd(&s_m_next, 1)] = it;
+      }
+    }
+    __syncthreads();
+    if (tid < s_m_next) s_pending[tid] = s_next[tid];
+    if (tid == 0) s_m = s_m_next;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(TS_BLOCK) void chain_lscale_kernel(
     int64_t n_shrunk, int nu, double alpha, uint64_t seed, uint64_t stream,
     ChainScalars* __restrict__ sc, const double* __restrict__ coef,
     double* __restrict__ lscale) {
+  __shared__ double s_tilt[TS_BLOCK];
   const double g = sc->gscale;
-  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n_shrunk;
-       j += (int64_t)gridDim.x * 256) {
+  for (int64_t base = (int64_t)blockIdx.x * TS_BLOCK; base < n_shrunk;
+       base += (int64_t)gridDim.x * TS_BLOCK) {
+    const int64_t count =
+        (n_shrunk - base < TS_BLOCK) ? (n_shrunk - base) : TS_BLOCK;
     if (alpha == 2.) {
-      lscale[j] = .5;  // bayesbridge.py:460-461
+      if (threadIdx.x < count) lscale[base + threadIdx.x] = .5;  // :460-461
       continue;
     }
-    const double r = coef[j + nu] / g;
-    Philox rng(seed, stream, (uint64_t)j);
-    const double ts = TiltedStable::draw(rng, alpha / 2., r * r);
-    double l = sqrt(.5 / ts);
-    if (l == 0.) {
-      l = 10e-16;  // bayesbridge.py:470-472
-    } else if (isinf(l)) {
-      l = 2.0 / g;  // bayesbridge.py:473-476
+    if (threadIdx.x < count) {
+      const double r = coef[base + threadIdx.x + nu] / g;
+      s_tilt[threadIdx.x] = r * r;
     }
-    lscale[j] = l;
+    __syncthreads();
+    tilted_stable_block(base, count, alpha / 2., seed, stream, s_tilt,
+                        [&](int item, double ts) {
+                          double l = sqrt(.5 / ts);
+                          if (l == 0.) {
+                            l = 10e-16;  // bayesbridge.py:470-472
+                          } else if (isinf(l)) {
+                            l = 2.0 / g;  // bayesbridge.py:473-476
+                          }
+                          lscale[base + item] = l;
+                        });
+    __syncthreads();
   }
 }
 
@@ -348,13 +439,18 @@ __global__ __launch_bounds__(256) void dev_pg_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void dev_ts_kernel(
+__global__ __launch_bounds__(TS_BLOCK) void dev_ts_kernel(
     int64_t n, uint64_t seed, double a, const double* __restrict__ tilt,
     double* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * 256) {
-    Philox g(seed, STREAM_LSCALE, (uint64_t)i);
-    out[i] = TiltedStable::draw(g, a, tilt[i]);
+  __shared__ double s_tilt[TS_BLOCK];
+  for (int64_t base = (int64_t)blockIdx.x * TS_BLOCK; base < n;
+       base += (int64_t)gridDim.x * TS_BLOCK) {
+    const int64_t count = (n - base < TS_BLOCK) ? (n - base) : TS_BLOCK;
+    if (threadIdx.x < count) s_tilt[threadIdx.x] = tilt[base + threadIdx.x];
+    __syncthreads();
+    tilted_stable_block(base, count, a, seed, STREAM_LSCALE, s_tilt,
+                        [&](int item, double ts) { out[base + item] = ts; });
+    __syncthreads();
   }
 }
 
@@ -463,7 +559,7 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
                      pp + 2 * NPART, c->sd_unshrunk.as<double>(), sc);
   if (n_shrunk > 0)
     hipLaunchKernelGGL(chain_lscale_kernel,
-                       dim3(grid_for(n_shrunk, ROW_GRID)), dim3(256), 0, s,
+                       dim3(grid_for(n_shrunk, 4096)), dim3(TS_BLOCK), 0, s,
                        n_shrunk, nu, c->bridge_exp, c->seed,
                        iter_stream(STREAM_LSCALE, c->iter), sc,
                        c->coef.as<double>(), c->lscale.as<double>());
