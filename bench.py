@@ -24,9 +24,11 @@ for path in (ROOT, os.path.join(ROOT, "bayes-bridge_amd")):
         sys.path.insert(0, path)
 
 CONFIGS = {
-    # name: (n, p, binary_pred_freq)
+    # name: (n, p, binary_pred_freq)      sparse binary logit designs
     "config2": (100000, 10000, .01),
     "config3": (1000000, 50000, .002),
+    # BASELINE config 4: linear model, dense N(0,1) design stored in f32
+    "config4": (200000, 8000, None),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -43,6 +45,21 @@ def parse_args():
                     help="Gibbs iterations of the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=111)
     return ap.parse_args()
+
+
+def build_dense_problem(torch, cfg, seed, device):
+    """Config 4: X ~ N(0,1) in f32 from torch's Philox generator (seed 111),
+    y = X beta + N(0,1) with the demo's beta (demo.ipynb cell 5)."""
+    n, p, _ = CONFIGS[cfg]
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    X = torch.randn((n, p), generator=gen, device=device, dtype=torch.float32)
+    offset = X.double().mean(dim=0)
+    beta = torch.zeros(15, dtype=torch.float64, device=device)
+    beta[:5], beta[5:10], beta[10:15] = 1.5, 1., .5
+    y = X[:, :15].double() @ beta + torch.randn(
+        n, generator=gen, device=device, dtype=torch.float64)
+    return dict(n=n, p=p, nnz=n * (p + 1), X=X, offset=offset, y=y)
 
 
 def build_problem(torch, cfg, seed, device):
@@ -150,29 +167,54 @@ def main():
     device = "cuda:%d" % dev_index
     lib = _lib.load()
 
-    prob = build_problem(torch, args.config, args.seed, device)
-    n, p, nnz = prob["n"], prob["p"], prob["nnz"]
-    torch.cuda.synchronize()
-    design = HipSparseDesignMatrix.from_device_csr(
-        n, p, nnz, prob["indptr"].data_ptr(), prob["indices"].data_ptr(),
-        None, prob["offset"].data_ptr(), add_intercept=True,
-        device=dev_index, storage=args.storage)
-    P = p + 1
-
-    # chain: prior and init of the reference demo (demo.ipynb cells 7, 9)
+    dense = args.config == "config4"
     chain = c_void_p()
-    n_success = prob["n_success"].cpu().numpy()
-    sd_unshrunk = np.array([np.inf])
-    _lib.check(lib.bbx_chain_create(
-        design.handle, _lib.MODEL_LOGIT,
-        n_success.ctypes.data_as(c_void_p), None, 1,
-        sd_unshrunk.ctypes.data_as(c_void_p), .5, 2., 0., 0.,
-        chains.chain_seed(args.seed, rank), byref(chain)))
     import math
     unit = math.gamma(2 / .5) / math.gamma(1 / .5)   # prior.py:163-167
-    coef0 = np.zeros(P)
-    ph = n_success.mean()
-    coef0[0] = math.log(ph / (1 - ph))               # intercept MLE
+    sd_unshrunk = np.array([np.inf])
+    if dense:
+        from bayesbridge_amd.design_matrix import (HipDenseDesignMatrix,
+                                                   HipDesignMatrix)
+        prob = build_dense_problem(torch, args.config, args.seed, device)
+        n, p, nnz = prob["n"], prob["p"], prob["nnz"]
+        design = HipDenseDesignMatrix.__new__(HipDenseDesignMatrix)
+        HipDesignMatrix.__init__(design)
+        design.centered, design.intercept_added = True, True
+        design.column_offset = None
+        torch.cuda.synchronize()
+        _lib.check(lib.bbx_design_create_dense_dev(
+            n, p, c_void_p(prob["X"].data_ptr()), _lib.F32, _lib.F32,
+            c_void_p(prob["offset"].data_ptr()), 1, dev_index,
+            byref(design._h)))
+        del prob["X"]
+        P = p + 1
+        outcome = prob["y"].cpu().numpy()
+        _lib.check(lib.bbx_chain_create(
+            design.handle, _lib.MODEL_LINEAR,
+            outcome.ctypes.data_as(c_void_p), None, 1,
+            sd_unshrunk.ctypes.data_as(c_void_p), .5, 2., 0., 0.,
+            chains.chain_seed(args.seed, rank), byref(chain)))
+        coef0 = np.zeros(P)
+        coef0[0] = outcome.mean()
+    else:
+        prob = build_problem(torch, args.config, args.seed, device)
+        n, p, nnz = prob["n"], prob["p"], prob["nnz"]
+        torch.cuda.synchronize()
+        design = HipSparseDesignMatrix.from_device_csr(
+            n, p, nnz, prob["indptr"].data_ptr(), prob["indices"].data_ptr(),
+            None, prob["offset"].data_ptr(), add_intercept=True,
+            device=dev_index, storage=args.storage)
+        P = p + 1
+        # chain: prior and init of the reference demo (demo.ipynb cells 7, 9)
+        n_success = prob["n_success"].cpu().numpy()
+        _lib.check(lib.bbx_chain_create(
+            design.handle, _lib.MODEL_LOGIT,
+            n_success.ctypes.data_as(c_void_p), None, 1,
+            sd_unshrunk.ctypes.data_as(c_void_p), .5, 2., 0., 0.,
+            chains.chain_seed(args.seed, rank), byref(chain)))
+        coef0 = np.zeros(P)
+        ph = n_success.mean()
+        coef0[0] = math.log(ph / (1 - ph))               # intercept MLE
     lscale0 = np.ones(P - 1) * unit
     g0 = c_double(.01 / unit)                        # init global_scale=.01
     _lib.check(lib.bbx_chain_set_state(
@@ -188,7 +230,7 @@ def main():
                                      ncg_w.ctypes.data_as(c_void_p)))
     # state after warm-up (for the CPU baseline)
     state = None
-    if rank == 0 and world == 1 and args.cpu_baseline_iters > 0:
+    if rank == 0 and world == 1 and args.cpu_baseline_iters > 0 and not dense:
         coef = np.empty(P)
         obs = np.empty(n)
         ls = np.empty(P - 1)
@@ -261,11 +303,16 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s: logit, sparse binary CSR %dx%d nnz=%d "
-                            "(simulate_data.py distribution, f=%g), one "
-                            "independent chain per GPU, seeds %d+rank"
-                            % (args.config, n, p, nnz,
-                               CONFIGS[args.config][2], args.seed),
+                "workload": (
+                    "%s: linear, dense N(0,1) %dx%d stored f32 (torch Philox "
+                    "seed %d), centred + intercept, one independent chain "
+                    "per GPU, seeds %d+rank" % (args.config, n, p, args.seed,
+                                                args.seed)) if dense else (
+                    "%s: logit, sparse binary CSR %dx%d nnz=%d "
+                    "(simulate_data.py distribution, f=%g), one "
+                    "independent chain per GPU, seeds %d+rank"
+                    % (args.config, n, p, nnz, CONFIGS[args.config][2],
+                       args.seed)),
                 "storage": design.storage_format,
                 "mean_n_cg_iter": round(float(ncg[:K].mean()), 2),
                 "mean_n_cg_iter_warmup": round(float(ncg_w[:W].mean()), 2)

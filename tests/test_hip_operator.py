@@ -137,3 +137,29 @@ def test_bad_arguments_raise():
         hip.Tdot(np.zeros(3))
     with pytest.raises(NotImplementedError):
         hip.compute_fisher_info(np.ones(50))
+
+
+def test_tiled_many_panels_and_valued_entries():
+    """More row panels than CUs (several rounds of workgroups, separate
+    sum kernel) and non-binary values (the value-carrying kernel), checked
+    through adjointness, linearity and a sampled comparison with SciPy."""
+    from bayesbridge_amd import HipSparseDesignMatrix, simulate
+    rng = np.random.default_rng(21)
+    X = simulate.simulate_binary_csr_fast(1200000, 300, .02, seed=22)
+    X = X.copy()
+    X.data = rng.standard_normal(X.nnz) + 2.          # valued entries
+    hip = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
+                                storage='tiled')
+    info = hip.tiled_info()
+    n_panel = -(-X.shape[0] // info['X']['PR'])
+    assert n_panel * info['X']['G'] > 256
+    n, P = hip.shape
+    v, w = rng.standard_normal(P), rng.standard_normal(n)
+    Xv, Xtw = hip.dot(v), hip.Tdot(w)
+    off = np.asarray(X.mean(axis=0)).ravel()
+    ref_v = v[0] + X @ v[1:] - off @ v[1:]
+    ref_w = np.concatenate(([w.sum()], X.T @ w - w.sum() * off))
+    assert np.abs(Xv - ref_v).max() <= 1e-10 * np.abs(ref_v).max()
+    assert np.abs(Xtw - ref_w).max() <= 1e-10 * np.abs(ref_w).max()
+    lhs, rhs = np.dot(Xv, w), np.dot(v, Xtw)
+    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs), 1.)
