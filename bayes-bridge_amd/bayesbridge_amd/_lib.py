@@ -76,6 +76,9 @@ def _declare(lib):
         "bbx_design_get_timing": (
             [hp, c_int, POINTER(c_int64), POINTER(c_double)], c_int),
         "bbx_design_reset_timing": ([hp], c_int),
+        "bbx_hbm_probe": (
+            [c_int, c_int64, c_int, POINTER(c_double), POINTER(c_double)],
+            c_int),
         "bbx_chain_create": (
             [hp, c_int, c_void_p, c_void_p, c_int, c_void_p, c_double,
              c_double, c_double, c_double, c_uint64, POINTER(hp)], c_int),
@@ -161,6 +164,13 @@ def device_count():
     n = c_int(0)
     check(load().bbx_device_count(byref(n)))
     return n.value
+
+
+def hbm_probe(nbytes, reps=20, device=0):
+    """(read GB/s, copy GB/s) of a streaming kernel over `nbytes` of HBM."""
+    rd, cp = c_double(0.), c_double(0.)
+    check(load().bbx_hbm_probe(device, nbytes, reps, byref(rd), byref(cp)))
+    return rd.value, cp.value
 
 
 def require_gpu():

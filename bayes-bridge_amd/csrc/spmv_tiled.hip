@@ -37,6 +37,10 @@
 
 #include "common.hpp"
 
+#ifndef BBX_RING_BIN
+#define BBX_RING_BIN 4  // register-ring depth of the value-free kernel
+#endif
+
 namespace bbx {
 
 constexpr int TILE_W_MAX = 16128;  // doubles of the vector slice in LDS
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
   if (tid < 8) xs[W + tid] = 0.;
 
   constexpr int BATCH = VALS ? BATCH_VAL : BATCH_BIN;  // steps per ring slot
-  constexpr int RING = VALS ? 2 : 4;   // slots: RING-1 batches in flight
+  constexpr int RING = VALS ? 2 : BBX_RING_BIN;  // slots: RING-1 batches in flight
   constexpr int NV = VALS ? 4 : 1;     // 16-byte value loads per step
   constexpr int LOADS_PER_STEP = BATCH * (VALS ? 5 : 1) + 1;
   constexpr int WAIT_COUNT = (RING - 1) * LOADS_PER_STEP;

@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="config3", choices=sorted(CONFIGS))
     ap.add_argument("--storage", default="auto",
@@ -280,9 +280,18 @@ def main():
         dom = "dot" if timing["dot"][1] >= timing["tdot"][1] else "tdot"
         ach = per[dom]["gbs"]
         traffic = committed_traffic(design, dom, args.config)
+        # measured on this box, same size as one launch's algorithmic bytes
+        # and at 2 GB: what a plain streaming kernel reaches
+        probe_small = _lib.hbm_probe(int(per[dom]["bytes"]), 50, dev_index)
+        probe_large = _lib.hbm_probe(2 << 30, 10, dev_index)
         roofline = dict(
             bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
             unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
+            stream_probe_gbs={
+                "read_same_bytes": round(probe_small[0], 1),
+                "copy_same_bytes": round(probe_small[1], 1),
+                "read_2GiB": round(probe_large[0], 1),
+                "copy_2GiB": round(probe_large[1], 1)},
             kernel=dom + " (" + design.storage_format + ")",
             avg_launch_ms=round(per[dom]["avg_ms"], 5),
             algorithmic_bytes_per_launch=per[dom]["bytes"],

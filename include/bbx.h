@@ -227,6 +227,14 @@ int bbx_design_get_timing(bbx_design* h, int which, int64_t* n_launch,
                           double* total_ms);
 int bbx_design_reset_timing(bbx_design* h);
 
+/* Attainable-HBM probe ("confirm with a device-to-device
+ * copy/stream on the box"): streams a scratch buffer of `bytes` through a
+ * read-only kernel and a copy kernel `reps` times each, 16 bytes per lane, and
+ * returns the HIP-event rates.  read_gbps counts bytes read; copy_gbps counts
+ * bytes read + written.  Diagnostic only; not on the sampling path. */
+int bbx_hbm_probe(int device, int64_t bytes, int reps, double* read_gbps,
+                  double* copy_gbps);
+
 /* ------------------------------------------- device-resident Gibbs chain */
 
 /*
