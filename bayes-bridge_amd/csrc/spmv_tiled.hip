@@ -32,6 +32,7 @@
 // nnz: 2 bytes per entry), adds lane-private sums into LDS accumulators, and
 // writes the panel once.  No atomics: every sum has a fixed order.
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 
@@ -450,6 +451,10 @@ struct PanelBuild {
   int split_T = 0;
   std::vector<BatchDesc> descs;   // quad0/row_slot local to the panel
   std::vector<int32_t> wave_desc; // [G * TILE_WAVES] local start of each wave
+  // schedule statistics (BBX_TILED_STATS): per workgroup, in batches
+  std::vector<int64_t> wg_critical;  // sum over tiles of the busiest wave
+  std::vector<int64_t> wg_total;     // all waves, all tiles
+  int64_t dup_quads = 0;             // quads re-loaded to fill a batch
 };
 
 // Per-wave schedules of one panel: for every workgroup (group of column
@@ -460,11 +465,23 @@ struct PanelBuild {
 static void build_schedules(PanelBuild& pb, int G, int batch) {
   pb.wave_desc.assign((size_t)G * TILE_WAVES, 0);
   size_t tile_cursor = 0;
-  std::vector<std::vector<int>> deal(TILE_WAVES);
+  // The id stream is re-laid in the order it will be READ: workgroup, wave,
+  // tile, slice.  Every wave then walks one contiguous region of HBM front to
+  // back (consecutive 1 KiB loads, DRAM-page friendly) instead of hopping
+  // between the slices the dealing happened to give it.
+  const bool has_vals = !pb.vals.empty();
+  std::vector<uint4> new_ids;
+  std::vector<double> new_vals;
+  std::vector<uint32_t> new_rowids;
+  std::vector<SliceMeta> new_slices;
+  new_ids.reserve(pb.ids.size());
+  new_rowids.reserve(pb.rowids.size());
+  new_slices.reserve(pb.slices.size());
+  if (has_vals) new_vals.reserve(pb.vals.size());
   for (int g = 0; g < G; ++g) {
     const size_t t0 = tile_cursor, t1 = tile_cursor + pb.group_tile_count[g];
     tile_cursor = t1;
-    // deal[t - t0][w] = slices of tile t handled by wave w
+    // tile_deal[t - t0][w] = slices of tile t handled by wave w
     std::vector<std::vector<std::vector<int>>> tile_deal(t1 - t0);
     for (size_t t = t0; t < t1; ++t) {
       const TileDesc& td = pb.tiles[t];
@@ -485,16 +502,52 @@ static void build_schedules(PanelBuild& pb, int G, int batch) {
         load[best] += (int64_t)pb.slices[(size_t)sl].n_quad + 2;
       }
     }
+    {
+      int64_t crit = 0, total = 0;
+      for (size_t t = t0; t < t1; ++t) {
+        int64_t worst = 0;
+        for (int w = 0; w < TILE_WAVES; ++w) {
+          int64_t nb = 0;
+          for (int sl : tile_deal[t - t0][w]) {
+            const int64_t nq = pb.slices[(size_t)sl].n_quad;
+            const int64_t b = (nq + batch - 1) / batch;
+            nb += b;
+            pb.dup_quads += b * batch - nq;
+          }
+          worst = std::max(worst, nb);
+          total += nb;
+        }
+        crit += worst;
+      }
+      pb.wg_critical.push_back(crit);
+      pb.wg_total.push_back(total);
+    }
     for (int w = 0; w < TILE_WAVES; ++w) {
       pb.wave_desc[(size_t)g * TILE_WAVES + w] = (int32_t)pb.descs.size();
       for (size_t t = t0; t < t1; ++t) {
         bool first = true;
         for (int sl : tile_deal[t - t0][w]) {
-          const SliceMeta& sm = pb.slices[(size_t)sl];
+          const SliceMeta& old = pb.slices[(size_t)sl];
+          // move the slice to the end of the re-laid stream
+          SliceMeta sm;
+          sm.first_quad = (uint32_t)(new_ids.size() / WAVE);
+          sm.n_quad = old.n_quad;
+          const uint32_t new_sl = (uint32_t)new_slices.size();
+          new_slices.push_back(sm);
+          const size_t src = (size_t)old.first_quad * WAVE;
+          const size_t cnt = (size_t)old.n_quad * WAVE;
+          new_ids.insert(new_ids.end(), pb.ids.begin() + src,
+                         pb.ids.begin() + src + cnt);
+          if (has_vals)
+            new_vals.insert(new_vals.end(), pb.vals.begin() + src * 8,
+                            pb.vals.begin() + (src + cnt) * 8);
+          new_rowids.insert(new_rowids.end(),
+                            pb.rowids.begin() + (size_t)sl * WAVE,
+                            pb.rowids.begin() + (size_t)(sl + 1) * WAVE);
           for (uint32_t q0 = 0; q0 < sm.n_quad; q0 += (uint32_t)batch) {
             BatchDesc d;
             d.quad0 = sm.first_quad + q0;
-            d.row_slot = (uint32_t)sl * WAVE;
+            d.row_slot = new_sl * WAVE;
             const uint32_t left = sm.n_quad - q0;
             d.info = left < (uint32_t)batch ? left : (uint32_t)batch;
             if (left <= (uint32_t)batch) d.info |= BD_LAST;
@@ -521,6 +574,12 @@ static void build_schedules(PanelBuild& pb, int G, int batch) {
       pb.descs.push_back(endd);
     }
   }
+  // TileDesc::slice_begin/end keep describing the sorted order (set-up only;
+  // the kernel reads col_block and the schedules).
+  pb.ids.swap(new_ids);
+  pb.vals.swap(new_vals);
+  pb.rowids.swap(new_rowids);
+  pb.slices.swap(new_slices);
 }
 
 struct VRow {
@@ -571,7 +630,20 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
         ++seg_cnt;
       }
     int t_min = 32;
-    if (seg_cnt > 0) t_min = std::max<int>(t_min, (int)(3 * seg_sum / seg_cnt));
+    if (seg_cnt > 0) {
+      // Heavy-tailed segment lengths (the columns of simulate_data.py designs:
+      // longest ~15x the mean) leave the waves that drew the long slices
+      // streaming alone at the end of every tile; chunks of ~1.5x the mean
+      // bring the busiest wave from 2.0x to 1.3x the ideal load (Tdot at
+      // 1M x 50k: 60.8 -> 57.2 us).  Balanced rows (longest ~2.4x the mean)
+      // only get more slices from splitting (dot: 54.3 -> 57.4 us), so they
+      // keep the 3x rule.
+      const double mean_seg = (double)seg_sum / (double)seg_cnt;
+      double t_factor = (double)longest > 6. * mean_seg ? 1.5 : 3.;
+      static const char* t_env = getenv("BBX_TILED_TFACTOR");
+      if (t_env) t_factor = atof(t_env);
+      t_min = std::max<int>(t_min, (int)(t_factor * mean_seg));
+    }
     if (extra_budget > 0 && longest > t_min) {
       int lo = t_min, hi = longest;  // extras_for(hi) == 0
       while (lo < hi) {
@@ -783,6 +855,37 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
     });
   for (auto& th : pool) th.join();
 
+  if (getenv("BBX_TILED_STATS")) {
+    int64_t crit_max = 0, total = 0, dup = 0, quads = 0, n_wg = 0, crit_sum = 0;
+    int stat_extra = 0, stat_T = 0;
+    for (auto& pb : pbs) {
+      for (size_t g = 0; g < pb.wg_critical.size(); ++g) {
+        crit_max = std::max(crit_max, pb.wg_critical[g]);
+        crit_sum += pb.wg_critical[g];
+        total += pb.wg_total[g];
+        ++n_wg;
+      }
+      dup += pb.dup_quads;
+      quads += (int64_t)(pb.ids.size() / WAVE);
+      int ex = 0;
+      for (const FoldDesc& fd : pb.folds) ex += fd.count;
+      stat_extra = std::max(stat_extra, ex);
+      if (pb.split_T > 0 && (stat_T == 0 || pb.split_T < stat_T))
+        stat_T = pb.split_T;
+    }
+    fprintf(stderr,
+            "[bbx tiled %lldx%lld] W=%d blocks=%d PR=%d G=%d split T=%d "
+            "extras=%d workgroups=%lld: "
+            "quads=%lld (+%lld re-loaded to fill batches, %.1f%%); batches per "
+            "wave: ideal %.1f, mean critical path %.1f, worst workgroup %lld "
+            "(%.1f%% over ideal)\n",
+            (long long)R, (long long)C, m.W, m.n_block, m.PR, m.G, stat_T,
+            stat_extra, (long long)n_wg, (long long)quads, (long long)dup,
+            100. * (double)dup / (double)std::max<int64_t>(quads, 1),
+            (double)total / (double)(n_wg * TILE_WAVES),
+            (double)crit_sum / (double)n_wg, (long long)crit_max,
+            100. * ((double)crit_max * n_wg * TILE_WAVES / (double)total - 1.));
+  }
   // concatenate with offset fix-ups
   size_t tot_ids = 0, tot_slices = 0, tot_tiles = 0, tot_descs = 0;
   for (auto& pb : pbs) {
