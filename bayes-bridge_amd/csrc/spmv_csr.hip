@@ -130,20 +130,69 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
     const double* __restrict__ x, const double* __restrict__ z,
     const double* __restrict__ phi, const double* __restrict__ eta2,
     double* __restrict__ out, double* __restrict__ dot_part) {
-  const double sumw = sum_partials(sumw_part);
   const int64_t P = p + intercept;
+  const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+  const int64_t jj0 = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x;
+  // This kernel is pure latency (400 KB of output): every load that depends
+  // on nothing else -- the sum(w) partials, the first 16 slabs, the centring
+  // offset and the epilogue vectors of the thread's first element -- is issued
+  // before the first wait, one memory round trip instead of three.
+  constexpr int PRE = 16;
+  double pw[NPART / WAVE];
+#pragma unroll
+  for (int k = 0; k < NPART / WAVE; ++k)
+    pw[k] = sumw_part[(threadIdx.x & (WAVE - 1)) + k * WAVE];  // branch-free
+  const bool has0 = jj0 < P;
+  const bool main0 = has0 && !(intercept && jj0 == 0);
+  const int64_t jm0 = jj0 - intercept;
+  double sv[PRE];
+#pragma unroll
+  for (int u = 0; u < PRE; ++u)
+    sv[u] = (main0 && gfull && u < n_slab)
+                ? gfull[(int64_t)u * slab_stride + jm0] : 0.;
+  const double off0 = main0 ? offset[jm0] : 0.;
+  double e0 = 0., e1 = 0., e2 = 0., e3 = 0.;
+  if (has0) {
+    if (mode == TD_OPER) {
+      e0 = x[jj0];
+      e1 = d[jj0];
+      e2 = s[jj0];
+    } else if (mode == TD_RHS) {
+      e0 = z[jj0];
+      e1 = phi[jj0];
+      e2 = eta2[jj0];
+      e3 = s[jj0];
+    }
+  }
+  // sum(w): same adds in the same order as sum_partials()
+  __shared__ double s_sumw;
+  if (threadIdx.x < WAVE) {
+    double a = 0.;
+#pragma unroll
+    for (int k = 0; k < NPART / WAVE; ++k) a += pw[k];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) s_sumw = a;
+  }
+  __syncthreads();
+  const double sumw = s_sumw;
   double dacc = 0.;
-  for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
-       jj += (int64_t)gridDim.x * VEC_BLOCK) {
+  for (int64_t jj = jj0; jj < P; jj += stride) {
+    const bool first = jj == jj0;
     double g;
     if (intercept && jj == 0) {
       g = sumw;
     } else {
       const int64_t j = jj - intercept;
       if (gfull) {
-        // partial slabs, added in slab order; loads issued 8 at a time
+        // partial slabs, added in slab order
         g = 0.;
         int k = 0;
+        if (first) {
+#pragma unroll
+          for (int u = 0; u < PRE; ++u)
+            if (u < n_slab) g += sv[u];
+          k = n_slab < PRE ? n_slab : PRE;
+        }
         for (; k + 8 <= n_slab; k += 8) {
           double v[8];
 #pragma unroll
@@ -158,15 +207,17 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
         const int32_t cb = row_chunk_ptr[j], ce = row_chunk_ptr[j + 1];
         for (int32_t c = cb; c < ce; ++c) g += partial[c];
       }
-      g -= sumw * offset[j];
+      g -= sumw * (first ? off0 : offset[j]);
     }
     double r;
     if (mode == TD_OPER) {
-      const double xj = x[jj];
-      r = d[jj] * xj + s[jj] * g;
+      const double xj = first ? e0 : x[jj];
+      r = (first ? e1 : d[jj]) * xj + (first ? e2 : s[jj]) * g;
       dacc += xj * r;
     } else if (mode == TD_RHS) {
-      r = s[jj] * (z[jj] + (g + phi[jj] * eta2[jj]));
+      r = (first ? e3 : s[jj]) *
+          ((first ? e0 : z[jj]) +
+           (g + (first ? e1 : phi[jj]) * (first ? e2 : eta2[jj])));
       dacc += r * r;
     } else {
       r = g;

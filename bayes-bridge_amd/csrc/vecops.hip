@@ -41,6 +41,37 @@ __device__ inline double sum_partials_v(const double* part) {
   return r;
 }
 
+// Split-phase form of sum_partials_v: the loads are ISSUED first so that the
+// caller can queue its own independent loads (vector elements, CG scalars)
+// behind them, and everything comes back in ONE memory round trip instead of
+// one per dependent step.  The P-vector kernels are pure latency (~5 us for
+// 400 KB), so the number of serial round trips is their cost.  Same adds in
+// the same order as sum_partials_v: bit-identical result.
+struct PartLoad {
+  double v[NPART / WAVE];
+};
+__device__ inline PartLoad part_issue(const double* part) {
+  PartLoad p;
+#pragma unroll
+  for (int k = 0; k < NPART / WAVE; ++k)
+    p.v[k] = part[(threadIdx.x & (WAVE - 1)) + k * WAVE];  // branch-free
+  return p;
+}
+__device__ inline double part_finish(const PartLoad& p) {
+  __shared__ double s_tot2;
+  if (threadIdx.x < WAVE) {
+    double a = 0.;
+#pragma unroll
+    for (int k = 0; k < NPART / WAVE; ++k) a += p.v[k];
+    a = wave_sum_v(a);
+    if (threadIdx.x == 0) s_tot2 = a;
+  }
+  __syncthreads();
+  const double r = s_tot2;
+  __syncthreads();
+  return r;
+}
+
 // v = s .* x (or x), c_part = partials of <offset, v[1:]>.
 __global__ __launch_bounds__(VEC_BLOCK) void prep_v_kernel(
     int64_t P, int intercept, const double* __restrict__ x,
@@ -149,20 +180,42 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_direction_kernel(
     double* __restrict__ pvec, const double* __restrict__ s,
     const double* __restrict__ offset, double* __restrict__ sp,
     double* __restrict__ c_part) {
-  if (st->done) return;
-  const double rho = sum_partials_v(rr_part);
+  // every load that does not depend on another one goes out first
+  const PartLoad pl = part_issue(rr_part);
+  const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+  const int64_t j0 = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x;
+  const bool has0 = j0 < P;
+  double r0 = 0., p0 = 0., s0 = 0., o0 = 0.;
+  if (has0) {
+    r0 = r[j0];
+    if (k > 0) p0 = pvec[j0];
+    s0 = s[j0];
+    if (j0 >= intercept) o0 = offset[j0 - intercept];
+  }
+  const int was_done = st->done;
+  const double atol = st->atol;
+  const double rho_prev = (k > 0) ? st->rho[(k - 1) & 1] : 1.;
+  if (was_done) return;
+  const double rho = part_finish(pl);
   const bool finite = (rho == rho) && (rho - rho == 0.);
-  if (!finite || sqrt(rho) < st->atol) {
+  if (!finite || sqrt(rho) < atol) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       st->done = 1;
       if (!finite) st->bad = 1;
     }
     return;
   }
-  const double beta = (k > 0) ? rho / st->rho[(k - 1) & 1] : 0.;
+  const double beta = (k > 0) ? rho / rho_prev : 0.;
   double acc = 0.;
-  for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
-       jj += (int64_t)gridDim.x * VEC_BLOCK) {
+  if (has0) {
+    double pj = r0;
+    if (k > 0) pj += beta * p0;
+    pvec[j0] = pj;
+    const double v = s0 * pj;
+    sp[j0] = v;
+    if (j0 >= intercept) acc += o0 * v;
+  }
+  for (int64_t jj = j0 + stride; jj < P; jj += stride) {
     double pj = r[jj];
     if (k > 0) pj += beta * pvec[jj];
     pvec[jj] = pj;
@@ -180,12 +233,30 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_update_kernel(
     const double* __restrict__ pq_part, const double* __restrict__ pvec,
     const double* __restrict__ q, double* __restrict__ x,
     double* __restrict__ r, double* __restrict__ rr_part) {
-  if (st->done) return;
-  const double pq = sum_partials_v(pq_part);
-  const double alpha = st->rho[k & 1] / pq;
+  const PartLoad pl = part_issue(pq_part);
+  const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
+  const int64_t j0 = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x;
+  const bool has0 = j0 < P;
+  double p0 = 0., q0 = 0., x0 = 0., r0 = 0.;
+  if (has0) {
+    p0 = pvec[j0];
+    q0 = q[j0];
+    x0 = x[j0];
+    r0 = r[j0];
+  }
+  const int was_done = st->done;
+  const double rho = st->rho[k & 1];
+  if (was_done) return;
+  const double pq = part_finish(pl);
+  const double alpha = rho / pq;
   double acc = 0.;
-  for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
-       jj += (int64_t)gridDim.x * VEC_BLOCK) {
+  if (has0) {
+    x[j0] = x0 + alpha * p0;
+    const double rj = r0 - alpha * q0;
+    r[j0] = rj;
+    acc += rj * rj;
+  }
+  for (int64_t jj = j0 + stride; jj < P; jj += stride) {
     x[jj] += alpha * pvec[jj];
     const double rj = r[jj] - alpha * q[jj];
     r[jj] = rj;
