@@ -173,8 +173,7 @@ constexpr int FILL_UNROLL = (TILE_W_MAX + TILE_THREADS - 1) / TILE_THREADS;
 
 template <bool VALS>
 __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
-    int64_t R, int64_t C, int W, int PR, int G,
-    const int32_t* __restrict__ wg_tiles, const TileDesc* __restrict__ tiles,
+    int64_t R, int64_t C, int W, int PR, int G, int blocks_per_group,
     const int32_t* __restrict__ wave_desc,
     const BatchDesc* __restrict__ descs, const uint32_t* __restrict__ rowids,
     const uint4* __restrict__ ids, const double* __restrict__ vals,
@@ -185,7 +184,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
     const double* __restrict__ rowscale, double* __restrict__ out,
     double* __restrict__ slab, int n_acc,
     const int32_t* __restrict__ panel_fold, const FoldDesc* __restrict__ folds,
-    double* __restrict__ out_sum_part, int ablate) {
+    double* __restrict__ out_sum_part, int ablate,
+    unsigned long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* xs = lds;               // W + 8 doubles; xs[W] == 0 (padding target)
   double* acc = lds + (W + 8);    // n_acc = PR + extra doubles
@@ -212,7 +212,11 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
   // RING-1 are in flight from HBM, across slice AND tile boundaries.  The
   // schedule marks where the wave enters a new tile; there every wave of the
   // workgroup meets at a barrier and the vector slice in LDS is replaced.
-  int t = wg_tiles[blockIdx.x] - 1;   // tile being processed (advanced at switch)
+  // Column block of the tile being processed.  A workgroup's tiles are the
+  // consecutive column blocks of its group (empty ones included), so the block
+  // index is arithmetic: no descriptor load sits between reaching a tile
+  // boundary and issuing the loads of the next vector slice.
+  int cb = group * blocks_per_group - 1;  // advanced at every switch
   // Issue cursor.  The wave's descriptors are fetched 64 at a time (one per
   // lane) and read back with v_readlane, so that no memory latency sits
   // between two ISSUE steps; the next block of 64 is prefetched.
@@ -228,6 +232,12 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
   unsigned rid[RING];
   unsigned info[RING];
   double a0 = 0., a1 = 0., b0 = 0., b1 = 0.;
+  // BBX_TILED_DEBUG: per-wave cycle stamps (start, time in tile switches,
+  // end of the stream loop, end of the kernel); dbg is null in production.
+  // 32-bit tick counts (durations only: s_memtime bases differ across XCDs)
+  unsigned t_start = 0, t_switch = 0, t_loop = 0, t_skew = 0;
+
+  if (dbg) t_start = (unsigned)__builtin_amdgcn_s_memtime();
 
 #define BBX_ISSUE(K)                                                          \
   do {                                                                        \
@@ -297,9 +307,10 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
         } else {
           if (inf & BD_TILE_FIRST) {
             // ---- enter the next tile: replace the vector slice in LDS
-            ++t;
-            const TileDesc td = tiles[t];
-            const int64_t col0 = (int64_t)td.col_block * W;
+            unsigned t_sw0 = 0;
+            if (dbg) t_sw0 = (unsigned)__builtin_amdgcn_s_memtime();
+            ++cb;
+            const int64_t col0 = (int64_t)cb * W;
             const int cols_here = (int)((C - col0 < W) ? (C - col0) : W);
             double fv[FILL_UNROLL];
 #pragma unroll
@@ -308,6 +319,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
               fv[u] = (j < cols_here && !(ablate & 2)) ? x[col0 + j] : 0.;
             }
             __syncthreads();  // every wave is done with the previous slice
+            if (dbg) t_skew += (unsigned)__builtin_amdgcn_s_memtime() - t_sw0;
             // one explicit wait for the slice values on every path, so that no
             // compiler-visible load is left "maybe pending" inside the loop
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
@@ -317,6 +329,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
               if (j < W) xs[j] = fv[u];
             }
             __syncthreads();
+            if (dbg) t_switch += (unsigned)__builtin_amdgcn_s_memtime() - t_sw0;
           }
           const int cntk = (int)(inf & 15u);
           if (cntk > 0) {
@@ -361,6 +374,7 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
   }
 #undef BBX_ISSUE
 #undef BBX_WAIT
+  if (dbg) t_loop = (unsigned)__builtin_amdgcn_s_memtime() - t_start;
   __syncthreads();
   {  // fold the chunk accumulators of split rows, fixed order
     const int f0 = panel_fold[panel], f1 = panel_fold[panel + 1];
@@ -414,6 +428,13 @@ __global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
   } else {
     double* dst = slab + (int64_t)group * R + row0;
     for (int r = tid; r < rows_here; r += TILE_THREADS) dst[r] = acc[r];
+  }
+  if (dbg && lane == 0) {
+    unsigned long long* o = dbg + ((size_t)blockIdx.x * TILE_WAVES + wave) * 4;
+    o[0] = (unsigned)__builtin_amdgcn_s_memtime() - t_start;  // whole wave
+    o[1] = t_loop;    // stream loop incl. tile switches
+    o[2] = t_switch;  // inside tile switches
+    o[3] = t_skew;    // of which: arrival -> every wave arrived
   }
 }
 
@@ -1061,25 +1082,57 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
   const unsigned grid = (unsigned)(m.n_panel * m.G);
   const size_t lb = lds_bytes(m);
   static const int ablate = getenv("BBX_ABLATE") ? atoi(getenv("BBX_ABLATE")) : 0;
+  // BBX_TILED_DEBUG=N: per-wave phase timing of launches N and N+1 (stderr)
+  static const int dbg_at =
+      getenv("BBX_TILED_DEBUG") ? atoi(getenv("BBX_TILED_DEBUG")) : -1;
+  static int dbg_count = 0;
+  static unsigned long long* dbg_buf = nullptr;
+  unsigned long long* dbg = nullptr;
+  if (dbg_at >= 0) {
+    if (!dbg_buf)
+      BBX_HIP(hipMalloc(&dbg_buf, sizeof(unsigned long long) * 4096 * TILE_WAVES * 4));
+    if ((dbg_count == dbg_at || dbg_count == dbg_at + 1) && grid <= 4096)
+      dbg = dbg_buf;
+    ++dbg_count;
+  }
   if (m.has_vals)
     hipLaunchKernelGGL(tiled_spmv_kernel<true>, dim3(grid), dim3(TILE_THREADS),
                        lb, h->stream, m.R, m.C, m.W, m.PR, m.G,
-                       m.wg_tiles.as<int32_t>(), m.tiles.as<TileDesc>(),
+                       (m.n_block + m.G - 1) / m.G,
                        m.wave_desc.as<int32_t>(), m.descs.as<BatchDesc>(),
                        m.rowids.as<uint32_t>(), m.ids.as<uint4>(),
                        m.vals.as<double>(), x, c_part, x0_ptr, rowscale, out,
                        slab, m.PR + m.n_extra, m.panel_fold.as<int32_t>(),
-                       m.folds.as<FoldDesc>(), out_sum_part, ablate);
+                       m.folds.as<FoldDesc>(), out_sum_part, ablate, dbg);
   else
     hipLaunchKernelGGL(tiled_spmv_kernel<false>, dim3(grid),
                        dim3(TILE_THREADS), lb, h->stream, m.R, m.C, m.W, m.PR,
-                       m.G, m.wg_tiles.as<int32_t>(), m.tiles.as<TileDesc>(),
+                       m.G, (m.n_block + m.G - 1) / m.G,
                        m.wave_desc.as<int32_t>(), m.descs.as<BatchDesc>(),
                        m.rowids.as<uint32_t>(), m.ids.as<uint4>(), nullptr, x,
                        c_part, x0_ptr, rowscale, out, slab, m.PR + m.n_extra,
                        m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),
-                       out_sum_part, ablate);
+                       out_sum_part, ablate, dbg);
   BBX_HIP(hipGetLastError());
+  if (dbg) {
+    BBX_HIP(hipStreamSynchronize(h->stream));
+    const size_t nw = (size_t)grid * TILE_WAVES;
+    std::vector<unsigned long long> hb(nw * 4);
+    BBX_HIP(hipMemcpy(hb.data(), dbg, hb.size() * 8, hipMemcpyDeviceToHost));
+    double tot = 0., loop = 0., sw = 0., skew = 0.;
+    for (size_t w = 0; w < nw; ++w) {
+      tot += (double)hb[w * 4];
+      loop += (double)hb[w * 4 + 1];
+      sw += (double)hb[w * 4 + 2];
+      skew += (double)hb[w * 4 + 3];
+    }
+    fprintf(stderr,
+            "[bbx tiled dbg grid=%u launch=%d] ticks per wave (mean): total "
+            "%.0f = streaming %.0f + tile switches %.0f (waiting for the last "
+            "wave %.0f, refill + second barrier %.0f) + epilogue %.0f\n",
+            grid, dbg_count, tot / nw, (loop - sw) / nw, sw / nw, skew / nw,
+            (sw - skew) / nw, (tot - loop) / nw);
+  }
   return BBX_OK;
 }
 
