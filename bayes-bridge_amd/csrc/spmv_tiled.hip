@@ -44,9 +44,24 @@
 
 namespace bbx {
 
-constexpr int TILE_W_MAX = 16128;  // doubles of the vector slice in LDS
+// Workgroup geometry.  Default: one 1024-thread workgroup owns a CU's LDS.
+// -DBBX_TILE_THREADS=512 -DBBX_TILE_LDS_KB=80 -DBBX_TILE_W_MAX=7168 builds the
+// "two half-width workgroups per CU" variant measured in DESIGN.md 3.1.
+#ifndef BBX_TILE_THREADS
+#define BBX_TILE_THREADS 1024
+#endif
+#ifndef BBX_TILE_LDS_KB
+#define BBX_TILE_LDS_KB 160
+#endif
+#ifndef BBX_TILE_W_MAX
+#define BBX_TILE_W_MAX 16128
+#endif
+constexpr int TILE_W_MAX = BBX_TILE_W_MAX;  // doubles of the vector slice in LDS
 constexpr int TILE_PR_MAX = 4096;  // row accumulators in LDS
-constexpr int TILE_THREADS = 1024;
+constexpr int TILE_THREADS = BBX_TILE_THREADS;
+constexpr int TILE_LDS_BYTES = BBX_TILE_LDS_KB * 1024;
+constexpr int TILE_WG_PER_CU = (160 / BBX_TILE_LDS_KB);
+constexpr int TILE_WG_PER_ROUND = 256 * TILE_WG_PER_CU;
 constexpr int TILE_WAVES = TILE_THREADS / WAVE;
 constexpr uint16_t NO_ROW = 0xFFFF;
 
@@ -172,7 +187,7 @@ __device__ __forceinline__ void asm_load_u32(unsigned& dst, unsigned off,
 constexpr int FILL_UNROLL = (TILE_W_MAX + TILE_THREADS - 1) / TILE_THREADS;
 
 template <bool VALS>
-__global__ __launch_bounds__(TILE_THREADS) void tiled_spmv_kernel(
+__global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
     int64_t R, int64_t C, int W, int PR, int G, int blocks_per_group,
     const int32_t* __restrict__ wave_desc,
     const BatchDesc* __restrict__ descs, const uint32_t* __restrict__ rowids,
@@ -797,7 +812,7 @@ static void choose_shape(int64_t R, int64_t C, int64_t nnz, int n_block, int W,
                          int* PR_out, int* G_out) {
   double best = 1e300;
   int best_pr = 256, best_g = 1;
-  const int lds_rows = (int)((160 * 1024 - 2048) / 8) - (W + 8);
+  const int lds_rows = (int)((TILE_LDS_BYTES - 2048) / 8) - (W + 8);
   int pr_cap = TILE_PR_MAX;
   if (lds_rows - 256 < pr_cap) pr_cap = lds_rows - 256;  // room for extras
   if (pr_cap < 128) pr_cap = 128;
@@ -807,7 +822,7 @@ static void choose_shape(int64_t R, int64_t C, int64_t nnz, int n_block, int W,
       const int bpg = (n_block + g - 1) / g;
       if ((n_block + bpg - 1) / bpg != g) continue;  // not a distinct split
       const double n_wg = (double)n_panel * g;
-      const double rounds = std::ceil(n_wg / 256.);
+      const double rounds = std::ceil(n_wg / (double)TILE_WG_PER_ROUND);
       const double rows = (double)std::min<int64_t>(pr, R);
       const double tile_nnz = (double)nnz * rows / (double)R / n_block;
       const double per_tile = 4.3 + tile_nnz * 24e-6;            // us
@@ -857,7 +872,7 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
   // LDS left after the vector slice and the row accumulators pays for the
   // extra accumulators of split rows (2 KB stay free for static LDS).
   int extra_budget =
-      (int)((160 * 1024 - 2048) / 8) - (m.W + 8) - m.PR;
+      (int)((TILE_LDS_BYTES - 2048) / 8) - (m.W + 8) - m.PR;
   if (extra_budget > 2048) extra_budget = 2048;
   if (extra_budget < 0) extra_budget = 0;
   if (const char* e = getenv("BBX_TILED_EXTRA")) extra_budget = atoi(e);
@@ -1056,7 +1071,7 @@ int build_tiled(bbx_design* h) {
                     h->binary ? nullptr : vals.data()));
   for (const TiledMatrix* m : {&tp->x, &tp->xt}) {
     const size_t lb = lds_bytes(*m);
-    if (lb > 160 * 1024)
+    if (lb > (size_t)TILE_LDS_BYTES)
       return fail(BBX_ERR_INVALID, "tile does not fit in LDS");
   }
   BBX_HIP(hipFuncSetAttribute(
