@@ -263,18 +263,21 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
     const unsigned inf =                                                      \
         (unsigned)__builtin_amdgcn_readlane((int)dcur.z, pos);                \
     const int cntk = (int)(inf & 15u);                                        \
-    const int left = cntk > 0 ? cntk : 1;                                     \
-    const unsigned quad0 = cntk > 0 ? d_quad0 : 0u;                           \
     _Pragma("unroll") for (int u = 0; u < BATCH; ++u) {                       \
-      const unsigned uu = (unsigned)((u < left) ? u : left - 1);              \
-      const unsigned slot = (quad0 + uu) * WAVE + lane;                       \
+      /* Steps past the end of a slice (and the loads of marker batches)   */ \
+      /* only keep the vmcnt bookkeeping uniform.  They must NOT re-read a */ \
+      /* line that is still in flight (the L1 parks such a request until   */ \
+      /* the line lands and blocks every request behind it): all lanes     */ \
+      /* read the first 16 bytes of the stream, one resident line.         */ \
+      const unsigned slot =                                                   \
+          (u < cntk) ? (d_quad0 + (unsigned)u) * WAVE + lane : 0u;            \
       asm_load_x4(e[K][u], slot * 16u, ids);                                  \
       if (VALS) {                                                             \
         _Pragma("unroll") for (int j = 0; j < NV; ++j)                        \
             asm_load_d2(ev[K][u][j], slot * 64u + 16u * j, vals);             \
       }                                                                       \
     }                                                                         \
-    asm_load_u32(rid[K], ((cntk > 0 ? d_row : 0u) + lane) * 4u, rowids);      \
+    asm_load_u32(rid[K], (cntk > 0 ? (d_row + lane) : 0u) * 4u, rowids);      \
     info[K] = inf;                                                            \
     if (!(inf & BD_END)) {                                                    \
       ++pos;                                                                  \
