@@ -185,8 +185,59 @@ __global__ void all_ones_kernel(int64_t nnz, const double* __restrict__ data,
     if (data[i] != 1.0) *flag = 0;
 }
 
+// Structure check of a CSR matrix that is already on the device.  flag bits:
+// 1 indptr not non-decreasing / wrong ends, 2 column index out of range,
+// 4 column indices of a row not in ascending order (duplicates are allowed:
+// like SciPy's csr_matvec they simply add up).
+__global__ void validate_csr_kernel(int64_t n, int64_t p, int64_t nnz,
+                                    const int32_t* __restrict__ indptr,
+                                    const int32_t* __restrict__ indices,
+                                    int* __restrict__ flag) {
+  int bad = 0;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n;
+       row += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = indptr[row], e = indptr[row + 1];
+    if ((row == 0 && b != 0) || (row == n - 1 && e != nnz) || e < b || b < 0 ||
+        e > nnz) {
+      bad |= 1;
+      continue;
+    }
+    int32_t prev = -1;
+    for (int64_t k = b; k < e; ++k) {
+      const int32_t c = indices[k];
+      if (c < 0 || c >= p) bad |= 2;
+      if (c < prev) bad |= 4;
+      prev = c;
+    }
+  }
+  if (bad) atomicOr(flag, bad);
+}
+
+static int validate_csr(bbx_design* h) {
+  int* d_flag = static_cast<int*>(h->cg_state.ptr);  // scratch
+  BBX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(validate_csr_kernel, dim3(4096), dim3(256), 0, h->stream,
+                     h->n, h->p, h->nnz, h->indptr.as<int32_t>(),
+                     h->indices.as<int32_t>(), d_flag);
+  BBX_HIP(hipGetLastError());
+  int flag = 0;
+  BBX_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost,
+                         h->stream));
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  if (flag & 1)
+    return fail(BBX_ERR_INVALID,
+                "indptr must start at 0, end at nnz and be non-decreasing");
+  if (flag & 2) return fail(BBX_ERR_INVALID, "column index out of range");
+  if (flag & 4)
+    return fail(BBX_ERR_INVALID,
+                "column indices must be ascending within each row "
+                "(scipy: X.sort_indices())");
+  return BBX_OK;
+}
+
 // Common tail of the two CSR constructors: the device CSR arrays are in place.
 static int finish_csr(bbx_design* h, int format) {
+  BBX_TRY(validate_csr(h));
   // Values that are all exactly 1.0 are dropped (binary designs,
   // simulate_data.py:100-117): the kernels then read indices only.
   if (h->data.ptr && h->nnz > 0) {
@@ -257,18 +308,7 @@ static int create_csr_common(int64_t n, int64_t p, int64_t nnz,
                         kind));
     else
       BBX_HIP(hipMemset(h->offset.ptr, 0, sizeof(double) * (size_t)p));
-    if (!from_device) {
-      // validate the host CSR structure (cheap, catches wrong dtypes early)
-      if (indptr[0] != 0 || indptr[n] != nnz)
-        return fail(BBX_ERR_INVALID, "indptr[0] != 0 or indptr[n] != nnz");
-      for (int64_t i = 0; i < n; ++i)
-        if (indptr[i + 1] < indptr[i])
-          return fail(BBX_ERR_INVALID, "indptr is not non-decreasing");
-      for (int64_t k = 0; k < nnz; ++k)
-        if (indices[k] < 0 || indices[k] >= p)
-          return fail(BBX_ERR_INVALID, "column index out of range");
-    }
-    BBX_TRY(finish_csr(h, format));
+    BBX_TRY(finish_csr(h, format));  // validates the structure first
     return BBX_OK;
   };
   st = body();

@@ -81,6 +81,10 @@ int bbx_device_count(int* count);
  *   indptr[n+1], indices[nnz]: int32, as SciPy CSR; data[nnz] f64 or NULL when
  *   every stored value is 1.0; col_offset[p] f64 or NULL (= zeros, i.e. not
  *   centred); add_intercept: 1 => shape is (n, p+1) (sparse_matrix.py:51-54).
+ * The structure is validated on the device (both constructors): indptr must
+ * run 0 .. nnz non-decreasing, column indices must lie in [0, p) and ascend
+ * within a row (duplicates allowed, they add up like in SciPy's csr_matvec;
+ * SciPy users call X.sort_indices() first) -- otherwise BBX_ERR_INVALID.
  */
 int bbx_design_create_csr(int64_t n, int64_t p, int64_t nnz,
                           const int32_t* indptr, const int32_t* indices,

@@ -163,3 +163,44 @@ def test_tiled_many_panels_and_valued_entries():
     assert np.abs(Xtw - ref_w).max() <= 1e-10 * np.abs(ref_w).max()
     lhs, rhs = np.dot(Xv, w), np.dot(v, Xtw)
     assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs), 1.)
+
+
+def test_cabi_rejects_malformed_csr():
+    """The C ABI validates the CSR structure on the device instead of reading
+    out of bounds: wrong indptr ends, column out of range, unsorted rows."""
+    from ctypes import byref, c_void_p
+    from bayesbridge_amd import _lib
+    lib = _lib.load()
+
+    def create(indptr, indices, n=3, p=4):
+        indptr = np.asarray(indptr, dtype=np.int32)
+        indices = np.asarray(indices, dtype=np.int32)
+        h = c_void_p()
+        st = lib.bbx_design_create_csr(
+            n, p, len(indices), indptr.ctypes.data_as(c_void_p),
+            indices.ctypes.data_as(c_void_p), None, None, 1, 0,
+            _lib.FORMAT_AUTO, byref(h))
+        if st == 0:
+            lib.bbx_design_destroy(h)
+        return st, _lib.last_error()
+
+    assert create([0, 2, 3, 5], [0, 3, 1, 0, 2])[0] == 0
+    st, msg = create([0, 2, 3, 4], [0, 3, 1, 0, 2])
+    assert st < 0 and 'indptr' in msg
+    st, msg = create([0, 3, 2, 5], [0, 3, 1, 0, 2])
+    assert st < 0 and 'indptr' in msg
+    st, msg = create([0, 2, 3, 5], [0, 4, 1, 0, 2])
+    assert st < 0 and 'out of range' in msg
+    st, msg = create([0, 2, 3, 5], [3, 0, 1, 0, 2])
+    assert st < 0 and 'ascending' in msg
+    # duplicates are legal and add up (SciPy semantics)
+    from bayesbridge_amd import HipSparseDesignMatrix
+    import scipy.sparse as sp
+    X = sp.csr_matrix((np.ones(4), np.array([1, 1, 2, 0], dtype=np.int32),
+                       np.array([0, 3, 3, 4], dtype=np.int32)), shape=(3, 3))
+    assert not X.has_canonical_format
+    for storage in STORAGES:
+        hip = HipSparseDesignMatrix(X, add_intercept=False, storage=storage)
+        v = np.array([1., 10., 100.])
+        np.testing.assert_allclose(hip.dot(v), [120., 0., 1.], rtol=1e-14)
+        np.testing.assert_allclose(hip.Tdot(v), [100., 2., 1.], rtol=1e-14)
