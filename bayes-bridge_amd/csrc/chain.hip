@@ -375,16 +375,20 @@ __device__ inline void tilted_stable_block(int64_t base, int64_t count,
   }
 }
 
+// `items` (<= TS_BLOCK) coefficients per pass of a 256-thread block: with fewer
+// items than threads every coefficient starts with TS_BLOCK/items candidate
+// proposals at once.  The accepted value is the one of the LOWEST accepted trial
+// index, so the result does not depend on `items` (or on the grid).
 __global__ __launch_bounds__(TS_BLOCK) void chain_lscale_kernel(
     int64_t n_shrunk, int nu, double alpha, uint64_t seed, uint64_t stream,
     ChainScalars* __restrict__ sc, const double* __restrict__ coef,
-    double* __restrict__ lscale) {
+    double* __restrict__ lscale, int items) {
   __shared__ double s_tilt[TS_BLOCK];
   const double g = sc->gscale;
-  for (int64_t base = (int64_t)blockIdx.x * TS_BLOCK; base < n_shrunk;
-       base += (int64_t)gridDim.x * TS_BLOCK) {
+  for (int64_t base = (int64_t)blockIdx.x * items; base < n_shrunk;
+       base += (int64_t)gridDim.x * items) {
     const int64_t count =
-        (n_shrunk - base < TS_BLOCK) ? (n_shrunk - base) : TS_BLOCK;
+        (n_shrunk - base < items) ? (n_shrunk - base) : items;
     if (alpha == 2.) {
       if (threadIdx.x < count) lscale[base + threadIdx.x] = .5;  // :460-461
       continue;
@@ -557,12 +561,23 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
                      nu, c->bridge_exp, c->shape0, c->rate0, lower_bd, c->seed,
                      iter_stream(STREAM_GSCALE, c->iter), pp, pp + NPART,
                      pp + 2 * NPART, c->sd_unshrunk.as<double>(), sc);
-  if (n_shrunk > 0)
-    hipLaunchKernelGGL(chain_lscale_kernel,
-                       dim3(grid_for(n_shrunk, 4096)), dim3(TS_BLOCK), 0, s,
-                       n_shrunk, nu, c->bridge_exp, c->seed,
+  if (n_shrunk > 0) {
+    // Measured at p = 50k (ms per Gibbs iteration, items per block): 256:
+    // 5.69, 128: 5.63, 64: 5.72, 32: 5.83, 16: 6.11 -- the speculative copies
+    // of small blocks cost more arithmetic than the extra blocks hide latency.
+    const int items_default = (n_shrunk / TS_BLOCK < 1024) ? 128 : TS_BLOCK;
+    int items = items_default;
+    static const char* items_env = getenv("BBX_TS_ITEMS");
+    if (items_env) items = atoi(items_env);
+    if (items < 1) items = 1;
+    if (items > TS_BLOCK) items = TS_BLOCK;
+    int64_t nb = (n_shrunk + items - 1) / items;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(chain_lscale_kernel, dim3((unsigned)nb), dim3(TS_BLOCK),
+                       0, s, n_shrunk, nu, c->bridge_exp, c->seed,
                        iter_stream(STREAM_LSCALE, c->iter), sc,
-                       c->coef.as<double>(), c->lscale.as<double>());
+                       c->coef.as<double>(), c->lscale.as<double>(), items);
+  }
   BBX_HIP(hipGetLastError());
   c->iter += 1;
   return info;
