@@ -21,6 +21,15 @@ Files written (all small .npz/.npy):
   chain_linear_dense_2000x500_summary.npz
       BASELINE config 1 (simulate_design(2000, 500, format_='dense',
       seed=111)): summary statistics of a 20-iteration reference run.
+  chain_logit_binary_20000x1000_summary.npz
+      BASELINE config 2 scaled down 5x10 (simulate_design(20000, 1000,
+      binary_frac=1, binary_pred_freq=.01, format_='sparse', seed=111), demo
+      coefficients and prior): the first 10 samples of a reference run
+      (exact-seed parity through the value-free tiled layout) and posterior
+      summaries of iterations 100..400 (distribution parity of the device
+      RNG chain).  The design itself is NOT stored: the tests regenerate it
+      with bayesbridge_amd.simulate (an exact replay of the reference's RNG
+      calls) and check it against the checksums kept here.
 """
 import os
 import sys
@@ -216,9 +225,49 @@ def config1_summary():
           info['_reg_coef_sampling_info']['n_cg_iter'])
 
 
+def config2_small_summary():
+    n, p, f = 20000, 1000, .01
+    X = refsim.simulate_design(n, p, binary_frac=1., binary_pred_freq=f,
+                               format_='sparse', seed=111)
+    X = X.tocsr()
+    X.sort_indices()
+    beta = np.zeros(p)
+    beta[:5], beta[5:10], beta[10:15] = 1.5, 1., .5
+    y = refsim.simulate_outcome(X, beta, 'logit', seed=1)
+    bridge = BayesBridge(
+        RegressionModel(y, X, 'logit'),
+        RegressionCoefPrior(bridge_exponent=.5, regularizing_slab_size=2.))
+    n_iter, n_burn = 400, 100
+    samples, info = bridge.gibbs(n_iter, 0, init={'global_scale': .01},
+                                 coef_sampler_type='cg', seed=111)
+    coef = samples['coef']
+    n_success, n_trial = y
+    np.savez_compressed(
+        os.path.join(HERE, 'chain_logit_binary_20000x1000_summary.npz'),
+        shape=np.array([n, p]), freq=f, nnz=X.nnz,
+        indices_checksum=np.int64(
+            (X.indices.astype(np.int64) * (np.arange(X.nnz) % 1009 + 1)).sum()),
+        indptr_tail=X.indptr[-4:], n_success_sum=n_success.sum(),
+        n_success_head=n_success[:32], n_trial_head=n_trial[:32],
+        coef_first10=coef[:, :10],
+        global_scale_first10=samples['global_scale'][:10],
+        logp_first10=samples['logp'][:10],
+        n_cg_iter=info['_reg_coef_sampling_info']['n_cg_iter'],
+        coef_mean=coef[:, n_burn:].mean(axis=1),
+        coef_sd=coef[:, n_burn:].std(axis=1, ddof=1),
+        global_scale_mean=samples['global_scale'][n_burn:].mean(),
+        global_scale_sd=samples['global_scale'][n_burn:].std(ddof=1),
+        logp_mean=samples['logp'][n_burn:].mean(),
+        n_iter=n_iter, n_burnin=n_burn)
+    print('config 2 (scaled) summary written, mean n_cg',
+          info['_reg_coef_sampling_info']['n_cg_iter'].mean(),
+          'gscale mean', samples['global_scale'][n_burn:].mean())
+
+
 if __name__ == '__main__':
     golden_chain('linear', 'dense')
     golden_chain('logit', 'sparse')
     operator_cases()
     mixed_logit_initcoef()
     config1_summary()
+    config2_small_summary()

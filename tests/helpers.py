@@ -30,3 +30,28 @@ def cg_inputs(n, P, n_unshrunk=1, seed=0, flat_intercept=True):
     return dict(obs_prec=omega, prior_prec_sqrt=phi, z=z, coef_cg_init=x0,
                 coef_scaled_sd=sd, randn_n=eta1, randn_P=eta2,
                 n_unshrunk=n_unshrunk)
+
+
+def config2_small_problem(golden_dir):
+    """The scaled-down BASELINE config 2 problem of
+    tests/golden/chain_logit_binary_20000x1000_summary.npz, regenerated without
+    the reference (bayesbridge_amd.simulate replays the reference's RNG calls)
+    and checked against the checksums stored in the fixture."""
+    import os
+    from bayesbridge_amd import simulate
+    g = np.load(os.path.join(golden_dir,
+                             'chain_logit_binary_20000x1000_summary.npz'))
+    n, p = (int(v) for v in g['shape'])
+    X = simulate.simulate_design_csr(n, p, binary_frac=1.,
+                                     binary_pred_freq=float(g['freq']),
+                                     seed=111)
+    assert X.nnz == int(g['nnz'])
+    assert np.array_equal(X.indptr[-4:], g['indptr_tail'])
+    chk = (X.indices.astype(np.int64) * (np.arange(X.nnz) % 1009 + 1)).sum()
+    assert chk == int(g['indices_checksum'])
+    beta = simulate.demo_beta(p)
+    n_success, n_trial = simulate.simulate_outcome(X, beta, 'logit', seed=1)
+    assert n_success.sum() == g['n_success_sum']
+    assert np.array_equal(n_success[:32], g['n_success_head'])
+    assert np.array_equal(n_trial[:32], g['n_trial_head'])
+    return g, X, (n_success, n_trial)

@@ -168,3 +168,50 @@ def test_reference_rng_resume_equals_straight_run(golden_dir):
     assert merged['coef'].shape == (51, 10)
     assert np.allclose(merged['coef'], full['coef'], atol=1e-12)
     assert info2['n_iter'] == 10
+
+
+def test_config2_scaled_exact_seed_and_device_rng(golden_dir):
+    """BASELINE config 2 scaled down (20000 x 1000 value-free binary CSR,
+    logit, demo prior; fixture from the reference, design regenerated here):
+    (1) on the reference's random streams the HIP chain reproduces the
+    reference's first 10 samples through the LDS-tiled value-free layout
+    (atol 1e-5, tests/gpu_tests/test_gibbs.py:44);
+    (2) the device-RNG chain (Philox streams) has the same posterior: means of
+    the signal coefficients and of log tau over iterations 100..400 agree with
+    the reference's within Monte-Carlo error."""
+    from helpers import config2_small_problem
+    g, X, outcome = config2_small_problem(golden_dir)
+    kw = dict(bridge_exponent=.5, regularizing_slab_size=2.)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bridge = _bridge(outcome, X, 'logit', **kw)
+        assert bridge.model.design.storage_format == 'tiled'
+        s, info = bridge.gibbs(10, 0, init={'global_scale': .01},
+                               coef_sampler_type='cg', seed=111,
+                               options={'rng': 'reference'})
+    assert np.allclose(s['coef'], g['coef_first10'], atol=1e-5)
+    assert np.allclose(s['global_scale'], g['global_scale_first10'], rtol=1e-5)
+    assert np.allclose(s['logp'], g['logp_first10'], rtol=1e-6)
+    n_cg = info['_reg_coef_sampling_info']['n_cg_iter']
+    assert np.abs(n_cg - g['n_cg_iter'][:10]).max() <= 2
+
+    n_iter, burn = int(g['n_iter']), int(g['n_burnin'])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        d, dinfo = _bridge(outcome, X, 'logit', **kw).gibbs(
+            n_iter, n_burnin=burn, init={'global_scale': .01},
+            coef_sampler_type='cg', seed=7)
+    mean_d = d['coef'].mean(axis=1)
+    mean_r, sd_r = g['coef_mean'], g['coef_sd']
+    big = np.abs(mean_r) > .2          # 8 of the 15 true signals are found
+    assert 5 <= big.sum() <= 40
+    # 300 autocorrelated draws on each side: allow 0.6 posterior sd
+    assert np.all(np.abs(mean_d - mean_r)[big] < .6 * sd_r[big] + .02)
+    # the bulk of the coefficients is shrunk to ~0 in both chains
+    assert np.abs(mean_d[~big]).max() < .35
+    assert np.corrcoef(mean_d, mean_r)[0, 1] > .9
+    lg = np.log(d['global_scale'])
+    ref_lg_sd = g['global_scale_sd'] / g['global_scale_mean']
+    assert abs(lg.mean() - np.log(g['global_scale_mean'])) < ref_lg_sd + .1
+    m_cg = dinfo['_reg_coef_sampling_info']['n_cg_iter'].mean()
+    assert abs(m_cg - g['n_cg_iter'][burn:].mean()) < 5

@@ -95,6 +95,22 @@ def test_chain_mixed_logit_initcoef(golden_dir):
     assert np.allclose(res['coef'], g['coef_samples'], atol=1e-5)
 
 
+def test_chain_config2_scaled_binary_logit(golden_dir):
+    """BASELINE config 2 scaled down (20000 x 1000 binary CSR, logit, demo
+    prior): the oracle on the regenerated design reproduces the reference's
+    first 10 samples."""
+    from helpers import config2_small_problem
+    g, X, outcome = config2_small_problem(golden_dir)
+    chain = OracleGibbs(outcome, X, 'logit', bridge_exponent=.5,
+                        regularizing_slab_size=2.)
+    res = chain.gibbs(10, seed=111, init={'global_scale': .01})
+    assert np.abs(res['n_cg_iter'] - g['n_cg_iter'][:10]).max() <= 2
+    assert np.allclose(res['coef'], g['coef_first10'], atol=1e-5)
+    assert np.allclose(res['global_scale'], g['global_scale_first10'],
+                       rtol=1e-6)
+    assert np.allclose(res['logp'], g['logp_first10'], rtol=1e-6)
+
+
 def test_scipy_style_cg_equals_scipy():
     import scipy.sparse.linalg as spla
     rng = np.random.default_rng(3)
