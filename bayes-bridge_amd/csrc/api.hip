@@ -308,6 +308,9 @@ static int create_csr_common(int64_t n, int64_t p, int64_t nnz,
                         kind));
     else
       BBX_HIP(hipMemset(h->offset.ptr, 0, sizeof(double) * (size_t)p));
+    // h->stream is non-blocking: the copies and memsets above ran on the null
+    // stream and, for device input, are asynchronous with respect to the host
+    BBX_HIP(hipDeviceSynchronize());
     BBX_TRY(finish_csr(h, format));  // validates the structure first
     return BBX_OK;
   };

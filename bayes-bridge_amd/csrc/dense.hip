@@ -273,6 +273,9 @@ static int create_dense_common(int64_t n, int64_t p, const void* X,
         off = d_off.as<double>();
       }
     }
+    // h->stream is non-blocking: wait for the null-stream memsets/copies above
+    // (and for whatever produced a device-resident X) before reading them
+    BBX_HIP(hipDeviceSynchronize());
     const dim3 grid(4096), block(256);
     if (in_dtype == BBX_F32 && storage_dtype == BBX_F32)
       hipLaunchKernelGGL((dense_ingest_kernel<float, float>), grid, block, 0,

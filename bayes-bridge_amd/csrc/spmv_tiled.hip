@@ -38,6 +38,12 @@
 
 #include "common.hpp"
 
+// -DBBX_TILED_INSTRUMENT=1 compiles the per-wave phase timers in (they cost
+// ~8 SGPRs, which the production kernel has no room for); BBX_TILED_DEBUG=N
+// then prints the breakdown of launches N and N+1.
+#ifndef BBX_TILED_INSTRUMENT
+#define BBX_TILED_INSTRUMENT 0
+#endif
 #ifndef BBX_RING_BIN
 #define BBX_RING_BIN 4  // register-ring depth of the value-free kernel
 #endif
@@ -104,6 +110,7 @@ struct TiledMatrix {
   DevMem vals;       // double[n_quad * 64 * 8] when has_vals
   DevMem descs;      // BatchDesc[n_desc]: per-wave schedules
   DevMem wave_desc;  // int32[n_panel * G * 16]: first descriptor of each wave
+  int desc_stride = 0;  // > 0: wave k's schedule starts at k * desc_stride
   int64_t n_desc = 0;
   DevMem rowids;     // uint32[n_slice * 64]: panel-local rows A | B << 16
   DevMem tiles;      // TileDesc[n_tile]
@@ -189,7 +196,7 @@ constexpr int FILL_UNROLL = (TILE_W_MAX + TILE_THREADS - 1) / TILE_THREADS;
 template <bool VALS>
 __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
     int64_t R, int64_t C, int W, int PR, int G, int blocks_per_group,
-    const int32_t* __restrict__ wave_desc,
+    const int32_t* __restrict__ wave_desc, int desc_stride,
     const BatchDesc* __restrict__ descs, const uint32_t* __restrict__ rowids,
     const uint4* __restrict__ ids, const double* __restrict__ vals,
     const double* __restrict__ x,
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
     double* __restrict__ slab, int n_acc,
     const int32_t* __restrict__ panel_fold, const FoldDesc* __restrict__ folds,
     double* __restrict__ out_sum_part, int ablate,
-    unsigned long long* __restrict__ dbg) {
+    unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* xs = lds;               // W + 8 doubles; xs[W] == 0 (padding target)
   double* acc = lds + (W + 8);    // n_acc = PR + extra doubles
@@ -235,7 +242,11 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
   // Issue cursor.  The wave's descriptors are fetched 64 at a time (one per
   // lane) and read back with v_readlane, so that no memory latency sits
   // between two ISSUE steps; the next block of 64 is prefetched.
-  int blk = wave_desc[blockIdx.x * TILE_WAVES + wave];
+  // With equal-stride schedules the first descriptor block needs no lookup
+  // (one dependent memory round trip less before the first stream load).
+  int blk = desc_stride > 0
+                ? (int)(blockIdx.x * TILE_WAVES + wave) * desc_stride
+                : wave_desc[blockIdx.x * TILE_WAVES + wave];
   int pos = 0;
   const uint4* __restrict__ desc4 = reinterpret_cast<const uint4*>(descs);
   uint4 dcur = desc4[blk + lane];
@@ -251,6 +262,7 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
   // end of the stream loop, end of the kernel); dbg is null in production.
   // 32-bit tick counts (durations only: s_memtime bases differ across XCDs)
   unsigned t_start = 0, t_switch = 0, t_loop = 0, t_skew = 0;
+  if (!BBX_TILED_INSTRUMENT) dbg = nullptr;  // folds every timer away
 
   if (dbg) t_start = (unsigned)__builtin_amdgcn_s_memtime();
 
@@ -336,7 +348,8 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
               const int j = tid + u * TILE_THREADS;
               fv[u] = (j < cols_here && !(ablate & 2)) ? x[col0 + j] : 0.;
             }
-            __syncthreads();  // every wave is done with the previous slice
+            if (!(ablate & 4))
+              __syncthreads();  // every wave is done with the previous slice
             if (dbg) t_skew += (unsigned)__builtin_amdgcn_s_memtime() - t_sw0;
             // one explicit wait for the slice values on every path, so that no
             // compiler-visible load is left "maybe pending" inside the loop
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
               const int j = tid + u * TILE_THREADS;
               if (j < W) xs[j] = fv[u];
             }
-            __syncthreads();
+            if (!(ablate & 4)) __syncthreads();
             if (dbg) t_switch += (unsigned)__builtin_amdgcn_s_memtime() - t_sw0;
           }
           const int cntk = (int)(inf & 15u);
@@ -1011,6 +1024,33 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
     return fail(BBX_ERR_INVALID, "matrix too large for the tiled format");
   if (tot_slices * WAVE >= ((size_t)1 << 31) || tot_descs >= ((size_t)1 << 31))
     return fail(BBX_ERR_INVALID, "matrix too large for the tiled format");
+  {  // equal-stride schedules when the padding stays small
+    const size_t n_wave = wave_desc.size();
+    size_t max_len = 0;
+    for (size_t k = 0; k < n_wave; ++k) {
+      const size_t end = (k + 1 < n_wave) ? (size_t)wave_desc[k + 1] : tot_descs;
+      max_len = std::max(max_len, end - (size_t)wave_desc[k]);
+    }
+    const size_t stride = (max_len + WAVE - 1) / WAVE * WAVE;
+    m.desc_stride = 0;
+    if (n_wave > 0 && stride > 0 && n_wave * stride <= 2 * tot_descs + 65536 &&
+        n_wave * stride < ((size_t)1 << 31)) {
+      BatchDesc endd;
+      endd.quad0 = 0;
+      endd.row_slot = 0;
+      endd.info = BD_END;
+      endd.pad = 0;
+      std::vector<BatchDesc> padded(n_wave * stride, endd);
+      for (size_t k = 0; k < n_wave; ++k) {
+        const size_t b = (size_t)wave_desc[k];
+        const size_t end = (k + 1 < n_wave) ? (size_t)wave_desc[k + 1] : tot_descs;
+        std::copy(descs.begin() + b, descs.begin() + end,
+                  padded.begin() + k * stride);
+      }
+      descs.swap(padded);
+      m.desc_stride = (int)stride;
+    }
+  }
   {  // the kernel prefetches descriptors in blocks of 64: keep reads in bounds
     BatchDesc endd;
     endd.quad0 = 0;
@@ -1106,7 +1146,9 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
   static int dbg_count = 0;
   static unsigned long long* dbg_buf = nullptr;
   unsigned long long* dbg = nullptr;
-  if (dbg_at >= 0) {
+  if (dbg_at >= 0 && !BBX_TILED_INSTRUMENT)
+    fprintf(stderr, "[bbx] BBX_TILED_DEBUG needs a -DBBX_TILED_INSTRUMENT=1 build\n");
+  if (dbg_at >= 0 && BBX_TILED_INSTRUMENT) {
     if (!dbg_buf)
       BBX_HIP(hipMalloc(&dbg_buf, sizeof(unsigned long long) * 4096 * TILE_WAVES * 4));
     if ((dbg_count == dbg_at || dbg_count == dbg_at + 1) && grid <= 4096)
@@ -1117,7 +1159,8 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
     hipLaunchKernelGGL(tiled_spmv_kernel<true>, dim3(grid), dim3(TILE_THREADS),
                        lb, h->stream, m.R, m.C, m.W, m.PR, m.G,
                        (m.n_block + m.G - 1) / m.G,
-                       m.wave_desc.as<int32_t>(), m.descs.as<BatchDesc>(),
+                       m.wave_desc.as<int32_t>(), m.desc_stride,
+                       m.descs.as<BatchDesc>(),
                        m.rowids.as<uint32_t>(), m.ids.as<uint4>(),
                        m.vals.as<double>(), x, c_part, x0_ptr, rowscale, out,
                        slab, m.PR + m.n_extra, m.panel_fold.as<int32_t>(),
@@ -1126,7 +1169,8 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
     hipLaunchKernelGGL(tiled_spmv_kernel<false>, dim3(grid),
                        dim3(TILE_THREADS), lb, h->stream, m.R, m.C, m.W, m.PR,
                        m.G, (m.n_block + m.G - 1) / m.G,
-                       m.wave_desc.as<int32_t>(), m.descs.as<BatchDesc>(),
+                       m.wave_desc.as<int32_t>(), m.desc_stride,
+                       m.descs.as<BatchDesc>(),
                        m.rowids.as<uint32_t>(), m.ids.as<uint4>(), nullptr, x,
                        c_part, x0_ptr, rowscale, out, slab, m.PR + m.n_extra,
                        m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),

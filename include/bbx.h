@@ -156,7 +156,12 @@ int bbx_design_dot(bbx_design* h, const double* v, double* out);
  *   out = [sum(w) ; X_main^T w - sum(w) * offset].
  */
 int bbx_design_tdot(bbx_design* h, const double* w, double* out);
-/* Device-pointer forms: asynchronous on the handle's stream. */
+/* Device-pointer forms: asynchronous on the handle's stream, which is a
+ * NON-BLOCKING stream (it does not wait for the legacy null stream).  The
+ * caller's buffers must be complete when the call is made (synchronise the
+ * stream that produced them, or launch the producer on bbx_design_stream()),
+ * and d_out is ready after bbx_design_synchronize().  The constructors taking
+ * device pointers synchronise the whole device once before they start. */
 int bbx_design_dot_dev(bbx_design* h, const double* d_v, double* d_out);
 int bbx_design_tdot_dev(bbx_design* h, const double* d_w, double* d_out);
 
