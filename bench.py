@@ -153,6 +153,12 @@ def committed_traffic(design, which, cfg):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line (the JSON result of rank 0): libraries
+    # that write to file descriptor 1 (gloo's connection notes, rocm tools)
+    # are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     from ctypes import byref, c_double, c_int64, c_void_p
@@ -336,7 +342,8 @@ def main():
                 torch, prob, state, args.cpu_baseline_iters, args.seed)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     lib.bbx_chain_destroy(chain)
     if world > 1:
         import torch.distributed as dist
