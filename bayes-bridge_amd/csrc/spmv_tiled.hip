@@ -695,6 +695,33 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
       static const char* t_env = getenv("BBX_TILED_TFACTOR");
       if (t_env) t_factor = atof(t_env);
       t_min = std::max<int>(t_min, (int)(t_factor * mean_seg));
+      // Small tiles: with fewer than ~1.5 slices per wave most of the 16
+      // waves of the workgroup have nothing to stream (100k x 10k: 4 slices
+      // per tile, busiest wave at 4-11x the ideal load).  There the split
+      // threshold is lowered until every tile has ~2 slices per wave; the
+      // chunks cost extra accumulators, which small panels have room for.
+      int64_t densest_rows = 0, densest_entries = 0;
+      for (int cb = 0; cb < n_block; ++cb) {
+        int64_t rows_cb = 0, ent_cb = 0;
+        for (int r = 0; r < rows_here; ++r) {
+          const int32_t v = seg_len[(size_t)cb * rows_here + r];
+          if (v > 0) {
+            ++rows_cb;
+            ent_cb += v;
+          }
+        }
+        if (ent_cb > densest_entries) {
+          densest_entries = ent_cb;
+          densest_rows = rows_cb;
+        }
+      }
+      const int64_t want_rows = 2 * TILE_WAVES * SLICE_ROWS;
+      if (densest_rows < (3 * TILE_WAVES * SLICE_ROWS) / 2 && !t_env) {
+        int t_par = (int)((densest_entries + want_rows - 1) / want_rows);
+        t_par = (t_par + 3) / 4 * 4;
+        if (t_par < 8) t_par = 8;
+        if (t_par < t_min) t_min = t_par;
+      }
     }
     if (extra_budget > 0 && longest > t_min) {
       int lo = t_min, hi = longest;  // extras_for(hi) == 0
@@ -889,7 +916,7 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
   // extra accumulators of split rows (2 KB stay free for static LDS).
   int extra_budget =
       (int)((TILE_LDS_BYTES - 2048) / 8) - (m.W + 8) - m.PR;
-  if (extra_budget > 2048) extra_budget = 2048;
+  if (extra_budget > 8192) extra_budget = 8192;
   if (extra_budget < 0) extra_budget = 0;
   if (const char* e = getenv("BBX_TILED_EXTRA")) extra_budget = atoi(e);
 
