@@ -406,6 +406,25 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
 #undef BBX_ISSUE
 #undef BBX_WAIT
   if (dbg) t_loop = (unsigned)__builtin_amdgcn_s_memtime() - t_start;
+  // Everything the epilogue reads from memory and that does not depend on the
+  // accumulators is requested NOW, before the wave joins the final barrier:
+  // the round trip (the row scale is an HBM-resident n-vector) overlaps the
+  // wait for the slowest wave instead of following it.
+  constexpr int EPI_UNROLL = TILE_PR_MAX / TILE_THREADS;
+  double rs_pre[EPI_UNROLL];
+  double cp_pre[NPART / WAVE];
+  double x0_pre = 0.;
+  if (out) {
+#pragma unroll
+    for (int u = 0; u < EPI_UNROLL; ++u) {
+      const int r = tid + u * TILE_THREADS;
+      rs_pre[u] = (rowscale && r < rows_here) ? rowscale[row0 + r] : 1.;
+    }
+#pragma unroll
+    for (int k = 0; k < NPART / WAVE; ++k)
+      cp_pre[k] = c_part ? c_part[lane + k * WAVE] : 0.;
+    if (x0_ptr) x0_pre = *x0_ptr;
+  }
   __syncthreads();
   {  // fold the chunk accumulators of split rows, fixed order
     const int f0 = panel_fold[panel], f1 = panel_fold[panel + 1];
@@ -423,20 +442,24 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
       double cs = 0.;
       if (c_part) {
 #pragma unroll
-        for (int k = 0; k < NPART / WAVE; ++k) cs += c_part[tid + k * WAVE];
+        for (int k = 0; k < NPART / WAVE; ++k) cs += cp_pre[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) cs += __shfl_down(cs, off, WAVE);
       }
-      if (tid == 0) xs[0] = (x0_ptr ? *x0_ptr : 0.) - cs;
+      if (tid == 0) xs[0] = x0_pre - cs;
     }
     __syncthreads();
     const double c = xs[0];
     double tsum = 0.;
-    for (int r = tid; r < rows_here; r += TILE_THREADS) {
-      double v = c + acc[r];
-      if (rowscale) v *= rowscale[row0 + r];
-      out[row0 + r] = v;
-      tsum += v;
+#pragma unroll
+    for (int u = 0; u < EPI_UNROLL; ++u) {
+      const int r = tid + u * TILE_THREADS;
+      if (r < rows_here) {
+        double v = c + acc[r];
+        if (rowscale) v *= rs_pre[u];
+        out[row0 + r] = v;
+        tsum += v;
+      }
     }
     if (out_sum_part) {
       // partial sum of this panel's outputs (feeds the intercept / centring

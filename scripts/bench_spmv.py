@@ -17,7 +17,11 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "config2"
 storage = sys.argv[2] if len(sys.argv) > 2 else "csr"
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 n, p, f = {"config2": (100000, 10000, .01),
-           "config3": (1000000, 50000, .002)}[cfg]
+           "config3": (1000000, 50000, .002),
+           # same tiles as config3, twice as many per workgroup (marginal
+           # cost of a tile vs per-launch fixed cost)
+           "wide": (1000000, 100000, .002),
+           "tall": (2000000, 50000, .002)}[cfg]
 t0 = time.time()
 indptr, indices = simulate.simulate_binary_csr_device(n, p, f, seed=111)
 torch.cuda.synchronize()
