@@ -258,6 +258,10 @@ def main():
     # ~10% of the iteration; DESIGN.md "Measurement")
     design.set_timing(True, every=16)
     design.reset_timing()
+    if world > 1:
+        # part of the warm-up: the first gather of a process group sets up the
+        # point-to-point connections (RCCL does that lazily, 100s of ms)
+        chains.gather_chain_samples(d_coef, dst=0)
     chains.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
