@@ -71,6 +71,7 @@ constexpr int TILE_WG_PER_ROUND = 256 * TILE_WG_PER_CU;
 constexpr int TILE_WAVES = TILE_THREADS / WAVE;
 constexpr uint16_t NO_ROW = 0xFFFF;
 
+// Set-up only (the kernel derives the column block arithmetically).
 struct TileDesc {
   int32_t col_block;
   int32_t slice_begin;
@@ -113,8 +114,6 @@ struct TiledMatrix {
   int desc_stride = 0;  // > 0: wave k's schedule starts at k * desc_stride
   int64_t n_desc = 0;
   DevMem rowids;     // uint32[n_slice * 64]: panel-local rows A | B << 16
-  DevMem tiles;      // TileDesc[n_tile]
-  DevMem wg_tiles;   // int32[n_panel * G + 1]
   DevMem folds;      // FoldDesc[n_fold]
   DevMem panel_fold; // int32[n_panel + 1]
   int n_extra = 0;   // extra accumulators per panel (row splitting)
@@ -122,8 +121,7 @@ struct TiledMatrix {
   DevMem slab;       // double[G * R] partial sums when G > 1 (or Tdot)
   int64_t stream_bytes() const {
     return (int64_t)n_quad * 64 * 16 * (has_vals ? 5 : 1) +
-           (int64_t)n_slice * 256 + (int64_t)n_desc * (int64_t)sizeof(BatchDesc) +
-           (int64_t)n_tile * (int64_t)sizeof(TileDesc);
+           (int64_t)n_slice * 256 + (int64_t)n_desc * (int64_t)sizeof(BatchDesc);
   }
 };
 
@@ -1003,13 +1001,11 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
   std::vector<BatchDesc> descs(tot_descs);
   std::vector<int32_t> wave_desc((size_t)m.n_panel * m.G * TILE_WAVES, 0);
   std::vector<uint32_t> rowids(tot_slices * WAVE);
-  std::vector<TileDesc> tiles(tot_tiles);
-  std::vector<int32_t> wg_tiles((size_t)m.n_panel * m.G + 1, 0);
   std::vector<FoldDesc> folds;
   std::vector<int32_t> panel_fold((size_t)m.n_panel + 1, 0);
   m.n_extra = 0;
   m.split_T = 0;
-  size_t id_off = 0, sl_off = 0, ti_off = 0, de_off = 0;
+  size_t id_off = 0, sl_off = 0, de_off = 0;
   for (int p = 0; p < m.n_panel; ++p) {
     PanelBuild& pb = pbs[(size_t)p];
     panel_fold[(size_t)p] = (int32_t)folds.size();
@@ -1039,25 +1035,12 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
     if (!pb.rowids.empty())
       memcpy(&rowids[sl_off * WAVE], pb.rowids.data(),
              pb.rowids.size() * sizeof(uint32_t));
-    for (size_t t = 0; t < pb.tiles.size(); ++t) {
-      TileDesc td = pb.tiles[t];
-      td.slice_begin += (int32_t)sl_off;
-      td.slice_end += (int32_t)sl_off;
-      tiles[ti_off + t] = td;
-    }
-    int32_t run = (int32_t)ti_off;
-    for (int g = 0; g < m.G; ++g) {
-      wg_tiles[(size_t)p * m.G + g] = run;
-      run += pb.group_tile_count[(size_t)g];
-    }
     id_off += pb.ids.size();
     sl_off += pb.slices.size();
-    ti_off += pb.tiles.size();
     de_off += pb.descs.size();
     std::vector<uint4>().swap(pb.ids);
     std::vector<double>().swap(pb.vals);
   }
-  wg_tiles[(size_t)m.n_panel * m.G] = (int32_t)ti_off;
   panel_fold[(size_t)m.n_panel] = (int32_t)folds.size();
   BBX_TRY(upload(m.folds, folds.data(), folds.size() * sizeof(FoldDesc)));
   BBX_TRY(upload(m.panel_fold, panel_fold.data(),
@@ -1113,9 +1096,6 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
   BBX_TRY(upload(m.wave_desc, wave_desc.data(),
                  wave_desc.size() * sizeof(int32_t)));
   BBX_TRY(upload(m.rowids, rowids.data(), rowids.size() * sizeof(uint32_t)));
-  BBX_TRY(upload(m.tiles, tiles.data(), tiles.size() * sizeof(TileDesc)));
-  BBX_TRY(upload(m.wg_tiles, wg_tiles.data(),
-                 wg_tiles.size() * sizeof(int32_t)));
   BBX_TRY(m.slab.alloc(sizeof(double) * (size_t)m.G * (size_t)R));
   return BBX_OK;
 }
