@@ -64,14 +64,19 @@ int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,
 static int apply_operator(bbx_design* h, const double* d_omega,
                           const double* sp, const double* x, const double* s,
                           const double* d, double* q) {
-  double* t = h->w_n[0].as<double>();
-  BBX_TRY(launch_dot(h, sp, d_omega, t, part_slot(h, PS_SUMW)));
   TdotEpilogue ep;
   ep.mode = TD_OPER;
   ep.s = s;
   ep.d = d;
   ep.x = x;
   ep.dot_part = part_slot(h, PS_PQ);
+  if (!h->sparse) {
+    // f32 dense designs: both products in one pass over the matrix
+    const int st = launch_operator_dense_fused(h, sp, d_omega, ep, q);
+    if (st <= 0) return st;
+  }
+  double* t = h->w_n[0].as<double>();
+  BBX_TRY(launch_dot(h, sp, d_omega, t, part_slot(h, PS_SUMW)));
   BBX_TRY(launch_tdot(h, t, part_slot(h, PS_SUMW), ep, q));
   return BBX_OK;
 }

@@ -108,6 +108,8 @@ struct bbx_design {
   bbx::DevMem dense;  // row-major n x dense_ld (intercept column included,
                       // centred, zero padded), f32 or f64
   bbx::DevMem dense_slab;  // Tdot partial sums [dense_chunks][dense_ld]
+  bbx::DevMem dense_fused_slab;  // fused operator: [workgroups][dense_ld]
+  int dense_fused_wgs = 0;
   int64_t dense_ld = 0;
   int dense_chunks = 1;
 
@@ -215,7 +217,14 @@ int launch_tdot_finalize(bbx_design* h, const double* d_gfull, int n_slab,
                          const double* d_sumw_part, const TdotEpilogue& ep,
                          double* d_out);
 int launch_tdot_finalize_dense(bbx_design* h, const TdotEpilogue& ep,
-                               double* d_out);
+                               double* d_out, const double* d_slab = nullptr,
+                               int n_slab = 0);
+// Dense designs stored in f32 with <= 8192 padded columns: one pass over the
+// matrix computes  out = epilogue(X^T (rowscale .* (X v)))  (dense.hip).
+// Returns 1 when the fused path does not apply (caller runs the two passes).
+int launch_operator_dense_fused(bbx_design* h, const double* d_v,
+                                const double* d_rowscale,
+                                const TdotEpilogue& ep, double* d_out);
 int build_tiled(bbx_design* h);
 void destroy_tiled(bbx_design* h);
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,

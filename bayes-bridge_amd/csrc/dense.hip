@@ -124,6 +124,150 @@ __global__ __launch_bounds__(256) void dense_tdot_kernel(
   dst[3] = a3;
 }
 
+// ---- one pass over X for  g = X^T (rowscale .* (X v))  (f32 storage) -------
+//
+// A CG iteration on a dense design reads the matrix twice (dot, then Tdot):
+// 2 x 6.4 GB at 200k x 8k.  Here a 1024-thread workgroup owns a contiguous
+// range of rows and walks it RB rows at a time.  A thread owns KQ groups of 4
+// adjacent columns (its slice of v and of the result stays in registers); the
+// RB x 4 KQ matrix entries it loaded stay in registers between the two
+// products:
+//   p_i = <X[i, own cols], v[own cols]>       lane-private
+//   t_i = sum over the 1024 threads of p_i     shuffles, LDS, ONE barrier
+//   g[own cols] += X[i, own cols] * (rowscale_i * t_i)
+// and the next RB rows are requested before the reduction starts, so HBM keeps
+// streaming through the barrier.  Per-workgroup results go to slabs that the
+// common Tdot epilogue adds in workgroup order (fixed order, no atomics).
+template <int KQ, int RB>
+__global__ __launch_bounds__(1024) void dense_fused_kernel(
+    int64_t n, int64_t P, int64_t ld, int64_t rows_per_wg,
+    const float* __restrict__ X, const double* __restrict__ v,
+    const double* __restrict__ rowscale, double* __restrict__ slab) {
+  __shared__ double red[2][RB][1024 / WAVE];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+  const int64_t ldq = ld / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = (r0 + rows_per_wg < n) ? r0 + rows_per_wg : n;
+  double4 vo[KQ], g[KQ];
+  bool has[KQ];
+#pragma unroll
+  for (int k = 0; k < KQ; ++k) {
+    const int64_t q = tid + 1024 * k;
+    has[k] = q < ldq;
+    vo[k] = make_double4(0., 0., 0., 0.);
+    g[k] = make_double4(0., 0., 0., 0.);
+    if (has[k]) {
+      const int64_t c = q * 4;
+      vo[k].x = (c + 0 < P) ? v[c + 0] : 0.;
+      vo[k].y = (c + 1 < P) ? v[c + 1] : 0.;
+      vo[k].z = (c + 2 < P) ? v[c + 2] : 0.;
+      vo[k].w = (c + 3 < P) ? v[c + 3] : 0.;
+    }
+  }
+  const float4* __restrict__ X4 = reinterpret_cast<const float4*>(X);
+  float4 xc[RB][KQ], xn[RB][KQ];
+  double sc[RB], sn[RB];
+  auto load_block = [&](int64_t r, float4 (&x)[RB][KQ], double (&s)[RB]) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const bool ok = r + i < r1;
+      s[i] = ok ? (rowscale ? rowscale[r + i] : 1.) : 0.;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k)
+        x[i][k] = (ok && has[k]) ? X4[(r + i) * ldq + tid + 1024 * k]
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  load_block(r0, xc, sc);
+  int buf = 0;
+  for (int64_t r = r0; r < r1; r += RB) {
+    load_block(r + RB, xn, sn);  // in flight across the reduction below
+    double p[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      double a0 = 0., a1 = 0.;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) {
+        a0 += (double)xc[i][k].x * vo[k].x + (double)xc[i][k].z * vo[k].z;
+        a1 += (double)xc[i][k].y * vo[k].y + (double)xc[i][k].w * vo[k].w;
+      }
+      p[i] = a0 + a1;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1)
+        p[i] += __shfl_down(p[i], off, WAVE);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) red[buf][i][wave] = p[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      double t = 0.;
+#pragma unroll
+      for (int w = 0; w < 1024 / WAVE; ++w) t += red[buf][i][w];
+      const double wi = sc[i] * t;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) {
+        g[k].x += (double)xc[i][k].x * wi;
+        g[k].y += (double)xc[i][k].y * wi;
+        g[k].z += (double)xc[i][k].z * wi;
+        g[k].w += (double)xc[i][k].w * wi;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      sc[i] = sn[i];
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) xc[i][k] = xn[i][k];
+    }
+    buf ^= 1;  // the next round's partials go to the other buffer: one barrier
+  }
+  double4* __restrict__ dst =
+      reinterpret_cast<double4*>(slab + (int64_t)blockIdx.x * ld);
+#pragma unroll
+  for (int k = 0; k < KQ; ++k)
+    if (has[k]) dst[tid + 1024 * k] = g[k];
+}
+
+int launch_operator_dense_fused(bbx_design* h, const double* d_v,
+                                const double* d_rowscale,
+                                const TdotEpilogue& ep, double* d_out) {
+  static const bool off =
+      getenv("BBX_DENSE_FUSED") && atoi(getenv("BBX_DENSE_FUSED")) == 0;
+  static const int rb_env =
+      getenv("BBX_DENSE_FUSED_RB") ? atoi(getenv("BBX_DENSE_FUSED_RB")) : 2;
+  if (off || h->sparse || h->dense_dtype != BBX_F32 || h->dense_ld > 8192 ||
+      h->n < 4096)
+    return 1;
+  const int wgs = 256;
+  if (h->dense_fused_wgs != wgs) {
+    BBX_TRY(h->dense_fused_slab.alloc(sizeof(double) * (size_t)wgs *
+                                      (size_t)h->dense_ld));
+    h->dense_fused_wgs = wgs;
+  }
+  const int64_t rows_per_wg = (h->n + wgs - 1) / wgs;
+  const bool kq1 = h->dense_ld <= 4096;
+  h->n_dot += 1;
+  h->n_tdot += 1;
+  BBX_TRY(timer_begin(h, 0));
+#define BBX_FUSED_LAUNCH(KQ, RB)                                               \
+  hipLaunchKernelGGL((dense_fused_kernel<KQ, RB>), dim3(wgs), dim3(1024), 0,   \
+                     h->stream, h->n, h->P, h->dense_ld, rows_per_wg,          \
+                     h->dense.as<float>(), d_v, d_rowscale,                    \
+                     h->dense_fused_slab.as<double>())
+  if (kq1) {
+    if (rb_env >= 4) BBX_FUSED_LAUNCH(1, 4); else BBX_FUSED_LAUNCH(1, 2);
+  } else {
+    if (rb_env >= 4) BBX_FUSED_LAUNCH(2, 4); else BBX_FUSED_LAUNCH(2, 2);
+  }
+#undef BBX_FUSED_LAUNCH
+  BBX_TRY(timer_end(h, 0));
+  BBX_HIP(hipGetLastError());
+  return launch_tdot_finalize_dense(h, ep, d_out,
+                                    h->dense_fused_slab.as<double>(), wgs);
+}
+
 // Device copy with centring, intercept column and zero padding:
 //   dst[i, 0] = 1 (intercept), dst[i, a + j] = src[i, j] - offset[j]
 template <typename TIN, typename TOUT>

@@ -294,10 +294,12 @@ int launch_tdot_finalize(bbx_design* h, const double* d_gfull, int n_slab,
 // Dense operator: intercept column and centring are part of the matrix, so the
 // epilogue sees a plain P-column product (intercept 0, offset 0, sum(w) 0).
 int launch_tdot_finalize_dense(bbx_design* h, const TdotEpilogue& ep,
-                               double* d_out) {
+                               double* d_out, const double* d_slab,
+                               int n_slab) {
   hipLaunchKernelGGL(tdot_finalize_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
                      h->stream, h->P, 0, nullptr, nullptr,
-                     h->dense_slab.as<double>(), h->dense_chunks, h->dense_ld,
+                     d_slab ? d_slab : h->dense_slab.as<double>(),
+                     d_slab ? n_slab : h->dense_chunks, h->dense_ld,
                      h->offset.as<double>(), part_slot(h, PS_ZERO), ep.mode,
                      ep.s, ep.d, ep.x, ep.z, ep.phi, ep.eta2, d_out,
                      ep.dot_part);

@@ -152,3 +152,40 @@ print('FUSED_OK', out[1]['n_iter'])
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert 'FUSED_OK' in res.stdout
+
+
+@pytest.mark.parametrize("n,p", [(8192, 200), (4500, 4300)])
+def test_cg_sample_dense_f32_single_pass_operator(n, p):
+    """f32-stored dense designs run the CG operator in ONE pass over the
+    matrix (dense_fused_kernel, one and two column groups per thread).  The
+    matrix is made exactly representable in f32 so that the f64 oracle sees
+    the same numbers."""
+    from bayesbridge_amd import HipCGSampler, HipDenseDesignMatrix
+    rng = np.random.default_rng(n + p)
+    X = rng.standard_normal((n, p)).astype(np.float32).astype(np.float64)
+    inp = cg_inputs(n, p + 1, seed=3)
+    ora = oracle.OracleDenseDesign(X, center_predictor=False,
+                                   add_intercept=True)
+    atol = 10e-6 * np.sqrt(p + 1)
+    c_o, i_o = oracle.cg_sample(
+        ora, inp['obs_prec'], inp['prior_prec_sqrt'], inp['z'],
+        inp['coef_cg_init'], inp['coef_scaled_sd'], inp['n_unshrunk'],
+        inp['randn_n'], inp['randn_P'], 500, atol)
+    hip = HipDenseDesignMatrix(X, center_predictor=False, add_intercept=True,
+                               storage_dtype='float32')
+
+    class _Replay:
+        def __init__(self, vecs): self.vecs = list(vecs)
+        def __call__(self, size): return self.vecs.pop(0)
+    orig = np.random.randn
+    np.random.randn = _Replay([inp['randn_n'], inp['randn_P']])
+    try:
+        c_h, i_h = HipCGSampler(inp['n_unshrunk']).sample(
+            hip, inp['obs_prec'], inp['prior_prec_sqrt'], inp['z'],
+            coef_cg_init=inp['coef_cg_init'], precond_by='prior',
+            coef_scaled_sd=inp['coef_scaled_sd'], maxiter=500, atol=atol)
+    finally:
+        np.random.randn = orig
+    _assert_close(c_h, i_h, c_o, i_o)
+    # matvec counters: the single pass counts as one dot and one Tdot
+    assert hip.get_dot_count()[0] == hip.get_dot_count()[1] - 1
