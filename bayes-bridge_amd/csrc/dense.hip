@@ -138,10 +138,10 @@ __global__ __launch_bounds__(256) void dense_tdot_kernel(
 // and the next RB rows are requested before the reduction starts, so HBM keeps
 // streaming through the barrier.  Per-workgroup results go to slabs that the
 // common Tdot epilogue adds in workgroup order (fixed order, no atomics).
-template <int KQ, int RB>
+template <typename T, int KQ, int RB>
 __global__ __launch_bounds__(1024) void dense_fused_kernel(
     int64_t n, int64_t P, int64_t ld, int64_t rows_per_wg,
-    const float* __restrict__ X, const double* __restrict__ v,
+    const T* __restrict__ X, const double* __restrict__ v,
     const double* __restrict__ rowscale, double* __restrict__ slab) {
   __shared__ double red[2][RB][1024 / WAVE];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
@@ -164,18 +164,22 @@ __global__ __launch_bounds__(1024) void dense_fused_kernel(
       vo[k].w = (c + 3 < P) ? v[c + 3] : 0.;
     }
   }
-  const float4* __restrict__ X4 = reinterpret_cast<const float4*>(X);
-  float4 xc[RB][KQ], xn[RB][KQ];
+  using V4 = typename Vec4<T>::type;
+  const V4* __restrict__ X4 = reinterpret_cast<const V4*>(X);
+  V4 xc[RB][KQ], xn[RB][KQ];
   double sc[RB], sn[RB];
-  auto load_block = [&](int64_t r, float4 (&x)[RB][KQ], double (&s)[RB]) {
+  auto load_block = [&](int64_t r, V4 (&x)[RB][KQ], double (&s)[RB]) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const bool ok = r + i < r1;
       s[i] = ok ? (rowscale ? rowscale[r + i] : 1.) : 0.;
 #pragma unroll
       for (int k = 0; k < KQ; ++k)
-        x[i][k] = (ok && has[k]) ? X4[(r + i) * ldq + tid + 1024 * k]
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && has[k]) {
+          x[i][k] = X4[(r + i) * ldq + tid + 1024 * k];
+        } else {
+          x[i][k].x = x[i][k].y = x[i][k].z = x[i][k].w = (T)0;
+        }
     }
   };
   load_block(r0, xc, sc);
@@ -237,9 +241,9 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
       getenv("BBX_DENSE_FUSED") && atoi(getenv("BBX_DENSE_FUSED")) == 0;
   static const int rb_env =
       getenv("BBX_DENSE_FUSED_RB") ? atoi(getenv("BBX_DENSE_FUSED_RB")) : 2;
-  if (off || h->sparse || h->dense_dtype != BBX_F32 || h->dense_ld > 8192 ||
-      h->n < 4096)
-    return 1;
+  // f64 storage: 8 registers per column group and row, one group per thread
+  const int64_t ld_max = h->dense_dtype == BBX_F32 ? 8192 : 4096;
+  if (off || h->sparse || h->dense_ld > ld_max || h->n < 4096) return 1;
   const int wgs = 256;
   if (h->dense_fused_wgs != wgs) {
     BBX_TRY(h->dense_fused_slab.alloc(sizeof(double) * (size_t)wgs *
@@ -251,15 +255,17 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
   h->n_dot += 1;
   h->n_tdot += 1;
   BBX_TRY(timer_begin(h, 0));
-#define BBX_FUSED_LAUNCH(KQ, RB)                                               \
-  hipLaunchKernelGGL((dense_fused_kernel<KQ, RB>), dim3(wgs), dim3(1024), 0,   \
-                     h->stream, h->n, h->P, h->dense_ld, rows_per_wg,          \
-                     h->dense.as<float>(), d_v, d_rowscale,                    \
+#define BBX_FUSED_LAUNCH(TT, KQ, RB)                                           \
+  hipLaunchKernelGGL((dense_fused_kernel<TT, KQ, RB>), dim3(wgs), dim3(1024),  \
+                     0, h->stream, h->n, h->P, h->dense_ld, rows_per_wg,       \
+                     h->dense.as<TT>(), d_v, d_rowscale,                       \
                      h->dense_fused_slab.as<double>())
-  if (kq1) {
-    if (rb_env >= 4) BBX_FUSED_LAUNCH(1, 4); else BBX_FUSED_LAUNCH(1, 2);
+  if (h->dense_dtype != BBX_F32) {
+    BBX_FUSED_LAUNCH(double, 1, 2);
+  } else if (kq1) {
+    if (rb_env >= 4) BBX_FUSED_LAUNCH(float, 1, 4); else BBX_FUSED_LAUNCH(float, 1, 2);
   } else {
-    if (rb_env >= 4) BBX_FUSED_LAUNCH(2, 4); else BBX_FUSED_LAUNCH(2, 2);
+    BBX_FUSED_LAUNCH(float, 2, 2);
   }
 #undef BBX_FUSED_LAUNCH
   BBX_TRY(timer_end(h, 0));

@@ -154,10 +154,13 @@ print('FUSED_OK', out[1]['n_iter'])
     assert 'FUSED_OK' in res.stdout
 
 
-@pytest.mark.parametrize("n,p", [(8192, 200), (4500, 4300)])
-def test_cg_sample_dense_f32_single_pass_operator(n, p):
-    """f32-stored dense designs run the CG operator in ONE pass over the
-    matrix (dense_fused_kernel, one and two column groups per thread).  The
+@pytest.mark.parametrize("n,p,dtype", [(8192, 200, 'float32'),
+                                       (4500, 4300, 'float32'),
+                                       (6000, 700, 'float64')])
+def test_cg_sample_dense_single_pass_operator(n, p, dtype):
+    """Dense designs (f32 storage up to 8192 columns, f64 up to 4096) run
+    the CG operator in ONE pass over the matrix (dense_fused_kernel, one and
+    two column groups per thread).  The
     matrix is made exactly representable in f32 so that the f64 oracle sees
     the same numbers."""
     from bayesbridge_amd import HipCGSampler, HipDenseDesignMatrix
@@ -172,7 +175,7 @@ def test_cg_sample_dense_f32_single_pass_operator(n, p):
         inp['coef_cg_init'], inp['coef_scaled_sd'], inp['n_unshrunk'],
         inp['randn_n'], inp['randn_P'], 500, atol)
     hip = HipDenseDesignMatrix(X, center_predictor=False, add_intercept=True,
-                               storage_dtype='float32')
+                               storage_dtype=dtype)
 
     class _Replay:
         def __init__(self, vecs): self.vecs = list(vecs)
