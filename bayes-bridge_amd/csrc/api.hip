@@ -55,6 +55,26 @@ int timer_begin(bbx_design* h, int which) {
   return BBX_OK;
 }
 
+int timer_arm(bbx_design* h, int which, hipEvent_t* a, hipEvent_t* b) {
+  *a = nullptr;
+  *b = nullptr;
+  if (!h->timer.enabled) return BBX_OK;
+  h->timer.armed[which] = false;  // no bracket for this launch
+  if ((h->timer.seen[which]++ % h->timer.period) != 0) return BBX_OK;
+  KernelTimer::Pair pr;
+  if (!h->timer.pool.empty()) {
+    pr = h->timer.pool.back();
+    h->timer.pool.pop_back();
+  } else {
+    BBX_HIP(hipEventCreate(&pr.a));
+    BBX_HIP(hipEventCreate(&pr.b));
+  }
+  h->timer.pending[which].push_back(pr);
+  *a = pr.a;
+  *b = pr.b;
+  return BBX_OK;
+}
+
 int timer_end(bbx_design* h, int which) {
   if (!h->timer.enabled || !h->timer.armed[which]) return BBX_OK;
   BBX_HIP(hipEventRecord(h->timer.pending[which].back().b, h->stream));

@@ -237,6 +237,12 @@ int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,
 
 int timer_begin(bbx_design* h, int which);
 int timer_end(bbx_design* h, int which);
+// Single-kernel families: hands out the event pair of this launch (nullptr,
+// nullptr when the launch is not sampled) to be passed to
+// hipExtLaunchKernelGGL, which stamps the KERNEL's own begin and end (what
+// rocprofv3 reports) instead of bracketing the dispatch with two record
+// commands (~3 us more per launch).
+int timer_arm(bbx_design* h, int which, hipEvent_t* a, hipEvent_t* b);
 
 // ---- CG sampler (cg_sampler.hip) -------------------------------------------
 int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,

@@ -36,6 +36,8 @@
 #include <cstring>
 #include <thread>
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 
 // -DBBX_TILED_INSTRUMENT=1 compiles the per-wave phase timers in (they cost
@@ -1254,7 +1256,8 @@ int build_tiled(bbx_design* h) {
 static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                         const double* c_part, const double* x0_ptr,
                         const double* rowscale, double* out, double* slab,
-                        double* out_sum_part) {
+                        double* out_sum_part, hipEvent_t ev_begin = nullptr,
+                        hipEvent_t ev_end = nullptr) {
   const unsigned grid = (unsigned)(m.n_panel * m.G);
   const size_t lb = lds_bytes(m);
   static const int ablate = getenv("BBX_ABLATE") ? atoi(getenv("BBX_ABLATE")) : 0;
@@ -1274,8 +1277,9 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
     ++dbg_count;
   }
 #define BBX_TILED_LAUNCH(VV, PP, VALPTR)                                       \
-  hipLaunchKernelGGL((tiled_spmv_kernel<VV, PP>), dim3(grid),                  \
-                     dim3(TILE_THREADS), lb, h->stream, m.R, m.C, m.W, m.PR,   \
+  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, PP>), dim3(grid),               \
+                     dim3(TILE_THREADS), (unsigned)lb, h->stream, ev_begin,    \
+                     ev_end, 0u, m.R, m.C, m.W, m.PR,                          \
                      m.G, (m.n_block + m.G - 1) / m.G,                         \
                      m.wave_desc.as<int32_t>(), m.desc_stride,                 \
                      m.descs.as<BatchDesc>(), m.rowids.as<uint32_t>(),         \
@@ -1323,23 +1327,25 @@ int launch_dot_tiled(bbx_design* h, const double* d_v,
   const double* x = d_v + h->intercept;
   const double* x0 = h->intercept ? d_v : nullptr;
   if (sum_done) *sum_done = 0;
-  BBX_TRY(timer_begin(h, 0));
   if (m.G == 1) {
     double* fused = nullptr;
     if (d_sum_part && m.n_panel <= NPART) {
       fused = d_sum_part;
       if (sum_done) *sum_done = 1;
     }
-    BBX_TRY(launch_tiled(h, m, x, part_slot(h, PS_C), x0, d_rowscale, d_t,
-                         nullptr, fused));
-  } else {
-    BBX_TRY(launch_tiled(h, m, x, nullptr, nullptr, nullptr, nullptr,
-                         m.slab.as<double>(), nullptr));
-    hipLaunchKernelGGL(tiled_dot_finalize_kernel, dim3(1024), dim3(256), 0,
-                       h->stream, m.R, m.G, m.slab.as<double>(),
-                       part_slot(h, PS_C), x0, d_rowscale, d_t);
-    BBX_HIP(hipGetLastError());
+    hipEvent_t ea, eb;
+    BBX_TRY(timer_arm(h, 0, &ea, &eb));
+    return launch_tiled(h, m, x, part_slot(h, PS_C), x0, d_rowscale, d_t,
+                        nullptr, fused, ea, eb);
   }
+  // G > 1: two kernels in the family, bracketed by a pair of record commands
+  BBX_TRY(timer_begin(h, 0));
+  BBX_TRY(launch_tiled(h, m, x, nullptr, nullptr, nullptr, nullptr,
+                       m.slab.as<double>(), nullptr));
+  hipLaunchKernelGGL(tiled_dot_finalize_kernel, dim3(1024), dim3(256), 0,
+                     h->stream, m.R, m.G, m.slab.as<double>(),
+                     part_slot(h, PS_C), x0, d_rowscale, d_t);
+  BBX_HIP(hipGetLastError());
   BBX_TRY(timer_end(h, 0));
   return BBX_OK;
 }
@@ -1349,10 +1355,10 @@ int launch_tdot_tiled(bbx_design* h, const double* d_w,
                       double* d_out) {
   TiledPair* tp = static_cast<TiledPair*>(h->tiled);
   const TiledMatrix& m = tp->xt;
-  BBX_TRY(timer_begin(h, 1));
+  hipEvent_t ea, eb;
+  BBX_TRY(timer_arm(h, 1, &ea, &eb));
   BBX_TRY(launch_tiled(h, m, d_w, nullptr, nullptr, nullptr, nullptr,
-                       m.slab.as<double>(), nullptr));
-  BBX_TRY(timer_end(h, 1));
+                       m.slab.as<double>(), nullptr, ea, eb));
   // the epilogue kernel adds the G partial slabs in group order
   return launch_tdot_finalize(h, m.slab.as<double>(), m.G, d_sumw_part, ep,
                               d_out);
@@ -1362,10 +1368,10 @@ int launch_tdot_main_tiled(bbx_design* h, const double* d_w,
                            TdotSource* src) {
   TiledPair* tp = static_cast<TiledPair*>(h->tiled);
   const TiledMatrix& m = tp->xt;
-  BBX_TRY(timer_begin(h, 1));
+  hipEvent_t ea, eb;
+  BBX_TRY(timer_arm(h, 1, &ea, &eb));
   BBX_TRY(launch_tiled(h, m, d_w, nullptr, nullptr, nullptr, nullptr,
-                       m.slab.as<double>(), nullptr));
-  BBX_TRY(timer_end(h, 1));
+                       m.slab.as<double>(), nullptr, ea, eb));
   src->gfull = m.slab.as<double>();
   src->n_slab = m.G;
   src->stride = h->p;
