@@ -197,6 +197,19 @@ class HipDesignMatrix():
     def synchronize(self):
         _lib.check(self._lib.bbx_design_synchronize(self._h))
 
+    def toarray(self):
+        """The explicit n x P matrix X~ (abstract_matrix.py:66-68;
+        dense_matrix.py:54-55).  Debugging aid: it is rebuilt column by column
+        from P operator applications, the device never stores it."""
+        n, P = self.shape
+        out = np.empty((n, P))
+        e = np.zeros(P)
+        for j in range(P):
+            e[j] = 1.
+            out[:, j] = self.dot(e)
+            e[j] = 0.
+        return out
+
     def compute_fisher_info(self, weight, diag_only=False):
         raise NotImplementedError(
             "compute_fisher_info belongs to the 'cholesky' sampler, which is "

@@ -55,6 +55,9 @@ def test_sparse_intercept_and_centering_vs_explicit(storage):
     assert np.allclose(hip.dot(v), A.dot(v), atol=REF_ATOL, rtol=REF_RTOL)
     assert np.allclose(hip.Tdot(w), A.T.dot(w), atol=REF_ATOL, rtol=REF_RTOL)
     assert hip.get_dot_count() == (1, 1)
+    # the explicit matrix (the reference's sparse toarray is broken upstream,
+    # sparse_matrix.py:198-202; this one returns what dot() applies)
+    assert np.allclose(hip.toarray(), A, atol=1e-12)
 
 
 @pytest.mark.parametrize("storage", STORAGES)
