@@ -16,6 +16,22 @@
 
 namespace bbx {
 
+// The matrix is read once per product: non-temporal loads keep it from evicting
+// the vectors and slabs the kernels re-read (same idea as the id stream of the
+// tiled layout).
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef double nt_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 stream_load(const float4* p) {
+  const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ double4 stream_load(const double4* p) {
+  const nt_d2* q = reinterpret_cast<const nt_d2*>(p);
+  const nt_d2 a = __builtin_nontemporal_load(q);
+  const nt_d2 b = __builtin_nontemporal_load(q + 1);
+  return make_double4(a.x, a.y, b.x, b.y);
+}
+
 constexpr int DENSE_ROW_CHUNKS = 64;
 
 template <typename T>
@@ -52,8 +68,9 @@ __global__ __launch_bounds__(256) void dense_dot_kernel(
     double a0 = 0., a1 = 0.;
     int64_t q = lane;
     for (; q + 3 * WAVE < nq; q += 4 * WAVE) {
-      const V4 x0 = xr[q], x1 = xr[q + WAVE], x2 = xr[q + 2 * WAVE],
-               x3 = xr[q + 3 * WAVE];
+      const V4 x0 = stream_load(xr + q), x1 = stream_load(xr + q + WAVE),
+               x2 = stream_load(xr + q + 2 * WAVE),
+               x3 = stream_load(xr + q + 3 * WAVE);
       const double4 w0 = v4[q], w1 = v4[q + WAVE], w2 = v4[q + 2 * WAVE],
                     w3 = v4[q + 3 * WAVE];
       a0 += (double)x0.x * w0.x + (double)x0.z * w0.z;
@@ -66,7 +83,7 @@ __global__ __launch_bounds__(256) void dense_dot_kernel(
       a1 += (double)x3.y * w3.y + (double)x3.w * w3.w;
     }
     for (; q < nq; q += WAVE) {
-      const V4 x0 = xr[q];
+      const V4 x0 = stream_load(xr + q);
       const double4 w0 = v4[q];
       a0 += (double)x0.x * w0.x + (double)x0.z * w0.z;
       a1 += (double)x0.y * w0.y + (double)x0.w * w0.w;
@@ -97,8 +114,8 @@ __global__ __launch_bounds__(256) void dense_tdot_kernel(
   const int64_t ldq = ld / 4;
   int64_t i = r0;
   for (; i + 1 < r1; i += 2) {
-    const V4 xa = xq[i * ldq];
-    const V4 xb = xq[(i + 1) * ldq];
+    const V4 xa = stream_load(xq + i * ldq);
+    const V4 xb = stream_load(xq + (i + 1) * ldq);
     const double wa = w[i], wb = w[i + 1];
     a0 += (double)xa.x * wa;
     a1 += (double)xa.y * wa;
@@ -110,7 +127,7 @@ __global__ __launch_bounds__(256) void dense_tdot_kernel(
     a3 += (double)xb.w * wb;
   }
   if (i < r1) {
-    const V4 xa = xq[i * ldq];
+    const V4 xa = stream_load(xq + i * ldq);
     const double wa = w[i];
     a0 += (double)xa.x * wa;
     a1 += (double)xa.y * wa;
@@ -176,7 +193,7 @@ __global__ __launch_bounds__(1024) void dense_fused_kernel(
 #pragma unroll
       for (int k = 0; k < KQ; ++k)
         if (ok && has[k]) {
-          x[i][k] = X4[(r + i) * ldq + tid + 1024 * k];
+          x[i][k] = stream_load(X4 + (r + i) * ldq + tid + 1024 * k);
         } else {
           x[i][k].x = x[i][k].y = x[i][k].z = x[i][k].w = (T)0;
         }
