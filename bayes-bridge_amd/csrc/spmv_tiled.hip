@@ -46,8 +46,14 @@
 #ifndef BBX_TILED_INSTRUMENT
 #define BBX_TILED_INSTRUMENT 0
 #endif
+// Register ring of the value-free kernel: RING slots of BATCH steps each.
+// With non-temporal id loads the kernel is insensitive to the bytes a wave has
+// in flight (even ONE 1 KiB step in flight per wave runs as fast); shallow and
+// fine-grained wins by a little.  Measured at 1M x 50k, X v / X^T w in us:
+// 4x2: 48.6 / 50.8   3x2: 47.6 / 50.0   4x1: 46.8 / 49.5   3x1: 46.7 / 49.3
+// 2x1: 46.7 / 49.7   6x1: 47.4 / 50.1   (100k x 10k Gibbs: 4x2 614, 3x1 675 it/s)
 #ifndef BBX_RING_BIN
-#define BBX_RING_BIN 4  // register-ring depth of the value-free kernel
+#define BBX_RING_BIN 3
 #endif
 
 namespace bbx {
@@ -100,7 +106,10 @@ struct BatchDesc {
 constexpr uint32_t BD_LAST = 1u << 8;
 constexpr uint32_t BD_TILE_FIRST = 1u << 9;
 constexpr uint32_t BD_END = 1u << 10;
-constexpr int BATCH_BIN = 2;   // steps per ring slot, value-free stream
+#ifndef BBX_BATCH_BIN
+#define BBX_BATCH_BIN 1
+#endif
+constexpr int BATCH_BIN = BBX_BATCH_BIN;  // steps per ring slot, value-free
 constexpr int BATCH_VAL = 1;   // steps per ring slot when values are stored
 
 // One orientation (X or X^T) in tiled form, device resident.
@@ -355,10 +364,15 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
                    : "n"(WAIT_COUNT)                                          \
                    : "memory");                                               \
     } else {                                                                  \
-      asm volatile("s_waitcnt vmcnt(%3)"                                      \
-                   : "+v"(e[K][0]), "+v"(e[K][BATCH - 1]), "+v"(rid[K])       \
+      asm volatile("s_waitcnt vmcnt(%2)"                                      \
+                   : "+v"(e[K][0]), "+v"(rid[K])                              \
                    : "n"(WAIT_COUNT)                                          \
                    : "memory");                                               \
+      /* every other register of the slot is tied to a statement AFTER the */ \
+      /* wait (asm volatile statements keep their order), so no use of it  */ \
+      /* can be scheduled above the wait; each operand appears once        */ \
+      _Pragma("unroll") for (int u_ = 1; u_ < BATCH; ++u_)                    \
+          asm volatile("" : "+v"(e[K][u_]));                                  \
     }                                                                         \
   } while (0)
 
@@ -439,9 +453,11 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
                    : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(e[k][0]), "+v"(e[k][BATCH - 1]), "+v"(rid[k])
+                   : "+v"(e[k][0]), "+v"(rid[k])
                    :
                    : "memory");
+#pragma unroll
+      for (int u_ = 1; u_ < BATCH; ++u_) asm volatile("" : "+v"(e[k][u_]));
     }
   }
 #undef BBX_ISSUE
