@@ -157,7 +157,9 @@ int launch_tdot_main(bbx_design* h, const double* d_w,
 
 int design_alloc_work(bbx_design* h) {
   for (auto& m : h->w_n) BBX_TRY(m.alloc(sizeof(double) * (size_t)h->n));
-  for (auto& m : h->w_P) BBX_TRY(m.alloc(sizeof(double) * (size_t)h->P));
+  // (+2: the CG loop shifts its scaled-direction buffer by one element so that
+  // the part after the intercept entry starts on a 16-byte boundary)
+  for (auto& m : h->w_P) BBX_TRY(m.alloc(sizeof(double) * (size_t)(h->P + 2)));
   BBX_TRY(h->part.alloc(sizeof(double) * NPART * PS_COUNT));
   BBX_HIP(hipMemset(h->part.ptr, 0, sizeof(double) * NPART * PS_COUNT));
   BBX_TRY(h->cg_state.alloc(sizeof(CGState)));

@@ -99,7 +99,11 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
   double* r = h->w_P[3].as<double>();
   double* pvec = h->w_P[4].as<double>();
   double* q = h->w_P[5].as<double>();
-  double* sp = h->w_P[6].as<double>();
+  // s.*p is the input of every X~ v inside the loop; the tiled kernel loads
+  // v[intercept:] slice by slice with 16-byte accesses when that address is
+  // 16-byte aligned, so the buffer starts one element in when there is an
+  // intercept entry
+  double* sp = h->w_P[6].as<double>() + (h->intercept ? 1 : 0);
   double* b = h->w_P[7].as<double>();
   CGState* st = h->cg_state.as<CGState>();
 

@@ -240,7 +240,7 @@ __device__ __forceinline__ void asm_load_u32(unsigned& dst, unsigned off,
 
 constexpr int FILL_UNROLL = (TILE_W_MAX + TILE_THREADS - 1) / TILE_THREADS;
 
-template <bool VALS, bool PACK>
+template <bool VALS, bool PACK, bool WIDE>
 __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
     int64_t R, int64_t C, int W, int PR, int G, int blocks_per_group,
     const int32_t* __restrict__ wave_desc, int desc_stride,
@@ -394,11 +394,33 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
             ++cb;
             const int64_t col0 = (int64_t)cb * W;
             const int cols_here = (int)((C - col0 < W) ? (C - col0) : W);
-            double fv[FILL_UNROLL];
+            // The slice moves through the CU's L1 at 64 B/clk (100-127 KB per
+            // switch, ~1 us): 16-byte lane loads where the source is 16-byte
+            // aligned (8-byte accesses reach ~0.6x the rate), pairs of doubles
+            // per thread, otherwise one double per lane and load.
+            constexpr int FILL_PAIRS = (FILL_UNROLL + 1) / 2;
+            v2d fp[FILL_PAIRS];
+            // (WIDE is chosen by the launcher: x and W * 8 are 16-byte aligned)
+            constexpr bool wide = WIDE;
+            if (wide) {
 #pragma unroll
-            for (int u = 0; u < FILL_UNROLL; ++u) {
-              const int j = tid + u * TILE_THREADS;
-              fv[u] = (j < cols_here && !(ablate & 2)) ? x[col0 + j] : 0.;
+              for (int u = 0; u < FILL_PAIRS; ++u) {
+                const int j = 2 * (tid + u * TILE_THREADS);
+                if (j + 1 < cols_here && !(ablate & 2)) {
+                  fp[u] = *reinterpret_cast<const v2d*>(x + col0 + j);
+                } else {
+                  fp[u].x = (j < cols_here && !(ablate & 2)) ? x[col0 + j] : 0.;
+                  fp[u].y = 0.;
+                }
+              }
+            } else {
+#pragma unroll
+              for (int u = 0; u < FILL_PAIRS; ++u) {
+                const int j0 = tid + (2 * u) * TILE_THREADS;
+                const int j1 = tid + (2 * u + 1) * TILE_THREADS;
+                fp[u].x = (j0 < cols_here && !(ablate & 2)) ? x[col0 + j0] : 0.;
+                fp[u].y = (j1 < cols_here && !(ablate & 2)) ? x[col0 + j1] : 0.;
+              }
             }
             if (!(ablate & 4))
               __syncthreads();  // every wave is done with the previous slice
@@ -406,10 +428,20 @@ __global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
             // one explicit wait for the slice values on every path, so that no
             // compiler-visible load is left "maybe pending" inside the loop
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+            if (wide) {
 #pragma unroll
-            for (int u = 0; u < FILL_UNROLL; ++u) {
-              const int j = tid + u * TILE_THREADS;
-              if (j < W) xs[j] = fv[u];
+              for (int u = 0; u < FILL_PAIRS; ++u) {
+                const int j = 2 * (tid + u * TILE_THREADS);
+                if (j < W) *reinterpret_cast<v2d*>(xs + j) = fp[u];  // W even
+              }
+            } else {
+#pragma unroll
+              for (int u = 0; u < FILL_PAIRS; ++u) {
+                const int j0 = tid + (2 * u) * TILE_THREADS;
+                const int j1 = tid + (2 * u + 1) * TILE_THREADS;
+                if (j0 < W) xs[j0] = fp[u].x;
+                if (j1 < W) xs[j1] = fp[u].y;
+              }
             }
             if (!(ablate & 4)) __syncthreads();
             if (dbg) t_switch += (unsigned)__builtin_amdgcn_s_memtime() - t_sw0;
@@ -1266,15 +1298,17 @@ int build_tiled(bbx_design* h) {
     if (lb > (size_t)TILE_LDS_BYTES)
       return fail(BBX_ERR_INVALID, "tile does not fit in LDS");
   }
-  BBX_HIP(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&tiled_spmv_kernel<false, false>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  BBX_HIP(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&tiled_spmv_kernel<false, true>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  BBX_HIP(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&tiled_spmv_kernel<true, false>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define BBX_TILED_ATTR(VV, PP, WW)                                             \
+  BBX_HIP(hipFuncSetAttribute(                                                 \
+      reinterpret_cast<const void*>(&tiled_spmv_kernel<VV, PP, WW>),           \
+      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+  BBX_TILED_ATTR(false, false, false);
+  BBX_TILED_ATTR(false, false, true);
+  BBX_TILED_ATTR(false, true, false);
+  BBX_TILED_ATTR(false, true, true);
+  BBX_TILED_ATTR(true, false, false);
+  BBX_TILED_ATTR(true, false, true);
+#undef BBX_TILED_ATTR
   // The reference-layout arrays are only needed to build; free the big ones.
   if (!getenv("BBX_KEEP_CSR")) {
     h->indices.release();
@@ -1308,8 +1342,8 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
       dbg = dbg_buf;
     ++dbg_count;
   }
-#define BBX_TILED_LAUNCH(VV, PP, VALPTR)                                       \
-  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, PP>), dim3(grid),               \
+#define BBX_TILED_LAUNCH_W(VV, PP, WW, VALPTR)                                 \
+  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, PP, WW>), dim3(grid),           \
                      dim3(TILE_THREADS), (unsigned)lb, h->stream, ev_begin,    \
                      ev_end, 0u, m.R, m.C, m.W, m.PR,                          \
                      m.G, (m.n_block + m.G - 1) / m.G,                         \
@@ -1319,6 +1353,18 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                      out, slab, m.PR + m.n_extra,                              \
                      m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),       \
                      out_sum_part, ablate, dbg)
+#define BBX_TILED_LAUNCH(VV, PP, VALPTR)                                       \
+  do {                                                                         \
+    if (wide) BBX_TILED_LAUNCH_W(VV, PP, true, VALPTR);                        \
+    else BBX_TILED_LAUNCH_W(VV, PP, false, VALPTR);                            \
+  } while (0)
+  // 16-byte slice loads need every slice start 16-byte aligned: W is a multiple
+  // of 64 doubles, so it is the alignment of x itself that decides (inside the
+  // CG loop x is an internal buffer placed accordingly; a caller's v + 1 of a
+  // design with intercept is not, and takes the 8-byte path)
+  static const bool no_wide =
+      getenv("BBX_TILED_NARROW_FILL") && atoi(getenv("BBX_TILED_NARROW_FILL")) == 1;
+  const bool wide = !no_wide && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
   if (m.has_vals)
     BBX_TILED_LAUNCH(true, false, m.vals.as<double>());
   else if (m.packed)
@@ -1326,6 +1372,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
   else
     BBX_TILED_LAUNCH(false, false, nullptr);
 #undef BBX_TILED_LAUNCH
+#undef BBX_TILED_LAUNCH_W
   BBX_HIP(hipGetLastError());
   if (dbg) {
     BBX_HIP(hipStreamSynchronize(h->stream));
