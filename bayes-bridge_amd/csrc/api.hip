@@ -336,7 +336,7 @@ static int create_csr_common(int64_t n, int64_t p, int64_t nnz,
     BBX_TRY(finish_csr(h, format));  // validates the structure first
     return BBX_OK;
   };
-  st = body();
+  st = no_throw(body);
   if (st < 0) {
     bbx_design_destroy(h);
     return st;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void hbm_copy_kernel(
 }
 }  // namespace bbx
 
-int bbx_hbm_probe(int device, int64_t bytes, int reps, double* read_gbps,
+static int bbx_hbm_probe_impl(int device, int64_t bytes, int reps, double* read_gbps,
                   double* copy_gbps) {
   using namespace bbx;
   if (bytes < 4096 || reps < 1 || !read_gbps || !copy_gbps)
@@ -456,6 +456,14 @@ int bbx_hbm_probe(int device, int64_t bytes, int reps, double* read_gbps,
   cleanup();
   return BBX_OK;
 }
+
+int bbx_hbm_probe(int device, int64_t bytes, int reps, double* read_gbps,
+                  double* copy_gbps) {
+  return no_throw([&]() -> int {
+    return bbx_hbm_probe_impl(device, bytes, reps, read_gbps, copy_gbps);
+  });
+}
+
 
 int bbx_design_create_csr(int64_t n, int64_t p, int64_t nnz,
                           const int32_t* indptr, const int32_t* indices,
@@ -579,7 +587,7 @@ int bbx_design_tdot(bbx_design* h, const double* w, double* out) {
   return BBX_OK;
 }
 
-int bbx_cg_sample_dev(bbx_design* h, const double* d_obs_prec,
+static int bbx_cg_sample_dev_impl(bbx_design* h, const double* d_obs_prec,
                       const double* d_prior_prec_sqrt, const double* d_z,
                       const double* d_x0, const double* d_precond_sd,
                       int n_unshrunk, const double* d_randn_n,
@@ -596,7 +604,20 @@ int bbx_cg_sample_dev(bbx_design* h, const double* d_obs_prec,
                           maxiter, atol, d_coef_out, n_iter_out, info_out);
 }
 
-int bbx_cg_sample(bbx_design* h, const double* obs_prec,
+int bbx_cg_sample_dev(bbx_design* h, const double* d_obs_prec,
+                      const double* d_prior_prec_sqrt, const double* d_z,
+                      const double* d_x0, const double* d_precond_sd,
+                      int n_unshrunk, const double* d_randn_n,
+                      const double* d_randn_P, uint64_t seed, int maxiter,
+                      double atol, double* d_coef_out, int* n_iter_out,
+                      int* info_out) {
+  return no_throw([&]() -> int {
+    return bbx_cg_sample_dev_impl(h, d_obs_prec, d_prior_prec_sqrt, d_z, d_x0, d_precond_sd, n_unshrunk, d_randn_n, d_randn_P, seed, maxiter, atol, d_coef_out, n_iter_out, info_out);
+  });
+}
+
+
+static int bbx_cg_sample_impl(bbx_design* h, const double* obs_prec,
                   const double* prior_prec_sqrt, const double* z,
                   const double* x0, const double* precond_sd, int n_unshrunk,
                   const double* randn_n, const double* randn_P, uint64_t seed,
@@ -648,6 +669,18 @@ int bbx_cg_sample(bbx_design* h, const double* obs_prec,
   return st;
 }
 
+int bbx_cg_sample(bbx_design* h, const double* obs_prec,
+                  const double* prior_prec_sqrt, const double* z,
+                  const double* x0, const double* precond_sd, int n_unshrunk,
+                  const double* randn_n, const double* randn_P, uint64_t seed,
+                  int maxiter, double atol, double* coef_out, int* n_iter_out,
+                  int* info_out) {
+  return no_throw([&]() -> int {
+    return bbx_cg_sample_impl(h, obs_prec, prior_prec_sqrt, z, x0, precond_sd, n_unshrunk, randn_n, randn_P, seed, maxiter, atol, coef_out, n_iter_out, info_out);
+  });
+}
+
+
 int bbx_design_matvec_count(const bbx_design* h, int64_t* n_dot,
                             int64_t* n_tdot) {
   BBX_TRY(check_handle(h));
@@ -673,7 +706,7 @@ int bbx_design_set_timing(bbx_design* h, int enabled) {
   return BBX_OK;
 }
 
-int bbx_design_get_timing(bbx_design* h, int which, int64_t* n_launch,
+static int bbx_design_get_timing_impl(bbx_design* h, int which, int64_t* n_launch,
                           double* total_ms) {
   BBX_TRY(check_handle(h));
   if (which < 0 || which > 1) return fail(BBX_ERR_INVALID, "which must be 0/1");
@@ -683,6 +716,14 @@ int bbx_design_get_timing(bbx_design* h, int which, int64_t* n_launch,
   if (total_ms) *total_ms = h->timer.total_ms[which];
   return BBX_OK;
 }
+
+int bbx_design_get_timing(bbx_design* h, int which, int64_t* n_launch,
+                          double* total_ms) {
+  return no_throw([&]() -> int {
+    return bbx_design_get_timing_impl(h, which, n_launch, total_ms);
+  });
+}
+
 
 int bbx_design_reset_timing(bbx_design* h) {
   BBX_TRY(check_handle(h));

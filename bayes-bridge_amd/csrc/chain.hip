@@ -677,7 +677,7 @@ int bbx_chain_create(bbx_design* design, int model, const double* outcome,
     BBX_HIP(hipStreamSynchronize(h->stream));
     return BBX_OK;
   };
-  int st = body();
+  int st = no_throw(body);
   if (st < 0) {
     bbx_chain_destroy(c);
     return st;
@@ -697,7 +697,7 @@ int bbx_chain_destroy(bbx_chain* c) {
   return BBX_OK;
 }
 
-int bbx_chain_set_state(bbx_chain* c, const double* coef,
+static int bbx_chain_set_state_impl(bbx_chain* c, const double* coef,
                         const double* obs_prec, const double* lscale,
                         const double* gscale) {
   BBX_TRY(chain_check(c));
@@ -724,7 +724,16 @@ int bbx_chain_set_state(bbx_chain* c, const double* coef,
   return BBX_OK;
 }
 
-int bbx_chain_get_state(bbx_chain* c, double* coef, double* obs_prec,
+int bbx_chain_set_state(bbx_chain* c, const double* coef,
+                        const double* obs_prec, const double* lscale,
+                        const double* gscale) {
+  return no_throw([&]() -> int {
+    return bbx_chain_set_state_impl(c, coef, obs_prec, lscale, gscale);
+  });
+}
+
+
+static int bbx_chain_get_state_impl(bbx_chain* c, double* coef, double* obs_prec,
                         double* lscale, double* gscale) {
   BBX_TRY(chain_check(c));
   bbx_design* h = c->h;
@@ -749,6 +758,14 @@ int bbx_chain_get_state(bbx_chain* c, double* coef, double* obs_prec,
   if (gscale) *gscale = sc.gscale;
   return BBX_OK;
 }
+
+int bbx_chain_get_state(bbx_chain* c, double* coef, double* obs_prec,
+                        double* lscale, double* gscale) {
+  return no_throw([&]() -> int {
+    return bbx_chain_get_state_impl(c, coef, obs_prec, lscale, gscale);
+  });
+}
+
 
 int bbx_chain_set_summary(bbx_chain* c, const double* mean,
                           const double* square, int64_t n_averaged) {
@@ -812,7 +829,7 @@ int bbx_chain_init_obs_prec(bbx_chain* c) {
   return BBX_OK;
 }
 
-int bbx_chain_run(bbx_chain* c, int n_iter, int n_burnin, int thin,
+static int bbx_chain_run_impl(bbx_chain* c, int n_iter, int n_burnin, int thin,
                   int maxiter, double atol, double* d_coef, double* d_lscale,
                   double* d_obs_prec, double* gscale, double* logp,
                   double* n_cg_iter) {
@@ -874,7 +891,17 @@ int bbx_chain_run(bbx_chain* c, int n_iter, int n_burnin, int thin,
   return n_unconverged;
 }
 
-int bbx_chain_run_host(bbx_chain* c, int n_iter, int n_burnin, int thin,
+int bbx_chain_run(bbx_chain* c, int n_iter, int n_burnin, int thin,
+                  int maxiter, double atol, double* d_coef, double* d_lscale,
+                  double* d_obs_prec, double* gscale, double* logp,
+                  double* n_cg_iter) {
+  return no_throw([&]() -> int {
+    return bbx_chain_run_impl(c, n_iter, n_burnin, thin, maxiter, atol, d_coef, d_lscale, d_obs_prec, gscale, logp, n_cg_iter);
+  });
+}
+
+
+static int bbx_chain_run_host_impl(bbx_chain* c, int n_iter, int n_burnin, int thin,
                        int maxiter, double atol, double* coef, double* lscale,
                        double* obs_prec, double* gscale, double* logp,
                        double* n_cg_iter) {
@@ -913,6 +940,16 @@ int bbx_chain_run_host(bbx_chain* c, int n_iter, int n_burnin, int thin,
   return st;
 }
 
+int bbx_chain_run_host(bbx_chain* c, int n_iter, int n_burnin, int thin,
+                       int maxiter, double atol, double* coef, double* lscale,
+                       double* obs_prec, double* gscale, double* logp,
+                       double* n_cg_iter) {
+  return no_throw([&]() -> int {
+    return bbx_chain_run_host_impl(c, n_iter, n_burnin, thin, maxiter, atol, coef, lscale, obs_prec, gscale, logp, n_cg_iter);
+  });
+}
+
+
 // ---- stand-alone device samplers (distribution tests)
 
 static int dev_sampler_common(int device, int64_t n_draw) {
@@ -926,7 +963,7 @@ static int dev_sampler_common(int device, int64_t n_draw) {
   return BBX_OK;
 }
 
-int bbx_device_polya_gamma(int device, uint64_t seed, int64_t n_draw,
+static int bbx_device_polya_gamma_impl(int device, uint64_t seed, int64_t n_draw,
                            const int32_t* shape, const double* tilt,
                            double* out) {
   BBX_TRY(dev_sampler_common(device, n_draw));
@@ -949,7 +986,16 @@ int bbx_device_polya_gamma(int device, uint64_t seed, int64_t n_draw,
   return BBX_OK;
 }
 
-int bbx_device_tilted_stable(int device, uint64_t seed, int64_t n_draw,
+int bbx_device_polya_gamma(int device, uint64_t seed, int64_t n_draw,
+                           const int32_t* shape, const double* tilt,
+                           double* out) {
+  return no_throw([&]() -> int {
+    return bbx_device_polya_gamma_impl(device, seed, n_draw, shape, tilt, out);
+  });
+}
+
+
+static int bbx_device_tilted_stable_impl(int device, uint64_t seed, int64_t n_draw,
                              double char_exp, const double* tilt,
                              double* out) {
   BBX_TRY(dev_sampler_common(device, n_draw));
@@ -971,7 +1017,16 @@ int bbx_device_tilted_stable(int device, uint64_t seed, int64_t n_draw,
   return BBX_OK;
 }
 
-int bbx_device_gamma(int device, uint64_t seed, int64_t n_draw, double shape,
+int bbx_device_tilted_stable(int device, uint64_t seed, int64_t n_draw,
+                             double char_exp, const double* tilt,
+                             double* out) {
+  return no_throw([&]() -> int {
+    return bbx_device_tilted_stable_impl(device, seed, n_draw, char_exp, tilt, out);
+  });
+}
+
+
+static int bbx_device_gamma_impl(int device, uint64_t seed, int64_t n_draw, double shape,
                      double* out) {
   BBX_TRY(dev_sampler_common(device, n_draw));
   if (n_draw == 0) return BBX_OK;
@@ -985,5 +1040,13 @@ int bbx_device_gamma(int device, uint64_t seed, int64_t n_draw, double shape,
                     hipMemcpyDeviceToHost));
   return BBX_OK;
 }
+
+int bbx_device_gamma(int device, uint64_t seed, int64_t n_draw, double shape,
+                     double* out) {
+  return no_throw([&]() -> int {
+    return bbx_device_gamma_impl(device, seed, n_draw, shape, out);
+  });
+}
+
 
 }  // extern "C"

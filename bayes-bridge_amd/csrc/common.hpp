@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -21,6 +23,29 @@ constexpr int VEC_BLOCK = 256;
 
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
+
+// The C ABI promises "no exceptions across the boundary": host-side set-up code
+// (std::vector, std::thread) runs under this guard.
+template <class F>
+int no_throw(F&& f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    try {
+      return fail(BBX_ERR_INVALID, "out of host memory");
+    } catch (...) {
+      return BBX_ERR_INVALID;
+    }
+  } catch (const std::exception& e) {
+    try {
+      return fail(BBX_ERR_INVALID, std::string("C++ exception: ") + e.what());
+    } catch (...) {
+      return BBX_ERR_INVALID;
+    }
+  } catch (...) {
+    return BBX_ERR_INVALID;
+  }
+}
 
 #define BBX_HIP(expr)                                                          \
   do {                                                                         \

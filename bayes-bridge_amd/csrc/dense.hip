@@ -470,7 +470,7 @@ static int create_dense_common(int64_t n, int64_t p, const void* X,
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return BBX_OK;
   };
-  int st = body();
+  int st = no_throw(body);
   if (st < 0) {
     bbx_design_destroy(h);
     return st;

@@ -1098,13 +1098,20 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
   if (n_thr > 64) n_thr = 64;
   if ((unsigned)m.n_panel < n_thr) n_thr = (unsigned)m.n_panel;
   std::vector<std::thread> pool;
+  std::vector<int> thread_status(n_thr, BBX_OK);
   for (unsigned t = 0; t < n_thr; ++t)
     pool.emplace_back([&, t]() {
-      for (int p = (int)t; p < m.n_panel; p += (int)n_thr)
-        build_panel(R, C, rowptr, colidx, vals, m.W, m.n_block, m.PR, m.G,
-                    extra_budget, p, m.packed, pbs[(size_t)p]);
+      // an exception must not leave a worker thread (std::terminate)
+      thread_status[t] = no_throw([&]() -> int {
+        for (int p = (int)t; p < m.n_panel; p += (int)n_thr)
+          build_panel(R, C, rowptr, colidx, vals, m.W, m.n_block, m.PR, m.G,
+                      extra_budget, p, m.packed, pbs[(size_t)p]);
+        return BBX_OK;
+      });
     });
   for (auto& th : pool) th.join();
+  for (int st_t : thread_status)
+    if (st_t < 0) return fail(BBX_ERR_INVALID, "out of host memory while tiling");
 
   if (getenv("BBX_TILED_STATS")) {
     int64_t crit_max = 0, total = 0, dup = 0, quads = 0, n_wg = 0, crit_sum = 0;
