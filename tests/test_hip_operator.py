@@ -246,3 +246,55 @@ print('QUADS', info['X']['n_quad'], info['Xt']['n_quad'])
     # for occupancy need 2 steps either way, and long gaps open new groups;
     # the layout pays off on big panels)
     assert all(q > 0 for q in quads['0'] + quads['1'])
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_shapes_and_patterns(case):
+    """Randomised shapes against SciPy: one to several column blocks
+    (p around the 16128-column slice width), panels from a handful of rows to
+    several thousand, rows from empty to dense, binary and valued entries,
+    duplicates, with and without intercept / centring."""
+    from bayesbridge_amd import HipSparseDesignMatrix
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.choice([3, 17, 130, 1000, 4097, 9000]))
+    p = int(rng.choice([2, 65, 900, 16128, 16130, 33000, 50000]))
+    density = float(rng.choice([.0005, .004, .03])) if p > 1000 \
+        else float(rng.choice([.02, .2, .7]))
+    nnz = max(1, int(n * p * density))
+    rows = rng.integers(0, n, nnz)
+    # skewed columns: a few hot ones, many rare ones
+    cols = np.minimum((p * rng.random(nnz) ** 3).astype(np.int64), p - 1)
+    binary = bool(case % 2)
+    vals = np.ones(nnz) if binary else rng.standard_normal(nnz)
+    X = sparse.coo_matrix((vals, (rows, cols)), shape=(n, p)).tocsr()
+    if not binary or case % 3 == 0:
+        X.sum_duplicates()
+    else:
+        # keep duplicates as separate stored entries (legal CSR, values add up)
+        order = np.lexsort((cols, rows))
+        indptr = np.zeros(n + 1, dtype=np.int32)
+        np.add.at(indptr, rows + 1, 1)
+        X = sparse.csr_matrix((vals[order], cols[order].astype(np.int32),
+                               np.cumsum(indptr).astype(np.int32)),
+                              shape=(n, p))
+    center, intercept = bool(case & 4), bool(case & 8)
+    from bayesbridge_amd.design_matrix import remove_intercept_indicator
+    Xr = remove_intercept_indicator(X.copy())
+    if Xr.shape[1] == 0:
+        pytest.skip("all columns constant")
+    for storage in STORAGES:
+        hip = HipSparseDesignMatrix(X.copy(), center_predictor=center,
+                                    add_intercept=intercept, storage=storage)
+        nn, P = hip.shape
+        v, w = rng.standard_normal(P), rng.standard_normal(nn)
+        off = np.asarray(Xr.mean(axis=0)).ravel() if center \
+            else np.zeros(Xr.shape[1])
+        a = 1 if intercept else 0
+        ref_v = (v[0] if intercept else 0.) + Xr @ v[a:] - off @ v[a:]
+        ref_w = Xr.T @ w - w.sum() * off
+        if intercept:
+            ref_w = np.concatenate(([w.sum()], ref_w))
+        tol_v = 1e-11 * max(1., np.abs(ref_v).max())
+        tol_w = 1e-11 * max(1., np.abs(ref_w).max())
+        assert np.abs(hip.dot(v) - ref_v).max() <= tol_v, (storage, n, p)
+        assert np.abs(hip.Tdot(w) - ref_w).max() <= tol_w, (storage, n, p)
