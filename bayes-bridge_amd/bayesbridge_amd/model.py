@@ -60,30 +60,33 @@ class LinearModel(_Model):
 class LogisticModel(_Model):
 
     def __init__(self, n_success, n_trial, design):
-        n_success = np.asarray(n_success)
-        if n_trial is None:                          # logistic_model.py:10-36
-            if np.max(n_success) > 1:
+        """Outcome checks of logistic_model.py:10-47: counts must line up with
+        the rows of the design, 0 < n_trial, n_success <= n_trial; without
+        n_trial the outcome has to be 0/1."""
+        n_row = design.shape[0]
+        n_success = np.asarray(n_success, dtype=np.float64)
+        binary_default = n_trial is None
+        if binary_default:
+            if n_success.size and n_success.max() > 1:
                 raise ValueError(
-                    "If not binary, the number of trials must be specified.")
-            if not len(n_success) == design.shape[0]:
-                raise ValueError(
-                    "Incompatible sizes of the outcome and design matrix.")
-            n_trial = np.ones(len(n_success))
-            warn("The numbers of trials were not specified. The binary "
-                 "outcome is assumed.")
+                    "n_trial is required when the outcome is not binary.")
+            n_trial = np.ones(n_success.shape)
         else:
-            n_trial = np.asarray(n_trial)
-            if not len(n_trial) == len(n_success) == design.shape[0]:
-                raise ValueError(
-                    "Incompatible sizes of the outcome vectors and design "
-                    "matrix.")
-            if np.any(n_trial <= 0):
-                raise ValueError("Number of trials must be strictly positive.")
-            if np.any(n_success > n_trial):
-                raise ValueError(
-                    "Number of successes cannot be larger than that of trials.")
-        self.n_trial = n_trial.astype('float64')
-        self.n_success = n_success.astype('float64')
+            n_trial = np.asarray(n_trial, dtype=np.float64)
+        if not (n_success.shape == n_trial.shape == (n_row,)):
+            raise ValueError(
+                "Outcome vectors and design matrix have incompatible sizes: "
+                "%s successes, %s trials, %d rows."
+                % (n_success.shape, n_trial.shape, n_row))
+        if not binary_default:
+            if (n_trial <= 0).any():
+                raise ValueError("Every n_trial must be strictly positive.")
+            if (n_success > n_trial).any():
+                raise ValueError("n_success exceeds n_trial in some row.")
+        else:
+            warn("n_trial not given: treating the outcome as binary.")
+        self.n_success = n_success
+        self.n_trial = n_trial
         self.design = design
         self.name = 'logit'
 

@@ -97,3 +97,73 @@ def test_csr_generator_replays_simulate_design(ref):
         A = refsim.simulate_design(400, 50, seed=11, format_='sparse', **kw)
         B = simulate.simulate_design_csr(400, 50, seed=11, **kw)
         assert (A != B).nnz == 0
+
+
+def test_prior_and_logit_validation_equal_reference(ref):
+    """The product's own RegressionCoefPrior / LogisticModel checks against the
+    reference's (prior.py:7-208, logistic_model.py:10-47): same attributes,
+    same get_info, same hyper-parameter solution, same accept/reject."""
+    import warnings
+    from bayesbridge.prior import RegressionCoefPrior as RefPrior
+    from bayesbridge.model.logistic_model import LogisticModel as RefLogit
+    from bayesbridge_amd.model import LogisticModel
+    from bayesbridge_amd.prior import RegressionCoefPrior
+    cases = [
+        dict(),
+        dict(bridge_exponent=.25, regularizing_slab_size=1.,
+             global_scale_prior_hyper_param={'log10_mean': -4., 'log10_sd': 1.}),
+        dict(bridge_exponent=1., n_fixed_effect=3,
+             sd_for_fixed_effect=[1., 2., 3.], sd_for_intercept=2.,
+             global_scale_prior_hyper_param={'log10_mean': -2., 'log10_sd': .5},
+             _global_scale_parametrization='raw'),
+        dict(bridge_exponent=1 / 16, n_fixed_effect=2, sd_for_fixed_effect=4.,
+             global_scale_prior_hyper_param={'log10_mean': -4.,
+                                             'log10_sd': .01}),
+    ]
+    for kw in cases:
+        mine, theirs = RegressionCoefPrior(**kw), RefPrior(**kw)
+        a, b = mine.get_info(), theirs.get_info()
+        assert list(a) == list(b)
+        for key in a:
+            assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), key
+        for hyp in ('shape', 'rate'):
+            x = mine.param['gscale_neg_power'][hyp]
+            y = theirs.param['gscale_neg_power'][hyp]
+            assert abs(x - y) <= 1e-10 * max(abs(y), 1e-300), (kw, hyp)
+        assert np.array_equal(mine.sd_for_fixed, theirs.sd_for_fixed)
+        assert mine.clone(bridge_exponent=.5).get_info()['bridge_exponent'] == .5
+        for to in ('raw', 'coef_magnitude'):
+            g1, l1 = mine.adjust_scale(.3, np.arange(1., 5.), to)
+            g2, l2 = theirs.adjust_scale(.3, np.arange(1., 5.), to)
+            assert g1 == g2 and np.array_equal(l1, l2)
+            ga, gb = np.array([.3, .4]), np.array([.3, .4])
+            mine.adjust_scale(ga, np.ones(2), to)
+            theirs.adjust_scale(gb, np.ones(2), to)
+            assert np.array_equal(ga, gb)        # in place, like the reference
+    for bad in (dict(bridge_exponent=2.5),
+                dict(n_fixed_effect=2, sd_for_fixed_effect=[1.]),
+                dict(global_scale_prior_hyper_param={'log10_mean': 0.})):
+        for cls in (RegressionCoefPrior, RefPrior):
+            with pytest.raises(ValueError):
+                cls(**bad)
+
+    class _D():
+        shape = (4, 3)
+    ok = [(np.array([0, 1, 1, 0]), None),
+          (np.array([0, 2, 1, 3]), np.array([1, 2, 3, 3]))]
+    bad = [(np.array([0, 2, 1, 0]), None),
+           (np.array([0, 1, 1]), None),
+           (np.array([0, 1, 1, 0]), np.array([1, 1, 1])),
+           (np.array([0, 1, 1, 0]), np.array([1, 0, 1, 1])),
+           (np.array([0, 2, 1, 0]), np.array([1, 1, 1, 1]))]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for ns, nt in ok:
+            m, r = LogisticModel(ns, nt, _D()), RefLogit(ns, nt, _D())
+            assert np.array_equal(m.n_success, r.n_success)
+            assert np.array_equal(m.n_trial, r.n_trial)
+            assert m.n_trial.dtype == r.n_trial.dtype == np.float64
+        for ns, nt in bad:
+            for cls in (LogisticModel, RefLogit):
+                with pytest.raises(ValueError):
+                    cls(ns, nt, _D())
