@@ -16,6 +16,9 @@ LIB_PATH = os.environ.get(
 FORMAT_AUTO, FORMAT_CSR, FORMAT_TILED = 0, 1, 2
 F64, F32 = 0, 1
 MODEL_LINEAR, MODEL_LOGIT = 0, 1
+GSCALE_SAMPLE, GSCALE_OPTIMIZE, GSCALE_FIXED = 0, 1, 2
+# Philox stream ids of the chain's draws (csrc/philox.hpp)
+STREAM_ETA1, STREAM_ETA2 = 1, 2
 
 _lib = None
 
@@ -48,6 +51,7 @@ def _declare(lib):
         "bbx_design_shape": ([hp, POINTER(c_int64), POINTER(c_int64)], c_int),
         "bbx_design_nnz": ([hp, POINTER(c_int64)], c_int),
         "bbx_design_is_sparse": ([hp, POINTER(c_int)], c_int),
+        "bbx_design_device": ([hp, POINTER(c_int)], c_int),
         "bbx_design_format": ([hp, POINTER(c_int)], c_int),
         "bbx_design_storage_bytes": ([hp, POINTER(c_int64)], c_int),
         "bbx_design_matvec_bytes": (
@@ -93,6 +97,12 @@ def _declare(lib):
         "bbx_chain_init_obs_prec": ([hp], c_int),
         "bbx_chain_get_iteration": ([hp, POINTER(c_int64)], c_int),
         "bbx_chain_set_iteration": ([hp, c_int64], c_int),
+        "bbx_chain_get_seed": ([hp, POINTER(c_uint64)], c_int),
+        "bbx_chain_set_seed": ([hp, c_uint64], c_int),
+        "bbx_chain_set_gscale_update": ([hp, c_int], c_int),
+        "bbx_chain_eta": ([hp, c_int64, c_void_p, c_void_p], c_int),
+        "bbx_chain_get_logp": (
+            [hp, POINTER(c_double), POINTER(c_double)], c_int),
         "bbx_chain_run": (
             [hp, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
              c_void_p, c_void_p, c_void_p, c_void_p], c_int),
@@ -105,6 +115,8 @@ def _declare(lib):
             [c_int, c_uint64, c_int64, c_double, c_void_p, c_void_p], c_int),
         "bbx_device_gamma": (
             [c_int, c_uint64, c_int64, c_double, c_void_p], c_int),
+        "bbx_device_normal": (
+            [c_int, c_uint64, c_uint64, c_int64, c_void_p], c_int),
     }
     for name, (argtypes, restype) in sigs.items():
         fn = getattr(lib, name)

@@ -20,12 +20,13 @@ store).  Two execution modes, chosen by `options={'rng': ...}`:
 """
 import math
 import time
-from ctypes import byref, c_double, c_int64, c_void_p
+from ctypes import c_void_p
 from warnings import warn
 
 import numpy as np
 
 from . import _lib
+from .device_chain import HipGibbsChain
 from .hostrng import ReferenceRandom
 from .model import LogisticModel
 from .prior import RegressionCoefPrior
@@ -108,7 +109,7 @@ class BayesBridge():
         self.prior = prior
         self.rg = None
         self._lib = _lib.load()
-        self._chain = c_void_p()
+        self._chain = None
         self._chain_seed = None
 
     def __del__(self):
@@ -116,12 +117,9 @@ class BayesBridge():
 
     def _destroy_chain(self):
         ch = getattr(self, '_chain', None)
-        if ch is not None and ch.value:
-            try:
-                self._lib.bbx_chain_destroy(ch)
-            except Exception:
-                pass
-            self._chain = c_void_p()
+        if ch is not None:
+            ch.close()
+        self._chain = None
 
     # ------------------------------------------------------------------ API
     def gibbs_resume(self, prev_mcmc_info, n_add_iter, n_status_update=0,
@@ -471,40 +469,15 @@ class BayesBridge():
     def _make_chain(self, seed):
         self._destroy_chain()
         model, prior = self.model, self.prior
-        outcome = model.y if model.name == 'linear' else model.n_success
-        outcome = np.ascontiguousarray(outcome, dtype=np.float64)
-        n_trial = None
-        if model.name == 'logit':
-            n_trial = np.ascontiguousarray(model.n_trial, dtype=np.float64)
-        sd = np.ascontiguousarray(self.prior_sd_for_unshrunk, dtype=np.float64)
         hyper = prior.param['gscale_neg_power']
-        _lib.check(self._lib.bbx_chain_create(
-            model.design.handle,
-            _lib.MODEL_LINEAR if model.name == 'linear' else _lib.MODEL_LOGIT,
-            _ptr(outcome), _ptr(n_trial), int(self.n_unshrunk), _ptr(sd),
-            float(prior.bridge_exp), float(prior.slab_size),
-            float(hyper['shape']), float(hyper['rate']),
-            int(seed) & 0xFFFFFFFFFFFFFFFF, byref(self._chain)))
+        self._chain = HipGibbsChain(
+            model.design, model.name,
+            model.y if model.name == 'linear' else model.n_success,
+            n_trial=model.n_trial if model.name == 'logit' else None,
+            sd_unshrunk=self.prior_sd_for_unshrunk,
+            bridge_exponent=prior.bridge_exp, slab_size=prior.slab_size,
+            gscale_shape=hyper['shape'], gscale_rate=hyper['rate'], seed=seed)
         self._chain_seed = seed
-
-    def _chain_set_state(self, coef, obs_prec, lscale, gscale):
-        obs = np.ascontiguousarray(
-            np.atleast_1d(np.asarray(obs_prec, dtype=np.float64)))
-        coef = np.ascontiguousarray(coef, dtype=np.float64)
-        lscale = np.ascontiguousarray(lscale, dtype=np.float64)
-        g = c_double(float(gscale))
-        _lib.check(self._lib.bbx_chain_set_state(
-            self._chain, _ptr(coef), _ptr(obs), _ptr(lscale), byref(g)))
-
-    def _chain_get_state(self):
-        coef = np.empty(self.n_pred)
-        lscale = np.empty(self.n_pred - self.n_unshrunk)
-        obs = np.empty(self.n_obs if self.model.name == 'logit' else 1)
-        g = c_double()
-        _lib.check(self._lib.bbx_chain_get_state(
-            self._chain, _ptr(coef), _ptr(obs), _ptr(lscale), byref(g)))
-        obs_prec = obs if self.model.name == 'logit' else float(obs[0])
-        return coef, obs_prec, lscale, float(g.value)
 
     def _gibbs_device(self, n_iter, n_burnin, thin, seed, init,
                       params_to_save, options, resume_from):
@@ -516,20 +489,22 @@ class BayesBridge():
             seed = int(np.random.SeedSequence().generate_state(1)[0])
         sampler = HipRegressionCoefficientSampler(
             self.n_pred, self.prior_sd_for_unshrunk, 'cg', prior.slab_size)
-        if resume_from is None:
+        if resume_from is None or self._chain is None:
             self._make_chain(seed)
-        elif not self._chain.value:
-            self._make_chain(seed)
+        elif self._chain_seed != seed:
+            # the handle last ran another seed's streams: a resumed chain has
+            # to continue ITS Philox key
+            self._chain.seed = seed
+            self._chain_seed = seed
+        chain = self._chain
+        chain.set_gscale_update(options.gscale_update)
         if resume_from is not None:
             st = resume_from['_reg_coef_sampler_state']
-            mean = np.ascontiguousarray(st['mean'], dtype=np.float64)
-            square = np.ascontiguousarray(st['square'], dtype=np.float64)
-            _lib.check(self._lib.bbx_chain_set_summary(
-                self._chain, _ptr(mean), _ptr(square), int(st['n_averaged'])))
-            _lib.check(self._lib.bbx_chain_set_iteration(
-                self._chain, int(resume_from['_random_gen_state']['iteration'])))
+            chain.set_summary(st['mean'], st['square'], st['n_averaged'])
+            chain.iteration = resume_from['_random_gen_state']['iteration']
         nu = self.n_unshrunk
         host_rng = np.random.default_rng(seed)
+        dev = model.design.device
 
         # Initialisation draws (once, O(n) / O(p)) reuse the device samplers
         # through the chain: set the state, then let one kernel refresh it.
@@ -542,14 +517,24 @@ class BayesBridge():
             out = np.empty(self.n_obs)
             shape = np.ascontiguousarray(model.n_trial, dtype=np.int32)
             _lib.check(self._lib.bbx_device_polya_gamma(
-                0, int(host_rng.integers(1, 2 ** 62)), self.n_obs,
+                dev, int(host_rng.integers(1, 2 ** 62)), self.n_obs,
                 _ptr(shape), _ptr(np.ascontiguousarray(eta)), _ptr(out)))
             return out
 
         def update_global_scale(gscale, beta, bridge_exp, method='sample'):
+            # only reached from initialize_chain with method='optimize'
+            # (bayesbridge.py:318-320); per-iteration updates run on the device
             if beta.size == 0:
                 return 1.
-            gscale = self._monte_carlo_em_global_scale(beta, bridge_exp)
+            if method is None:
+                return gscale
+            if method == 'optimize':
+                gscale = self._monte_carlo_em_global_scale(beta, bridge_exp)
+            else:
+                hyper = prior.param['gscale_neg_power']
+                phi = host_rng.gamma(hyper['shape'] + beta.size / bridge_exp) \
+                    / (hyper['rate'] + np.sum(np.abs(beta) ** bridge_exp))
+                gscale = 1 / phi ** (1 / bridge_exp)
             return max(gscale, self._lower_bd(bridge_exp))
 
         def update_local_scale(gscale, beta, bridge_exp):
@@ -559,7 +544,7 @@ class BayesBridge():
             tilt = np.ascontiguousarray((beta / gscale) ** 2)
             if beta.size:
                 _lib.check(self._lib.bbx_device_tilted_stable(
-                    0, int(host_rng.integers(1, 2 ** 62)), beta.size,
+                    dev, int(host_rng.integers(1, 2 ** 62)), beta.size,
                     float(bridge_exp / 2), _ptr(tilt), _ptr(out)))
             lscale = np.sqrt(.5 / out)
             lscale[lscale == 0] = 10e-16
@@ -570,53 +555,36 @@ class BayesBridge():
             self._initialize_chain(init, bridge_exp, update_local_scale,
                                    update_obs_precision, update_global_scale,
                                    sampler)
-        self._chain_set_state(coef, obs_prec, lscale, gscale)
+        chain.set_state(coef, obs_prec, lscale, gscale)
 
-        n_sample = math.floor((n_iter - n_burnin) / thin)
         samples, sampling_info = self._pre_allocate(
             n_iter - n_burnin, thin, params_to_save)
-        n_shrunk = self.n_pred - nu
-        op_len = self.n_obs if model.name == 'logit' else 1
-        # sample-major host buffers filled by the library at the end
-        h_coef = np.zeros((max(n_sample, 1), self.n_pred)) \
-            if 'coef' in samples else None
-        h_ls = np.zeros((max(n_sample, 1), max(n_shrunk, 1))) \
-            if 'local_scale' in samples else None
-        h_op = np.zeros((max(n_sample, 1), op_len)) \
-            if 'obs_prec' in samples else None
-        gs = np.zeros(max(n_sample, 1))
-        lp = np.zeros(max(n_sample, 1))
-        ncg = np.zeros(max(n_sample, 1))
-        n_unconv = _lib.check(self._lib.bbx_chain_run_host(
-            self._chain, int(n_iter), int(n_burnin), int(thin), 500, 0.,
-            _ptr(h_coef), _ptr(h_ls), _ptr(h_op), _ptr(gs), _ptr(lp),
-            _ptr(ncg)))
+        kept, n_unconv = chain.run(
+            n_iter, n_burnin, thin, maxiter=500, atol=0.,
+            save=[k for k in ('coef', 'local_scale', 'obs_prec')
+                  if k in samples])
         if n_unconv > 0:
             warn("The conjugate gradient algorithm did not achieve the "
                  "requested tolerance level in %d iteration(s)." % n_unconv)
-        if 'coef' in samples:
-            samples['coef'][:] = h_coef[:n_sample].T
-        if 'local_scale' in samples and n_shrunk > 0:
-            samples['local_scale'][:] = h_ls[:n_sample, :n_shrunk].T
+        # the library stores samples sample-major; users get the MCMC index
+        # last (gibbs_util.py:126-127)
+        for key in ('coef', 'local_scale'):
+            if key in samples and samples[key].size:
+                samples[key][:] = kept[key].T
         if 'obs_prec' in samples:
-            samples['obs_prec'][:] = h_op[:n_sample, 0] \
-                if model.name == 'linear' else h_op[:n_sample].T
-        if 'global_scale' in samples:
-            samples['global_scale'][:] = gs[:n_sample]
-        if 'logp' in samples:
-            samples['logp'][:] = lp[:n_sample]
-        sampling_info['n_cg_iter'][:] = ncg[:n_sample]
-        coef, obs_prec, lscale, gscale = self._chain_get_state()
-        mean, square = np.empty(self.n_pred), np.empty(self.n_pred)
-        n_avg, it = c_int64(), c_int64()
-        _lib.check(self._lib.bbx_chain_get_summary(
-            self._chain, _ptr(mean), _ptr(square), byref(n_avg)))
-        _lib.check(self._lib.bbx_chain_get_iteration(self._chain, byref(it)))
+            samples['obs_prec'][:] = kept['obs_prec'][:, 0] \
+                if model.name == 'linear' else kept['obs_prec'].T
+        for key in ('global_scale', 'logp'):
+            if key in samples:
+                samples[key][:] = kept[key]
+        sampling_info['n_cg_iter'][:] = kept['n_cg_iter']
+        coef, obs_prec, lscale, gscale = chain.get_state()
+        mean, square, n_avg = chain.get_summary()
         extra = {
             '_random_gen_state': {'kind': 'philox', 'seed': seed,
-                                  'iteration': int(it.value)},
+                                  'iteration': chain.iteration},
             '_reg_coef_sampler_state': {'mean': mean, 'square': square,
-                                        'n_averaged': int(n_avg.value)},
+                                        'n_averaged': n_avg},
         }
         return (samples, sampling_info, (coef, obs_prec, lscale, gscale),
                 init_used, optim_info, extra)

@@ -80,6 +80,13 @@ class HipDesignMatrix():
         return int(v.value)
 
     @property
+    def device(self):
+        """HIP device index the operator lives on."""
+        v = c_int()
+        _lib.check(self._lib.bbx_design_device(self._h, byref(v)))
+        return int(v.value)
+
+    @property
     def storage_format(self):
         v = c_int()
         _lib.check(self._lib.bbx_design_format(self._h, byref(v)))
@@ -315,6 +322,26 @@ class HipDenseDesignMatrix(HipDesignMatrix):
         _lib.check(self._lib.bbx_design_create_dense(
             n, p, _ptr(X), in_dtype, st, _ptr(offset),
             int(bool(add_intercept)), int(device), byref(self._h)))
+
+    @classmethod
+    def from_device_array(cls, n, p, X_ptr, offset_ptr=None,
+                          add_intercept=True, device=0, in_dtype='float32',
+                          storage_dtype='float32'):
+        """Adopts a row-major n x p array that already lives in HBM (raw
+        device pointer); it is copied (centred, intercept column added) into
+        the operator's own storage."""
+        self = cls.__new__(cls)
+        HipDesignMatrix.__init__(self)
+        _lib.require_gpu()
+        self.centered = offset_ptr is not None
+        self.intercept_added = add_intercept
+        self.column_offset = None
+        code = {'float64': _lib.F64, 'float32': _lib.F32}
+        _lib.check(self._lib.bbx_design_create_dense_dev(
+            n, p, c_void_p(X_ptr), code[in_dtype], code[storage_dtype],
+            c_void_p(offset_ptr) if offset_ptr else None,
+            int(bool(add_intercept)), int(device), byref(self._h)))
+        return self
 
     @property
     def is_sparse(self):

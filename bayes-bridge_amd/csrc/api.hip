@@ -280,9 +280,20 @@ static int finish_csr(bbx_design* h, int format) {
     h->binary = true;
   }
   BBX_TRY(build_transpose_csr(h));
-  if (format == BBX_FORMAT_AUTO) format = BBX_FORMAT_TILED;
+  const bool automatic = (format == BBX_FORMAT_AUTO);
+  if (automatic) format = BBX_FORMAT_TILED;
   h->format = format;
-  if (format == BBX_FORMAT_TILED) BBX_TRY(build_tiled(h));
+  if (format == BBX_FORMAT_TILED) {
+    const int st = build_tiled(h);
+    if (st == BBX_ERR_INVALID && automatic) {
+      // "tiled when it applies, else csr" (bbx.h): the reference-layout arrays
+      // are only released at the end of a successful build_tiled
+      destroy_tiled(h);
+      h->format = BBX_FORMAT_CSR;
+      return BBX_OK;
+    }
+    BBX_TRY(st);
+  }
   return BBX_OK;
 }
 
@@ -521,6 +532,12 @@ int bbx_design_is_sparse(const bbx_design* h, int* flag) {
   return BBX_OK;
 }
 
+int bbx_design_device(const bbx_design* h, int* device) {
+  BBX_TRY(check_handle(h));
+  if (device) *device = h->device;
+  return BBX_OK;
+}
+
 int bbx_design_format(const bbx_design* h, int* format) {
   BBX_TRY(check_handle(h));
   if (format) *format = h->sparse ? h->format : 0;
@@ -658,10 +675,16 @@ static int bbx_cg_sample_impl(bbx_design* h, const double* obs_prec,
   }
   // pageable host memory: the copies above must not outlive the call
   BBX_HIP(hipStreamSynchronize(h->stream));
+  int x0_zero = 1;  // numpy: x0.any()
+  for (int64_t j = 0; j < h->P; ++j)
+    if (x0[j] != 0.) {
+      x0_zero = 0;
+      break;
+    }
   int st = cg_sample_device(h, d_omega, d_phi, d_z, d_x0, d_sd, n_unshrunk,
                             randn_n ? d_eta1 : nullptr,
                             randn_n ? d_eta2 : nullptr, seed, maxiter, atol,
-                            d_coef, n_iter_out, info_out);
+                            d_coef, n_iter_out, info_out, x0_zero);
   if (st < 0) return st;
   BBX_HIP(hipMemcpyAsync(coef_out, d_coef, Pb, hipMemcpyDeviceToHost,
                          h->stream));

@@ -47,6 +47,15 @@ __global__ __launch_bounds__(256) void fill_normal_kernel(
   }
 }
 
+__global__ __launch_bounds__(256) void any_nonzero_kernel(
+    int64_t len, const double* __restrict__ x, int* __restrict__ flag) {
+  bool nz = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (int64_t)gridDim.x * blockDim.x)
+    nz = nz || (x[i] != 0.);  // NaN counts as non-zero, like ndarray.any()
+  if (nz) atomicOr(flag, 1);
+}
+
 int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,
                        uint64_t stream, double* d_out) {
   int64_t nb = (len + 255) / 256;
@@ -86,7 +95,7 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
                      const double* d_sd, int n_unshrunk, const double* d_eta1,
                      const double* d_eta2, uint64_t seed, int maxiter,
                      double atol, double* d_coef, int* n_iter_out,
-                     int* info_out) {
+                     int* info_out, int x0_zero) {
   if (maxiter < 0) return fail(BBX_ERR_INVALID, "maxiter must be >= 0");
   if (n_unshrunk < 0 || n_unshrunk > h->P)
     return fail(BBX_ERR_INVALID, "n_unshrunk out of range");
@@ -132,10 +141,29 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     BBX_TRY(launch_tdot(h, w, part_slot(h, PS_SUMW), ep, b));
   }
 
-  // r = b - A x0
-  BBX_TRY(launch_prep_v(h, x, s, sp, part_slot(h, PS_C)));
-  BBX_TRY(apply_operator(h, d_omega, sp, x, s, d, q));
-  BBX_TRY(launch_cg_init_resid(h, b, q, r, part_slot(h, PS_RR)));
+  // r = b - A x0, or r = b when the warm start is all zeros: SciPy's cg skips
+  // the product then (`r = b - matvec(x) if x.any() else b.copy()`), and so do
+  // we, so that the dot/Tdot counters match the reference's for cold starts.
+  CGState* host_st = static_cast<CGState*>(h->host_pinned);
+  if (x0_zero < 0) {
+    int* d_flag = reinterpret_cast<int*>(st);  // CGState is uploaded below
+    int* h_flag = reinterpret_cast<int*>(host_st);
+    BBX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(any_nonzero_kernel, dim3(NPART), dim3(256), 0,
+                       h->stream, h->P, d_x0, d_flag);
+    BBX_HIP(hipGetLastError());
+    BBX_HIP(hipMemcpyAsync(h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost,
+                           h->stream));
+    BBX_HIP(hipStreamSynchronize(h->stream));
+    x0_zero = (*h_flag == 0) ? 1 : 0;
+  }
+  if (x0_zero) {
+    BBX_TRY(launch_cg_init_resid(h, b, nullptr, r, part_slot(h, PS_RR)));
+  } else {
+    BBX_TRY(launch_prep_v(h, x, s, sp, part_slot(h, PS_C)));
+    BBX_TRY(apply_operator(h, d_omega, sp, x, s, d, q));
+    BBX_TRY(launch_cg_init_resid(h, b, q, r, part_slot(h, PS_RR)));
+  }
 
   CGState init;
   init.rho[0] = init.rho[1] = 0.;
@@ -145,7 +173,6 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
   init.done = 0;
   init.bad = 0;
   init.pad = 0;
-  CGState* host_st = static_cast<CGState*>(h->host_pinned);
   *host_st = init;
   BBX_HIP(hipMemcpyAsync(st, host_st, sizeof(CGState), hipMemcpyHostToDevice,
                          h->stream));
@@ -238,6 +265,13 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
                          h->stream));
   BBX_HIP(hipStreamSynchronize(h->stream));
   const int n_iter = host_st->n_iter;
+  // Operator applications enqueued past the stopping iteration exited at entry
+  // (their kernels see `done`): they are not matvecs and do not count
+  // (abstract_matrix.py:61-72 counts products that ran).
+  if (k > n_iter) {
+    h->n_dot -= (k - n_iter);
+    h->n_tdot -= (k - n_iter);
+  }
   int info = host_st->done ? 0 : maxiter;
   if (host_st->bad) info = -1;
   h->last_cg_iter = n_iter;

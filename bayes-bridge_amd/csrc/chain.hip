@@ -34,6 +34,8 @@ struct bbx_chain {
   uint64_t seed = 0;
   int64_t iter = 0;        // iterations done (Philox key)
   int64_t n_averaged = 0;  // summariser count
+  bool mean_zero = true;   // running mean still all zeros => CG warm start 0
+  int gscale_update = BBX_GSCALE_SAMPLE;
   bbx::DevMem outcome, n_trial, kappa;  // n
   bbx::DevMem zbase;                    // P: X~^T kappa (logit) or X~^T y
   bbx::DevMem coef, phi, x0, sd, z, mean, square, sd_unshrunk;  // P-length
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void chain_coef_sums_kernel(
 // and, with the new tau, the log posterior (bayesbridge.py:480-511).
 __global__ __launch_bounds__(256) void chain_gscale_kernel(
     int64_t n_shrunk, int nu, double alpha, double shape0, double rate0,
-    double lower_bd, uint64_t seed, uint64_t stream,
+    double lower_bd, int update_mode, uint64_t seed, uint64_t stream,
     const double* __restrict__ part_pow, const double* __restrict__ part_slab,
     const double* __restrict__ part_fixed,
     const double* __restrict__ sd_unshrunk, ChainScalars* __restrict__ sc) {
@@ -262,16 +264,23 @@ __global__ __launch_bounds__(256) void chain_gscale_kernel(
   if (threadIdx.x != 0) return;
   double g = sc->gscale;
   if (n_shrunk > 0) {
-    if (pow_sum == 0.) {
-      g = 0.;  // bayesbridge.py:430-431
-    } else {
-      const double shape = shape0 + (double)n_shrunk / alpha;
-      const double rate = rate0 + pow_sum;
-      Philox rng(seed, stream, 0);
-      const double ph = gamma_draw(rng, shape) / rate;
-      g = 1. / pow(ph, 1. / alpha);
+    if (update_mode == BBX_GSCALE_OPTIMIZE) {
+      // Monte-Carlo EM step (bayesbridge.py:450-456)
+      const double ph = (double)n_shrunk / alpha / pow_sum;
+      g = pow(ph, -(1. / alpha));
+    } else if (update_mode == BBX_GSCALE_SAMPLE) {
+      if (pow_sum == 0.) {
+        g = 0.;  // bayesbridge.py:430-431
+      } else {
+        const double shape = shape0 + (double)n_shrunk / alpha;
+        const double rate = rate0 + pow_sum;
+        Philox rng(seed, stream, 0);
+        const double ph = gamma_draw(rng, shape) / rate;
+        g = 1. / pow(ph, 1. / alpha);
+      }
     }
-    if (g < lower_bd) {
+    // method None keeps tau and skips the bound (bayesbridge.py:441)
+    if (update_mode != BBX_GSCALE_FIXED && g < lower_bd) {
       g = lower_bd;
       sc->n_gscale_clamped += 1;
     }
@@ -499,6 +508,11 @@ static double power_exp_ave_magnitude(double exponent) {
   return std::tgamma(2. / exponent) / std::tgamma(1. / exponent);
 }
 
+// Philox key of the CG draw's normals at 0-based iteration `it`.
+static inline uint64_t cg_draw_seed(const bbx_chain* c, uint64_t it) {
+  return c->seed + 0x9E3779B97F4A7C15ull * (it + 1);
+}
+
 // One Gibbs iteration (bayesbridge.py:210-240); returns the CG info (>= 0).
 static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
   bbx_design* h = c->h;
@@ -524,9 +538,10 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
   int st = cg_sample_device(
       h, c->obs_prec.as<double>(), c->phi.as<double>(), c->z.as<double>(),
       c->x0.as<double>(), c->sd.as<double>(), nu, nullptr, nullptr,
-      c->seed + 0x9E3779B97F4A7C15ull * (it + 1), maxiter, atol,
-      c->coef.as<double>(), n_cg_iter, &info);
+      cg_draw_seed(c, it), maxiter, atol, c->coef.as<double>(), n_cg_iter,
+      &info, c->mean_zero ? 1 : 0);
   if (st < 0) return st;
+  c->mean_zero = false;
   hipLaunchKernelGGL(chain_summary_kernel, dim3(NPART), dim3(256), 0, s, P, nu,
                      c->slab, (long long)c->n_averaged, sc,
                      c->lscale.as<double>(), c->coef.as<double>(),
@@ -558,7 +573,8 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
                      pp + 2 * NPART);
   const double lower_bd = .001 / power_exp_ave_magnitude(c->bridge_exp);
   hipLaunchKernelGGL(chain_gscale_kernel, dim3(1), dim3(256), 0, s, n_shrunk,
-                     nu, c->bridge_exp, c->shape0, c->rate0, lower_bd, c->seed,
+                     nu, c->bridge_exp, c->shape0, c->rate0, lower_bd,
+                     c->gscale_update, c->seed,
                      iter_stream(STREAM_GSCALE, c->iter), pp, pp + NPART,
                      pp + 2 * NPART, c->sd_unshrunk.as<double>(), sc);
   if (n_shrunk > 0) {
@@ -777,6 +793,12 @@ int bbx_chain_set_summary(bbx_chain* c, const double* mean,
   BBX_HIP(hipMemcpy(c->mean.ptr, mean, Pb, hipMemcpyHostToDevice));
   BBX_HIP(hipMemcpy(c->square.ptr, square, Pb, hipMemcpyHostToDevice));
   c->n_averaged = n_averaged;
+  c->mean_zero = true;
+  for (int64_t j = 0; j < c->h->P; ++j)
+    if (mean[j] != 0.) {
+      c->mean_zero = false;
+      break;
+    }
   return BBX_OK;
 }
 
@@ -803,6 +825,70 @@ int bbx_chain_set_iteration(bbx_chain* c, int64_t iteration) {
   BBX_TRY(chain_check(c));
   if (iteration < 0) return fail(BBX_ERR_INVALID, "iteration < 0");
   c->iter = iteration;
+  return BBX_OK;
+}
+
+int bbx_chain_get_seed(bbx_chain* c, uint64_t* seed) {
+  BBX_TRY(chain_check(c));
+  if (seed) *seed = c->seed;
+  return BBX_OK;
+}
+
+int bbx_chain_set_seed(bbx_chain* c, uint64_t seed) {
+  BBX_TRY(chain_check(c));
+  c->seed = seed;
+  return BBX_OK;
+}
+
+int bbx_chain_set_gscale_update(bbx_chain* c, int mode) {
+  BBX_TRY(chain_check(c));
+  if (mode != BBX_GSCALE_SAMPLE && mode != BBX_GSCALE_OPTIMIZE &&
+      mode != BBX_GSCALE_FIXED)
+    return fail(BBX_ERR_INVALID, "unknown global-scale update mode");
+  c->gscale_update = mode;
+  return BBX_OK;
+}
+
+static int bbx_chain_eta_impl(bbx_chain* c, int64_t iteration, double* eta1,
+                              double* eta2) {
+  BBX_TRY(chain_check(c));
+  if (iteration < 0) return fail(BBX_ERR_INVALID, "iteration < 0");
+  bbx_design* h = c->h;
+  BBX_HIP(hipSetDevice(h->device));
+  const uint64_t seed = cg_draw_seed(c, (uint64_t)iteration);
+  DevMem tmp;
+  const int64_t len = h->n > h->P ? h->n : h->P;
+  BBX_TRY(tmp.alloc(sizeof(double) * (size_t)len));
+  if (eta1) {
+    BBX_TRY(launch_fill_normal(h, h->n, seed, STREAM_ETA1, tmp.as<double>()));
+    BBX_HIP(hipMemcpyAsync(eta1, tmp.ptr, sizeof(double) * (size_t)h->n,
+                           hipMemcpyDeviceToHost, h->stream));
+    BBX_HIP(hipStreamSynchronize(h->stream));
+  }
+  if (eta2) {
+    BBX_TRY(launch_fill_normal(h, h->P, seed, STREAM_ETA2, tmp.as<double>()));
+    BBX_HIP(hipMemcpyAsync(eta2, tmp.ptr, sizeof(double) * (size_t)h->P,
+                           hipMemcpyDeviceToHost, h->stream));
+    BBX_HIP(hipStreamSynchronize(h->stream));
+  }
+  return BBX_OK;
+}
+
+int bbx_chain_eta(bbx_chain* c, int64_t iteration, double* eta1,
+                  double* eta2) {
+  return no_throw([&]() -> int {
+    return bbx_chain_eta_impl(c, iteration, eta1, eta2);
+  });
+}
+
+int bbx_chain_get_logp(bbx_chain* c, double* loglik, double* logp) {
+  BBX_TRY(chain_check(c));
+  BBX_HIP(hipSetDevice(c->h->device));
+  BBX_HIP(hipStreamSynchronize(c->h->stream));
+  ChainScalars sc;
+  BBX_HIP(hipMemcpy(&sc, c->scalars.ptr, sizeof(sc), hipMemcpyDeviceToHost));
+  if (loglik) *loglik = sc.loglik;
+  if (logp) *logp = sc.logp;
   return BBX_OK;
 }
 
@@ -1048,5 +1134,36 @@ int bbx_device_gamma(int device, uint64_t seed, int64_t n_draw, double shape,
   });
 }
 
+
+__global__ __launch_bounds__(256) void dev_normal_kernel(
+    int64_t n, uint64_t seed, uint64_t stream, double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256) {
+    bbx::Philox g(seed, stream, (uint64_t)i);
+    out[i] = g.normal();
+  }
+}
+
+static int bbx_device_normal_impl(int device, uint64_t seed, uint64_t stream,
+                                  int64_t n_draw, double* out) {
+  BBX_TRY(dev_sampler_common(device, n_draw));
+  if (n_draw == 0) return BBX_OK;
+  if (!out) return fail(BBX_ERR_INVALID, "out is NULL");
+  DevMem dout;
+  BBX_TRY(dout.alloc(sizeof(double) * (size_t)n_draw));
+  hipLaunchKernelGGL(dev_normal_kernel, dim3(grid_for(n_draw, 4096)),
+                     dim3(256), 0, 0, n_draw, seed, stream, dout.as<double>());
+  BBX_HIP(hipGetLastError());
+  BBX_HIP(hipMemcpy(out, dout.ptr, sizeof(double) * (size_t)n_draw,
+                    hipMemcpyDeviceToHost));
+  return BBX_OK;
+}
+
+int bbx_device_normal(int device, uint64_t seed, uint64_t stream,
+                      int64_t n_draw, double* out) {
+  return no_throw([&]() -> int {
+    return bbx_device_normal_impl(device, seed, stream, n_draw, out);
+  });
+}
 
 }  // extern "C"

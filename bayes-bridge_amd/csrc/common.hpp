@@ -275,6 +275,8 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
                      const double* d_sd, int n_unshrunk, const double* d_eta1,
                      const double* d_eta2, uint64_t seed, int maxiter,
                      double atol, double* d_coef, int* n_iter_out,
-                     int* info_out);
+                     int* info_out, int x0_zero = -1);
+// x0_zero: 1 the warm start is known to be all zeros (the initial-residual
+// product is skipped, as SciPy does), 0 known not to be, -1 check on the device.
 
 }  // namespace bbx

@@ -156,14 +156,14 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_setup_kernel(
   }
 }
 
-// r = b - q, partials of r.r   (SciPy cg: r = b - A x0)
+// r = b - q (q == nullptr: r = b), partials of r.r   (SciPy cg: r = b - A x0)
 __global__ __launch_bounds__(VEC_BLOCK) void cg_init_resid_kernel(
     int64_t P, const double* __restrict__ b, const double* __restrict__ q,
     double* __restrict__ r, double* __restrict__ rr_part) {
   double acc = 0.;
   for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
        jj += (int64_t)gridDim.x * VEC_BLOCK) {
-    const double val = b[jj] - q[jj];
+    const double val = q ? b[jj] - q[jj] : b[jj];
     r[jj] = val;
     acc += val * val;
   }

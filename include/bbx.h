@@ -59,6 +59,13 @@ extern "C" {
 #define BBX_MODEL_LINEAR 0
 #define BBX_MODEL_LOGIT 1
 
+/* global-scale update of a chain: SamplerOptions.gscale_update
+ * (gibbs_util.py:9-31; bayesbridge.py:412-448) */
+#define BBX_GSCALE_SAMPLE 0   /* 'sample': conjugate Gamma draw of tau^-alpha  */
+#define BBX_GSCALE_OPTIMIZE 1 /* 'optimize': Monte-Carlo EM step
+                                 (bayesbridge.py:450-456)                       */
+#define BBX_GSCALE_FIXED 2    /* None: tau stays at its current value           */
+
 typedef struct bbx_design bbx_design; /* opaque: one design operator on one GPU */
 typedef struct bbx_chain bbx_chain;   /* opaque: one device-resident Gibbs chain */
 
@@ -126,6 +133,9 @@ int bbx_design_destroy(bbx_design* h);
 int bbx_design_shape(const bbx_design* h, int64_t* n, int64_t* P);
 int bbx_design_nnz(const bbx_design* h, int64_t* nnz);
 int bbx_design_is_sparse(const bbx_design* h, int* flag);
+/* HIP device index the handle lives on (the reference's counterpart is the
+ * CuPy array's device, sparse_matrix.py:35). */
+int bbx_design_device(const bbx_design* h, int* device);
 /* Format actually in use (BBX_FORMAT_CSR / BBX_FORMAT_TILED; 0 for dense). */
 int bbx_design_format(const bbx_design* h, int* format);
 /* HBM bytes held by the operator's matrix storage (both orientations). */
@@ -294,6 +304,26 @@ int bbx_chain_init_obs_prec(bbx_chain* c);
 /* Iterations done so far (keys the Philox streams; settable for resume). */
 int bbx_chain_get_iteration(bbx_chain* c, int64_t* iteration);
 int bbx_chain_set_iteration(bbx_chain* c, int64_t iteration);
+/* The Philox key of the chain (bbx_chain_create's `seed`); settable so that a
+ * handle can continue another run's streams (gibbs_resume,
+ * bayesbridge.py:43-107 restores the generator state the same way). */
+int bbx_chain_get_seed(bbx_chain* c, uint64_t* seed);
+int bbx_chain_set_seed(bbx_chain* c, uint64_t seed);
+/* How tau is updated each iteration: BBX_GSCALE_SAMPLE (default),
+ * BBX_GSCALE_OPTIMIZE or BBX_GSCALE_FIXED (bayesbridge.py:412-448 `method`). */
+int bbx_chain_set_gscale_update(bbx_chain* c, int mode);
+/*
+ * Regenerates, on the device, the standard normals the chain's CG draw
+ * consumes at 0-based iteration `iteration` (cg_sampler.py:61-62: eta1[n] for
+ * the likelihood part, eta2[P] for the prior part) and copies them to the
+ * host.  Philox is counter-based, so this does not disturb the chain; it
+ * exists so that a test can feed the very same perturbation to the CPU oracle
+ * and compare the device chain's draw exactly.
+ */
+int bbx_chain_eta(bbx_chain* c, int64_t iteration, double* eta1, double* eta2);
+/* Log-likelihood and log-posterior of the state left by the last iteration
+ * (bayesbridge.py:480-511), host pointers, either may be NULL. */
+int bbx_chain_get_logp(bbx_chain* c, double* loglik, double* logp);
 
 /*
  * Runs n_iter Gibbs iterations; a sample is kept every `thin` iterations
@@ -327,6 +357,11 @@ int bbx_device_tilted_stable(int device, uint64_t seed, int64_t n_draw,
                              double char_exp, const double* tilt, double* out);
 int bbx_device_gamma(int device, uint64_t seed, int64_t n_draw, double shape,
                      double* out);
+/* n_draw standard normals of Philox stream `stream` (element i = counter i):
+ * the generator behind eta1 / eta2 (cg_sampler.py:61-62 uses
+ * np.random.randn). */
+int bbx_device_normal(int device, uint64_t seed, uint64_t stream,
+                      int64_t n_draw, double* out);
 
 /* ----------------------- host-side reference-stream samplers (libbbx_hostrng)
  * Exported by the separate, HIP-free libbbx_hostrng.so.  `bitgen` is the

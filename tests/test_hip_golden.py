@@ -210,6 +210,20 @@ def test_config2_scaled_exact_seed_and_device_rng(golden_dir):
     # the bulk of the coefficients is shrunk to ~0 in both chains
     assert np.abs(mean_d[~big]).max() < .35
     assert np.corrcoef(mean_d, mean_r)[0, 1] > .9
+    # posterior SPREAD, not only location: a perturbation (eta) variance off
+    # by 2x would leave the means alone and move every sd by sqrt(2)
+    sd_d = d['coef'].std(axis=1)
+    ratio = sd_d[big] / sd_r[big]
+    assert np.all((ratio > .55) & (ratio < 1.8)), ratio
+    assert .8 < np.median(ratio) < 1.25, np.median(ratio)
+    # ... and over the bulk: total posterior variance of the shrunk block
+    bulk = ~big
+    bulk[0] = False
+    tot = np.sqrt((sd_d[bulk] ** 2).sum() / (sd_r[bulk] ** 2).sum())
+    assert .75 < tot < 1.33, tot
+    # the device log posterior averages where the reference's does
+    assert abs(d['logp'].mean() - float(g['logp_mean'])) \
+        < 1.5 * d['logp'].std() + 1e-3 * abs(float(g['logp_mean']))
     lg = np.log(d['global_scale'])
     ref_lg_sd = g['global_scale_sd'] / g['global_scale_mean']
     assert abs(lg.mean() - np.log(g['global_scale_mean'])) < ref_lg_sd + .1
