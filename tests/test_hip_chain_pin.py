@@ -125,7 +125,11 @@ def test_device_chain_iteration_equals_oracle(family, kind, storage):
         assert n_unconv == 0
         coef_d = kept['coef'][0]
         n_cg = int(kept['n_cg_iter'][0])
-        assert abs(n_cg - info_o['n_iter']) <= 2, (n_cg, info_o['n_iter'])
+        # +-2 around the oracle's stopping iteration; solves of ~100 iterations
+        # (dense Gaussian designs) sit on a flat stretch of the residual curve
+        # where the summation order moves the stop by a few (+-5 %)
+        slack = max(2, math.ceil(.05 * info_o['n_iter']))
+        assert abs(n_cg - info_o['n_iter']) <= slack, (n_cg, info_o['n_iter'])
         scale = max(1., np.abs(coef_o).max())
         tol = 1e-6 if n_cg == info_o['n_iter'] else 1e-5
         assert np.abs(coef_d - coef_o).max() <= tol * scale, \
@@ -150,12 +154,16 @@ def test_device_chain_iteration_equals_oracle(family, kind, storage):
         assert np.array_equal(ls_a, kept['local_scale'][0])
         lp_o = ora.logp(coef_a, g_a, obs_a)
         lp_d = float(kept['logp'][0])
-        assert abs(lp_d - lp_o) <= 1e-10 * abs(lp_o), (lp_d, lp_o)
+        # f32 storage rounds the CENTRED entries (X - mean is not
+        # f32-representable even when X is): the stored operator differs from
+        # the oracle's by 6e-8 relative per entry
+        lp_tol = 1e-7 if storage == 'float32' else 1e-10
+        assert abs(lp_d - lp_o) <= lp_tol * abs(lp_o), (lp_d, lp_o)
         ll_d, lp_d2 = chain.logp()
         assert lp_d2 == lp_d
         from oracle.gibbs import loglik
         ll_o = loglik(family, ora.design, ora.outcome, coef_a, obs_a)
-        assert abs(ll_d - ll_o) <= 1e-10 * abs(ll_o)
+        assert abs(ll_d - ll_o) <= lp_tol * abs(ll_o)
         assert g_a == kept['global_scale'][0] and g_a > 0
         assert np.all(ls_a > 0) and np.all(np.isfinite(ls_a))
         if family == 'logit':
