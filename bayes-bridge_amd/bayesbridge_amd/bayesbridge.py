@@ -215,6 +215,20 @@ class BayesBridge():
         mcmc_info.update(extra)
         return samples, mcmc_info
 
+    def gibbs_multichain(self, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
+                         init={'global_scale': 0.1},
+                         params_to_save=('coef', 'global_scale', 'logp'),
+                         options=None):
+        """`n_chain` independent chains, seeds seed + k; under
+        torch.distributed.run one rank per GPU shares them and the samples are
+        gathered once over RCCL on rank 0 (`chains.run_chains`).  The
+        reference has one chain per process (bayesbridge.py:109); this is the
+        multi-GPU capability of SURVEY.md 8(e).  Returns (samples, infos) with
+        samples[name] shaped (n_chain, ..., n_sample) on rank 0."""
+        from . import chains
+        return chains.run_chains(self, n_chain, n_iter, n_burnin, thin, seed,
+                                 init, params_to_save, options)
+
     # ------------------------------------------------- shared initialisation
     def _pre_allocate(self, n_post_burnin, thin, params_to_save):
         n_sample = math.floor(n_post_burnin / thin)        # gibbs_util.py:122

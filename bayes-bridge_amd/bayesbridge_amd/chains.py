@@ -8,8 +8,38 @@ the kept samples are gathered once over RCCL/xGMI (`backend='nccl'` IS RCCL on
 ROCm; `gloo` on CPU for the tests).  SURVEY.md 8(e).
 """
 import os
+import socket
+import subprocess
+import sys
 
 import numpy as np
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(n_ranks, script_argv, port=None, extra_env=None,
+                 capture=False, timeout=None):
+    """Starts `n_ranks` processes of `script_argv` (a Python script + its
+    arguments) on this node through torch.distributed.run, one rank per GPU,
+    as a CHILD process (never exec: a process that has touched the GPU must
+    not be replaced) and returns its exit code -- or the CompletedProcess when
+    `capture`.  Call it before anything in the parent initialises HIP."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node=%d" % int(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port or free_port())] + list(script_argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL
+    env.setdefault("OMP_NUM_THREADS", "1")
+    if extra_env:
+        env.update(extra_env)
+    if capture:
+        return subprocess.run(cmd, env=env, capture_output=True, text=True,
+                              timeout=timeout)
+    return subprocess.call(cmd, env=env, timeout=timeout)
 
 
 def init_process_group_from_env(backend=None):
@@ -28,6 +58,9 @@ def init_process_group_from_env(backend=None):
                                  torch.cuda.device_count() >= world) else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
+        if backend == "nccl":
+            # RCCL binds a communicator to the current device
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -50,12 +83,15 @@ def gather_chain_samples(local, dst=0):
     world = dist.get_world_size()
     rank = dist.get_rank()
     local = local.contiguous()
+    came_from = local.device
     if dist.get_backend() == "gloo" and local.is_cuda:
         local = local.cpu()
+    elif dist.get_backend() == "nccl" and not local.is_cuda:
+        local = local.cuda()          # RCCL moves device memory only
     if rank == dst:
         bucket = [torch.empty_like(local) for _ in range(world)]
         dist.gather(local, gather_list=bucket, dst=dst)
-        return torch.stack(bucket)
+        return torch.stack(bucket).to(came_from)
     dist.gather(local, gather_list=None, dst=dst)
     return None
 
@@ -82,6 +118,78 @@ def barrier():
 def split_chains(n_chain, world, rank):
     """Chains handled by `rank` when there are more chains than ranks."""
     return list(range(rank, n_chain, world))
+
+
+def run_chains(bridge, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
+               init=None, params_to_save=('coef', 'global_scale', 'logp'),
+               options=None, dst=0):
+    """`n_chain` independent chains of `bridge.gibbs(...)` (BASELINE config 5).
+
+    Inside a torch.distributed.run launch (one rank per GPU, each with its own
+    replica of the design) rank r runs chains r, r + world, ...; chain k uses
+    seed `seed + k` whatever the number of ranks, so the result does not depend
+    on how many GPUs shared the work.  Nothing is exchanged while sampling; at
+    the end each saved parameter is gathered ONCE on rank `dst`.
+
+    Returns on `dst` (samples, infos): samples[name] has the chain index first
+    and the MCMC index last, e.g. 'coef' is (n_chain, P, n_sample); infos is
+    the list of this rank's mcmc_info dicts (chain index in info['chain']).
+    Other ranks get (None, infos).  Without a process group all chains run one
+    after the other on this process's GPU.
+    """
+    import copy
+    import torch
+    rank, world, _ = init_process_group_from_env()
+    mine = split_chains(n_chain, world, rank)
+    per_rank = -(-n_chain // world)               # ranks pad to equal counts
+    init = {'global_scale': .1} if init is None else init
+    kept, infos = {}, []
+    for k in mine:
+        samples, info = bridge.gibbs(
+            n_iter, n_burnin, thin, seed=chain_seed(seed, k),
+            init=copy.deepcopy(init), params_to_save=params_to_save,
+            coef_sampler_type='cg', options=options)
+        info['chain'] = k
+        infos.append(info)
+        samples = dict(samples)
+        samples['n_cg_iter'] = info['_reg_coef_sampling_info']['n_cg_iter']
+        for name, arr in samples.items():
+            kept.setdefault(name, []).append(np.asarray(arr, dtype=np.float64))
+    names = sorted(kept) if kept else None
+    if world > 1:                                 # ranks without a chain
+        import torch.distributed as dist
+        box = [names]
+        src_rank = 0                              # rank 0 always owns chain 0
+        dist.broadcast_object_list(box, src=src_rank)
+        names = box[0]
+    merged = {}
+    for name in names:
+        have = kept.get(name, [])
+        if have:
+            block = np.stack(have)
+        else:
+            block = None
+        shape = None if block is None else block.shape[1:]
+        if world > 1:
+            import torch.distributed as dist
+            box = [shape]
+            dist.broadcast_object_list(box, src=0)
+            shape = tuple(box[0])
+        padded = np.zeros((per_rank,) + tuple(shape))
+        if block is not None:
+            padded[:len(have)] = block
+        got = gather_chain_samples(torch.from_numpy(padded), dst=dst)
+        if got is None:
+            continue
+        got = got.numpy()                          # [world, per_rank, ...]
+        out = np.empty((n_chain,) + tuple(shape))
+        for r in range(got.shape[0]):
+            for slot, k in enumerate(split_chains(n_chain, got.shape[0], r)):
+                out[k] = got[r, slot]
+        merged[name] = out
+    if world > 1 and rank != dst:
+        return None, infos
+    return merged, infos
 
 
 def merge_chain_outputs(gathered, params=('coef',)):

@@ -106,6 +106,21 @@ class HipDesignMatrix():
                                                       byref(b)))
         return int(a.value), int(b.value)
 
+    @property
+    def timed_bytes(self):
+        """Bytes moved by the kernels that get_timing() stamps (dot, Tdot)."""
+        a, b = c_int64(), c_int64()
+        _lib.check(self._lib.bbx_design_timed_bytes(self._h, byref(a),
+                                                     byref(b)))
+        return int(a.value), int(b.value)
+
+    @property
+    def fused_operator_bytes(self):
+        v = c_int64()
+        _lib.check(self._lib.bbx_design_fused_operator_bytes(self._h,
+                                                              byref(v)))
+        return int(v.value)
+
     def tiled_info(self):
         """Geometry of the LDS-tiled layout: {'X': {...}, 'Xt': {...}}."""
         out = {}
@@ -194,7 +209,7 @@ class HipDesignMatrix():
     def get_timing(self):
         """{'dot': (launches, total_ms), 'tdot': (...)} from HIP events."""
         res = {}
-        for which, name in ((0, "dot"), (1, "tdot")):
+        for which, name in ((0, "dot"), (1, "tdot"), (2, "operator")):
             cnt, ms = c_int64(), c_double()
             _lib.check(self._lib.bbx_design_get_timing(
                 self._h, which, byref(cnt), byref(ms)))

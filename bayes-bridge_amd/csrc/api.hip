@@ -83,7 +83,7 @@ int timer_end(bbx_design* h, int which) {
 
 static int timer_collect(bbx_design* h) {
   BBX_HIP(hipStreamSynchronize(h->stream));
-  for (int which = 0; which < 2; ++which) {
+  for (int which = 0; which < KernelTimer::FAMILIES; ++which) {
     for (auto& pr : h->timer.pending[which]) {
       float ms = 0.f;
       BBX_HIP(hipEventElapsedTime(&ms, pr.a, pr.b));
@@ -499,7 +499,7 @@ int bbx_design_destroy(bbx_design* h) {
   if (!h) return BBX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (int which = 0; which < 2; ++which)
+  for (int which = 0; which < KernelTimer::FAMILIES; ++which)
     for (auto& pr : h->timer.pending[which]) h->timer.pool.push_back(pr);
   for (auto& pr : h->timer.pool) {
     (void)hipEventDestroy(pr.a);
@@ -725,14 +725,17 @@ int bbx_design_set_timing(bbx_design* h, int enabled) {
   if (!enabled && h->timer.enabled) BBX_TRY(timer_collect(h));
   h->timer.enabled = enabled != 0;
   h->timer.period = enabled > 1 ? enabled : 1;
-  h->timer.seen[0] = h->timer.seen[1] = 0;
+  for (auto& v : h->timer.seen) v = 0;
+  // whole-operator brackets sample other launches than the kernel stamps
+  h->timer.seen[2] = h->timer.period / 2;
   return BBX_OK;
 }
 
 static int bbx_design_get_timing_impl(bbx_design* h, int which, int64_t* n_launch,
                           double* total_ms) {
   BBX_TRY(check_handle(h));
-  if (which < 0 || which > 1) return fail(BBX_ERR_INVALID, "which must be 0/1");
+  if (which < 0 || which >= KernelTimer::FAMILIES)
+    return fail(BBX_ERR_INVALID, "which must be 0, 1 or 2");
   BBX_HIP(hipSetDevice(h->device));
   BBX_TRY(timer_collect(h));
   if (n_launch) *n_launch = h->timer.n_launch[which];
@@ -752,7 +755,7 @@ int bbx_design_reset_timing(bbx_design* h) {
   BBX_TRY(check_handle(h));
   BBX_HIP(hipSetDevice(h->device));
   BBX_TRY(timer_collect(h));
-  for (int which = 0; which < 2; ++which) {
+  for (int which = 0; which < KernelTimer::FAMILIES; ++which) {
     h->timer.n_launch[which] = 0;
     h->timer.total_ms[which] = 0.;
   }
@@ -781,15 +784,20 @@ int bbx_design_tiled_info(const bbx_design* h, int which, int* W,
   return tiled_describe(h, which, W, n_block, PR, G, n_quad, n_slice);
 }
 
-int bbx_design_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
-                            int64_t* tdot_bytes) {
+static int matvec_bytes_impl(const bbx_design* h, bool timed_only,
+                             int64_t* dot_bytes, int64_t* tdot_bytes) {
   BBX_TRY(check_handle(h));
   int64_t db = 0, tb = 0;
   if (!h->sparse) {
+    // one pass over the stored matrix + vector in + vector out; the Tdot's
+    // chunk slabs (written by the main kernel, read by the epilogue kernel)
     const int64_t el = h->dense_dtype == BBX_F32 ? 4 : 8;
-    db = tb = h->n * h->P * el + 8 * (h->n + h->P);
+    const int64_t mat = h->n * h->dense_ld * el;
+    const int64_t slab = 8 * (int64_t)h->dense_chunks * h->dense_ld;
+    db = mat + 8 * (h->n + h->P);
+    tb = timed_only ? mat + 8 * h->n + slab : mat + 8 * (h->n + h->P) + 2 * slab;
   } else if (h->format == BBX_FORMAT_TILED) {
-    BBX_TRY(tiled_matvec_bytes(h, &db, &tb));
+    BBX_TRY(tiled_matvec_bytes(h, &db, &tb, timed_only));
   } else {
     // nnz*(b_val+b_idx) + (rows+1)*b_ptr + 8*len(in) + 8*len(out)
     const int64_t bval = h->binary ? 0 : 8;
@@ -798,6 +806,30 @@ int bbx_design_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
   }
   if (dot_bytes) *dot_bytes = db;
   if (tdot_bytes) *tdot_bytes = tb;
+  return BBX_OK;
+}
+
+int bbx_design_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
+                            int64_t* tdot_bytes) {
+  return matvec_bytes_impl(h, false, dot_bytes, tdot_bytes);
+}
+
+int bbx_design_timed_bytes(const bbx_design* h, int64_t* dot_bytes,
+                           int64_t* tdot_bytes) {
+  return matvec_bytes_impl(h, true, dot_bytes, tdot_bytes);
+}
+
+int bbx_design_fused_operator_bytes(const bbx_design* h, int64_t* bytes) {
+  BBX_TRY(check_handle(h));
+  int64_t b = 0;
+  const int64_t ld_max = h->dense_dtype == BBX_F32 ? 8192 : 4096;
+  if (!h->sparse && h->dense_ld <= ld_max && h->n >= 4096) {
+    const int64_t el = h->dense_dtype == BBX_F32 ? 4 : 8;
+    // ONE pass over the matrix, v and Omega in, 256 per-workgroup slabs out
+    b = h->n * h->dense_ld * el + 8 * (h->P + h->n) +
+        8 * (int64_t)256 * h->dense_ld;
+  }
+  if (bytes) *bytes = b;
   return BBX_OK;
 }
 

@@ -93,15 +93,18 @@ struct CGState {
 struct KernelTimer {
   bool enabled = false;
   int period = 1;          // time every period-th launch of each family
-  int64_t seen[2] = {0, 0};
-  bool armed[2] = {false, false};
+  // families: 0 dot kernel(s), 1 Tdot main kernel(s), 2 one whole operator
+  // application of the CG loop (dot + Tdot + epilogue)
+  static constexpr int FAMILIES = 3;
+  int64_t seen[FAMILIES] = {0, 0, 0};
+  bool armed[FAMILIES] = {false, false, false};
   struct Pair {
     hipEvent_t a, b;
   };
-  std::vector<Pair> pending[2];
+  std::vector<Pair> pending[FAMILIES];
   std::vector<Pair> pool;
-  int64_t n_launch[2] = {0, 0};
-  double total_ms[2] = {0., 0.};
+  int64_t n_launch[FAMILIES] = {0, 0, 0};
+  double total_ms[FAMILIES] = {0., 0., 0.};
 };
 
 }  // namespace bbx
@@ -252,8 +255,10 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
                                 const TdotEpilogue& ep, double* d_out);
 int build_tiled(bbx_design* h);
 void destroy_tiled(bbx_design* h);
+// timed_only: count what the timed kernel of each family moves (tiled Tdot:
+// without the epilogue kernel's slab read and P-vector output)
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
-                       int64_t* tdot_bytes);
+                       int64_t* tdot_bytes, bool timed_only = false);
 int64_t tiled_storage_bytes(const bbx_design* h);
 int tiled_describe(const bbx_design* h, int which, int* W, int* n_block,
                    int* PR, int* G, int64_t* n_quad, int64_t* n_slice);

@@ -1468,14 +1468,23 @@ int launch_tdot_main_tiled(bbx_design* h, const double* d_w,
 }
 
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
-                       int64_t* tdot_bytes) {
+                       int64_t* tdot_bytes, bool timed_only) {
   const TiledPair* tp = static_cast<const TiledPair*>(h->tiled);
   if (!tp) return fail(BBX_ERR_STATE, "tiled format not built");
-  // bytes of the format actually read + vector in + vector out (+ slabs)
+  // Whole product: bytes of the format actually read + vector in + vector out
+  // + the partial slabs written by the main kernel and read back by the
+  // epilogue kernel.  Dot with G == 1 is a single kernel; with G > 1 the timer
+  // brackets both kernels, so timed == whole.  Tdot: the timer stamps the main
+  // kernel only (ids + w in + G slabs out); the epilogue kernel (slab read,
+  // P-vector out) is outside it.
   *dot_bytes = tp->x.stream_bytes() + 8 * (h->P + h->n) +
                (tp->x.G > 1 ? 16 * tp->x.G * h->n : 0);
-  *tdot_bytes = tp->xt.stream_bytes() + 8 * (h->n + h->P) +
-                16 * (int64_t)tp->xt.G * h->p;
+  if (timed_only)
+    *tdot_bytes = tp->xt.stream_bytes() + 8 * h->n +
+                  8 * (int64_t)tp->xt.G * h->p;
+  else
+    *tdot_bytes = tp->xt.stream_bytes() + 8 * (h->n + h->P) +
+                  16 * (int64_t)tp->xt.G * h->p;
   return BBX_OK;
 }
 

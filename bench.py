@@ -10,10 +10,15 @@ resident in HBM.  For N > 1 every rank runs its own chain on a full replica of
 X (weak scaling; seeds 111 + rank) and the kept coefficient samples are
 gathered on rank 0 over RCCL once, inside the timed region.
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N
+ranks itself (`python -m torch.distributed.run ... bench.py ...` as a child
+process, before this process touches torch or HIP) and relays rank 0's line.
+
 Prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -29,22 +34,31 @@ CONFIGS = {
     "config3": (1000000, 50000, .002),
     # BASELINE config 4: linear model, dense N(0,1) design stored in f32
     "config4": (200000, 8000, None),
+    # small smoke configuration (launcher dry runs, tests)
+    "tiny": (20000, 1000, .02),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+ALPHA, SLAB = .5, 2.   # demo.ipynb cell 7 prior
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--burnin", type=int, default=40,
+                    help="untimed Gibbs iterations run as part of the chain's "
+                         "initialisation (the reference runs an L-BFGS mode "
+                         "search there, bayesbridge.py:333), so that the CG "
+                         "warm start / preconditioner summaries are "
+                         "stationary when the W warm-up steps begin")
     ap.add_argument("--config", default="config3", choices=sorted(CONFIGS))
     ap.add_argument("--storage", default="auto",
                     choices=["auto", "csr", "tiled"])
-    ap.add_argument("--cpu-baseline-iters", type=int, default=2,
-                    help="Gibbs iterations of the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=5,
+                    help="Gibbs iterations of each CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=111)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def build_dense_problem(torch, cfg, seed, device):
@@ -88,71 +102,106 @@ def build_problem(torch, cfg, seed, device):
                 offset=offset, n_success=n_success)
 
 
-def cpu_baseline(torch, prob, state, n_iters, seed):
-    """Times the CPU oracle (SciPy CSR products + SciPy cg, the primitives the
-    reference runs; one thread) on the SAME matrix, started from the GPU
-    chain's current state, for `n_iters` Gibbs iterations."""
+def cpu_baselines(prob, state, n_iters, seed):
+    """Times the CPU oracle on the SAME matrix, started from the GPU chain's
+    post-warm-up state, for `n_iters` Gibbs iterations each:
+      port      SciPy CSR products + scipy.sparse.linalg.cg -- the primitives
+                the reference runs (single-threaded, like SciPy's SpMV)
+      port-omp  the same chain with OpenMP products and CG on all host cores
+                (oracle/csrc/oracle_cg_omp.cpp); the scalar samplers stay on
+                one thread (their PCG64 streams are sequential)."""
     import numpy as np
     import scipy.sparse as sparse
     from oracle.gibbs import OracleGibbs
+    from oracle.omp_baseline import load as load_omp
+    from oracle.rng import OracleRandom
     from oracle.summarizer import CoefSummarizer
     n, p = prob["n"], prob["p"]
     X = sparse.csr_matrix(
         (np.ones(prob["nnz"]), prob["indices"].cpu().numpy(),
          prob["indptr"].cpu().numpy()), shape=(n, p))
     n_success = prob["n_success"].cpu().numpy()
-    chain = OracleGibbs((n_success, np.ones(n)), X, 'logit',
-                        bridge_exponent=.5, regularizing_slab_size=2.,
-                        use_scipy_cg=True)
-    from oracle.rng import OracleRandom
-    chain.rng = OracleRandom(seed)
-    coef, obs_prec, lscale, gscale, mean, square, n_avg = state
-    summ = CoefSummarizer(chain.P, chain.nu, chain.slab)
-    summ.set_state({'mean': mean, 'square': square, 'n_averaged': n_avg})
-    n_cg = []
-    t0 = time.perf_counter()
-    for _ in range(n_iters):
-        coef, info = chain.draw_coef(obs_prec, gscale, lscale, summ)
-        obs_prec = chain.draw_obs_prec(coef)
-        gscale = chain.draw_gscale(coef[chain.nu:])
-        lscale = chain.draw_lscale(gscale, coef[chain.nu:])
-        chain.logp(coef, gscale, obs_prec)
-        n_cg.append(info['n_iter'])
-    dt = time.perf_counter() - t0
-    return dict(value=n_iters / dt, unit="Gibbs iters/sec", cores=1,
-                kind="port",
-                sample="%d Gibbs iterations of the NumPy/SciPy oracle "
-                       "(scipy.sparse CSR @, .T @, scipy.sparse.linalg.cg; C "
-                       "Polya-Gamma/tilted-stable) on the same %dx%d nnz=%d "
-                       "design from the GPU chain's post-warm-up state; mean "
-                       "n_cg=%.1f; %.1f s" % (
-                           n_iters, n, p, prob["nnz"],
-                           float(np.mean(n_cg)), dt),
-                host_cores=os.cpu_count())
+    coef0, obs0, ls0, g0, mean, square, n_avg = state
+    host_cores = os.cpu_count()
+    omp_cores = min(load_omp().oracle_omp_max_threads(), host_cores or 1)
+
+    def run(kind, cores, **kw):
+        chain = OracleGibbs((n_success, np.ones(n)), X, 'logit',
+                            bridge_exponent=ALPHA,
+                            regularizing_slab_size=SLAB, **kw)
+        chain.rng = OracleRandom(seed)
+        summ = CoefSummarizer(chain.P, chain.nu, chain.slab)
+        summ.set_state({'mean': mean, 'square': square, 'n_averaged': n_avg})
+        coef, obs_prec, lscale, gscale = coef0, obs0, ls0, g0
+        n_cg = []
+        t0 = time.perf_counter()
+        for _ in range(n_iters):
+            coef, info = chain.draw_coef(obs_prec, gscale, lscale, summ)
+            obs_prec = chain.draw_obs_prec(coef)
+            gscale = chain.draw_gscale(coef[chain.nu:])
+            lscale = chain.draw_lscale(gscale, coef[chain.nu:])
+            chain.logp(coef, gscale, obs_prec)
+            n_cg.append(info['n_iter'])
+        dt = time.perf_counter() - t0
+        what = ("scipy.sparse CSR @, .T @, scipy.sparse.linalg.cg"
+                if kind == "port" else
+                "OpenMP CSR / CSR-of-X^T products and CG loop in C++")
+        return dict(value=round(n_iters / dt, 5), unit="Gibbs iters/sec",
+                    cores=cores, kind=kind,
+                    sample="%d Gibbs iterations of the CPU oracle chain (%s; "
+                           "C Polya-Gamma/tilted-stable samplers on 1 "
+                           "thread) on the same %dx%d nnz=%d design from the "
+                           "GPU chain's post-warm-up state; mean n_cg=%.1f; "
+                           "%.1f s" % (n_iters, what, n, p, prob["nnz"],
+                                       float(np.mean(n_cg)), dt),
+                    host_cores=host_cores)
+    port = run("port", 1, use_scipy_cg=True)
+    omp = run("port-omp", omp_cores, omp_threads=omp_cores)
+    return port, omp
 
 
 def committed_traffic(design, which, cfg):
     """HBM bytes per launch of the dominant kernel from the committed PMC
-    passes (profiles/r01_spmv_profile.json; FETCH_SIZE doubled per the gfx950
-    correction + WRITE_SIZE), matched by launch grid; None when no profile of
-    this workload/geometry is committed."""
+    passes (profiles/r0N_spmv_profile.json; FETCH_SIZE doubled per the gfx950
+    correction + WRITE_SIZE), matched by launch grid.  NOT measured in this
+    run: PMC collection needs its own rocprofv3 passes.  (bytes, source) or
+    (None, None) when no profile of this workload/geometry is committed."""
     if cfg != "config3" or design.storage_format != "tiled":
-        return None
-    path = os.path.join(ROOT, "profiles", "r01_spmv_profile.json")
-    if not os.path.exists(path):
-        return None
+        return None, None
     info = design.tiled_info()["X" if which == "dot" else "Xt"]
     n, P = design.shape
     rows = n if which == "dot" else P - 1
     n_wg = -(-rows // info["PR"]) * info["G"]
-    with open(path) as fh:
-        prof = json.load(fh)
-    entry = prof.get("hbm_traffic", {}).get("grid=%d" % n_wg)
-    return int(entry["total_bytes"]) if entry else None
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_spmv_profile.json" % tag)
+        if not os.path.exists(path):
+            continue
+        with open(path) as fh:
+            prof = json.load(fh)
+        entry = prof.get("hbm_traffic", {}).get("grid=%d" % n_wg)
+        if entry:
+            return int(entry["total_bytes"]), \
+                "profiles/%s_spmv_profile.json (separate rocprofv3 --pmc " \
+                "passes of the same kernel and matrix; not collected in " \
+                "this run)" % tag
+    return None, None
 
 
 def main():
     args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # self-launch: nothing here has imported torch or touched HIP yet
+        from bayesbridge_amd.chains import launch_ranks
+        assert "torch" not in sys.modules
+        sys.exit(launch_ranks(args.gpus, [os.path.abspath(__file__)]
+                              + sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d does not match WORLD_SIZE=%s "
+                         "(launch with --nproc-per-node %d, or let bench.py "
+                         "launch the ranks itself by unsetting WORLD_SIZE)\n"
+                         % (args.gpus, env_world, args.gpus))
+        sys.exit(2)
     # stdout carries exactly ONE line (the JSON result of rank 0): libraries
     # that write to file descriptor 1 (gloo's connection notes, rocm tools)
     # are sent to stderr for the duration of the run
@@ -161,47 +210,45 @@ def main():
     os.dup2(2, 1)
     import numpy as np
     import torch
-    from ctypes import byref, c_double, c_int64, c_void_p
-    from bayesbridge_amd import (BayesBridge, HipSparseDesignMatrix, _lib,
-                                 chains)
+    from bayesbridge_amd import (HipDenseDesignMatrix, HipGibbsChain,
+                                 HipSparseDesignMatrix, _lib, chains)
     rank, world, local_rank = chains.init_process_group_from_env()
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
     n_dev = torch.cuda.device_count()
+    backend = None
+    if world > 1:
+        import torch.distributed as dist
+        backend = dist.get_backend()
+        if n_dev >= world:
+            # one rank per GPU over RCCL (backend 'nccl' IS RCCL on ROCm)
+            assert backend == "nccl", backend
+            assert local_rank < n_dev
     dev_index = local_rank % max(n_dev, 1)   # == local_rank on a full node
     torch.cuda.set_device(dev_index)
     device = "cuda:%d" % dev_index
-    lib = _lib.load()
+    if world > 1 and n_dev >= world:
+        # every rank really sits on its own device
+        ids = [None] * world
+        import torch.distributed as dist
+        dist.all_gather_object(ids, dev_index)
+        assert len(set(ids)) == world, ids
 
     dense = args.config == "config4"
-    chain = c_void_p()
-    import math
-    unit = math.gamma(2 / .5) / math.gamma(1 / .5)   # prior.py:163-167
-    sd_unshrunk = np.array([np.inf])
+    unit = math.gamma(2 / ALPHA) / math.gamma(1 / ALPHA)   # prior.py:163-167
+    seed_k = chains.chain_seed(args.seed, rank)
     if dense:
-        from bayesbridge_amd.design_matrix import (HipDenseDesignMatrix,
-                                                   HipDesignMatrix)
         prob = build_dense_problem(torch, args.config, args.seed, device)
         n, p, nnz = prob["n"], prob["p"], prob["nnz"]
-        design = HipDenseDesignMatrix.__new__(HipDenseDesignMatrix)
-        HipDesignMatrix.__init__(design)
-        design.centered, design.intercept_added = True, True
-        design.column_offset = None
         torch.cuda.synchronize()
-        _lib.check(lib.bbx_design_create_dense_dev(
-            n, p, c_void_p(prob["X"].data_ptr()), _lib.F32, _lib.F32,
-            c_void_p(prob["offset"].data_ptr()), 1, dev_index,
-            byref(design._h)))
+        design = HipDenseDesignMatrix.from_device_array(
+            n, p, prob["X"].data_ptr(), prob["offset"].data_ptr(),
+            add_intercept=True, device=dev_index, in_dtype='float32',
+            storage_dtype='float32')
         del prob["X"]
-        P = p + 1
         outcome = prob["y"].cpu().numpy()
-        _lib.check(lib.bbx_chain_create(
-            design.handle, _lib.MODEL_LINEAR,
-            outcome.ctypes.data_as(c_void_p), None, 1,
-            sd_unshrunk.ctypes.data_as(c_void_p), .5, 2., 0., 0.,
-            chains.chain_seed(args.seed, rank), byref(chain)))
-        coef0 = np.zeros(P)
-        coef0[0] = outcome.mean()
+        chain = HipGibbsChain(design, 'linear', outcome,
+                              bridge_exponent=ALPHA, slab_size=SLAB,
+                              seed=seed_k)
+        intercept0 = outcome.mean()
     else:
         prob = build_problem(torch, args.config, args.seed, device)
         n, p, nnz = prob["n"], prob["p"], prob["nnz"]
@@ -210,51 +257,32 @@ def main():
             n, p, nnz, prob["indptr"].data_ptr(), prob["indices"].data_ptr(),
             None, prob["offset"].data_ptr(), add_intercept=True,
             device=dev_index, storage=args.storage)
-        P = p + 1
         # chain: prior and init of the reference demo (demo.ipynb cells 7, 9)
         n_success = prob["n_success"].cpu().numpy()
-        _lib.check(lib.bbx_chain_create(
-            design.handle, _lib.MODEL_LOGIT,
-            n_success.ctypes.data_as(c_void_p), None, 1,
-            sd_unshrunk.ctypes.data_as(c_void_p), .5, 2., 0., 0.,
-            chains.chain_seed(args.seed, rank), byref(chain)))
-        coef0 = np.zeros(P)
+        chain = HipGibbsChain(design, 'logit', n_success,
+                              bridge_exponent=ALPHA, slab_size=SLAB,
+                              seed=seed_k)
         ph = n_success.mean()
-        coef0[0] = math.log(ph / (1 - ph))               # intercept MLE
-    lscale0 = np.ones(P - 1) * unit
-    g0 = c_double(.01 / unit)                        # init global_scale=.01
-    _lib.check(lib.bbx_chain_set_state(
-        chain, coef0.ctypes.data_as(c_void_p), None,
-        lscale0.ctypes.data_as(c_void_p), byref(g0)))
-    _lib.check(lib.bbx_chain_init_obs_prec(chain))
+        intercept0 = math.log(ph / (1 - ph))             # intercept MLE
+    P = p + 1
+    coef0 = np.zeros(P)
+    coef0[0] = intercept0
+    # init global_scale=.01 in the user parametrisation (prior.py:129-141)
+    chain.set_state(coef0, None, np.ones(P - 1) * unit, .01 / unit)
+    chain.init_obs_prec()
 
-    K, W = args.steps, args.warmup
-    ncg_w = np.zeros(max(W, 1))
-    if W > 0:
-        _lib.check(lib.bbx_chain_run(chain, W, 0, 1, 500, 0., None, None, None,
-                                     None, None,
-                                     ncg_w.ctypes.data_as(c_void_p)))
-    # state after warm-up (for the CPU baseline)
+    K, W, B = args.steps, args.warmup, args.burnin
+    ncg_b = chain.run_device(B)[2] if B > 0 else np.zeros(0)
+    ncg_w = chain.run_device(W)[2] if W > 0 else np.zeros(0)
+    # state after warm-up (for the CPU baselines)
     state = None
     if rank == 0 and world == 1 and args.cpu_baseline_iters > 0 and not dense:
-        coef = np.empty(P)
-        obs = np.empty(n)
-        ls = np.empty(P - 1)
-        g = c_double()
-        _lib.check(lib.bbx_chain_get_state(
-            chain, coef.ctypes.data_as(c_void_p),
-            obs.ctypes.data_as(c_void_p), ls.ctypes.data_as(c_void_p),
-            byref(g)))
-        mean, square, navg = np.empty(P), np.empty(P), c_int64()
-        _lib.check(lib.bbx_chain_get_summary(
-            chain, mean.ctypes.data_as(c_void_p),
-            square.ctypes.data_as(c_void_p), byref(navg)))
-        state = (coef, obs, ls, float(g.value), mean, square,
-                 int(navg.value))
+        coef, obs, ls, g = chain.get_state()
+        mean, square, navg = chain.get_summary()
+        state = (coef, obs, ls, g, mean, square, navg)
 
     d_coef = torch.empty((max(K, 1), P), dtype=torch.float64, device=device)
-    gs, lp, ncg = np.zeros(max(K, 1)), np.zeros(max(K, 1)), np.zeros(max(K, 1))
-    # HIP events around one dot/Tdot launch in 16 (timing every launch costs
+    # kernel stamps / brackets on one launch in 16 (timing every launch costs
     # ~10% of the iteration; DESIGN.md "Measurement")
     design.set_timing(True, every=16)
     design.reset_timing()
@@ -265,10 +293,7 @@ def main():
     chains.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    _lib.check(lib.bbx_chain_run(
-        chain, K, 0, 1, 500, 0., c_void_p(d_coef.data_ptr()), None, None,
-        gs.ctypes.data_as(c_void_p), lp.ctypes.data_as(c_void_p),
-        ncg.ctypes.data_as(c_void_p)))
+    gs, lp, ncg, _ = chain.run_device(K, d_coef_ptr=d_coef.data_ptr())
     gathered = chains.gather_chain_samples(d_coef, dst=0)
     chains.barrier()
     torch.cuda.synchronize()
@@ -280,33 +305,77 @@ def main():
     if rank == 0:
         assert gathered is not None and gathered.shape[0] == world
         assert bool(torch.isfinite(gathered).all())
-        dot_b, tdot_b = design.matvec_bytes
+        assert np.all(np.isfinite(lp)) and np.all(gs > 0)
+        ms_step = 1e3 * elapsed / K
+        mean_ncg = float(ncg.mean())
+        dot_tb, tdot_tb = design.timed_bytes      # what the stamps cover
+        dot_wb, tdot_wb = design.matvec_bytes     # whole products
+        fused_b = design.fused_operator_bytes if dense else 0
         per = {}
-        for name, b in (("dot", dot_b), ("tdot", tdot_b)):
+        for name, b in (("dot", dot_tb), ("tdot", tdot_tb)):
             cnt, ms = timing[name]
             avg_ms = ms / max(cnt, 1)
             per[name] = dict(launches=cnt, avg_ms=avg_ms, bytes=b,
                              gbs=b / avg_ms / 1e6 if avg_ms > 0 else 0.)
+        if dense and fused_b:
+            # inside the CG loop family 0 is the single-pass operator kernel
+            per["dot"]["bytes"] = fused_b
+            per["dot"]["gbs"] = fused_b / per["dot"]["avg_ms"] / 1e6
         dom = "dot" if timing["dot"][1] >= timing["tdot"][1] else "tdot"
         ach = per[dom]["gbs"]
-        traffic = committed_traffic(design, dom, args.config)
+        traffic, traffic_src = committed_traffic(design, dom, args.config)
+        # whole operator application (dot + Tdot + epilogue kernel)
+        op_cnt, op_ms = timing["operator"]
+        op_avg = op_ms / max(op_cnt, 1)
+        if dense and fused_b:
+            ld = -(-P // 8) * 8       # + the epilogue's slab read and output
+            op_bytes = fused_b + 8 * 256 * ld + 8 * P
+        else:
+            op_bytes = dot_wb + tdot_wb
+        op_gbs = op_bytes / op_avg / 1e6 if op_avg > 0 else 0.
+        # whole Gibbs iteration: (n_cg + 1) operator applications (warm start),
+        # the RHS Tdot, the linear predictor of the Omega update, 12 P-vector
+        # passes per CG iteration (direction 6, update 6), ~64 bytes per row
+        # and ~30 P-vector passes for the eta draws and the chain kernels
+        iter_bytes = ((mean_ncg + 1) * op_bytes + dot_wb + tdot_wb
+                      + mean_ncg * 12 * 8 * P + 64 * n + 30 * 8 * P)
+        iter_gbs = iter_bytes / ms_step / 1e6
         # measured on this box, same size as one launch's algorithmic bytes
         # and at 2 GB: what a plain streaming kernel reaches
         probe_small = _lib.hbm_probe(int(per[dom]["bytes"]), 50, dev_index)
         probe_large = _lib.hbm_probe(2 << 30, 10, dev_index)
+        kernel_name = ("operator X^T(Omega(X v)), one pass (dense f32)"
+                       if dense and fused_b and dom == "dot"
+                       else dom + " (" + design.storage_format + ")")
         roofline = dict(
             bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
             unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
+            traffic_source=traffic_src,
+            kernel=kernel_name,
+            avg_launch_ms=round(per[dom]["avg_ms"], 5),
+            algorithmic_bytes_per_launch=per[dom]["bytes"],
+            timing="kernel begin/end stamps (hipExtLaunchKernelGGL events) on "
+                   "the launching stream, one launch in 16, inside the timed "
+                   "region" if design.storage_format == "tiled" else
+                   "hipEventRecord bracket on the launching stream, one launch "
+                   "in 16, inside the timed region",
+            operator_frac=round(op_gbs / HBM_PEAK_GBS, 4),
+            operator=dict(avg_ms=round(op_avg, 5), bytes=int(op_bytes),
+                          gbs=round(op_gbs, 1), launches=op_cnt,
+                          what="one application of the CG operator: dot + "
+                               "Tdot + epilogue kernel, event bracket"),
+            iteration_frac=round(iter_gbs / HBM_PEAK_GBS, 4),
+            iteration=dict(bytes=int(iter_bytes), gbs=round(iter_gbs, 1),
+                           what="algorithmic bytes of one whole Gibbs "
+                                "iteration / ms_per_step"),
             stream_probe_gbs={
                 "read_same_bytes": round(probe_small[0], 1),
                 "copy_same_bytes": round(probe_small[1], 1),
                 "read_2GiB": round(probe_large[0], 1),
                 "copy_2GiB": round(probe_large[1], 1)},
-            kernel=dom + " (" + design.storage_format + ")",
-            avg_launch_ms=round(per[dom]["avg_ms"], 5),
-            algorithmic_bytes_per_launch=per[dom]["bytes"],
             other={k: dict(avg_ms=round(v["avg_ms"], 5),
-                           gbs=round(v["gbs"], 1), launches=v["launches"])
+                           gbs=round(v["gbs"], 1), launches=v["launches"],
+                           bytes=v["bytes"])
                    for k, v in per.items()})
         line = {
             "metric": "Gibbs iters/sec (cg sampler)",
@@ -315,7 +384,7 @@ def main():
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": round(1e3 * elapsed / K, 4),
+            "ms_per_step": round(ms_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -333,22 +402,31 @@ def main():
                     % (args.config, n, p, nnz, CONFIGS[args.config][2],
                        args.seed)),
                 "storage": design.storage_format,
-                "mean_n_cg_iter": round(float(ncg[:K].mean()), 2),
-                "mean_n_cg_iter_warmup": round(float(ncg_w[:W].mean()), 2)
+                "init": "coef=0 + intercept MLE, global_scale=.01, then %d "
+                        "untimed burn-in iterations (in place of the "
+                        "reference's L-BFGS mode search)" % B,
+                "mean_n_cg_iter": round(mean_ncg, 2),
+                "mean_n_cg_iter_warmup": round(float(ncg_w.mean()), 2)
                 if W > 0 else None,
+                "mean_n_cg_iter_burnin": round(float(ncg_b.mean()), 2)
+                if B > 0 else None,
                 "parallelism": "chains=%d" % world,
                 "devices": min(world, n_dev),
+                "backend": backend,
+                "rccl_ranks": world if backend == "nccl" else 0,
             },
             "roofline": roofline,
         }
         if state is not None:
-            line["cpu_baseline"] = cpu_baseline(
-                torch, prob, state, args.cpu_baseline_iters, args.seed)
+            port, omp = cpu_baselines(prob, state, args.cpu_baseline_iters,
+                                      args.seed)
+            line["cpu_baseline"] = port
+            line["cpu_baseline_omp"] = omp
         else:
             line["cpu_baseline"] = None
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
-    lib.bbx_chain_destroy(chain)
+    chain.close()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -144,6 +144,17 @@ int bbx_design_storage_bytes(const bbx_design* h, int64_t* bytes);
  * read (nnz*(b_val+b_idx) + row pointers + in + out). */
 int bbx_design_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
                             int64_t* tdot_bytes);
+/* The part of those bytes that the kernels TIMED by bbx_design_get_timing
+ * (which = 0 / 1) move.  Differs from bbx_design_matvec_bytes where a product
+ * is more than one kernel and only the main one is stamped: the tiled and
+ * dense Tdot write partial slabs that a separate epilogue kernel adds up
+ * (the epilogue's slab read and its P-vector output are not counted here). */
+int bbx_design_timed_bytes(const bbx_design* h, int64_t* dot_bytes,
+                           int64_t* tdot_bytes);
+/* Algorithmic bytes of the single-pass dense operator kernel X^T(Omega (X v))
+ * (dense designs that qualify for it; 0 otherwise): one pass over the stored
+ * matrix + v + Omega + the per-workgroup slabs it writes. */
+int bbx_design_fused_operator_bytes(const bbx_design* h, int64_t* bytes);
 
 /* Geometry of the tiled format (BBX_FORMAT_TILED only): which = 0 for X, 1 for
  * X^T; W = column-block width, n_block = column blocks, PR = rows per panel,
@@ -241,7 +252,10 @@ int bbx_design_reset_matvec_count(bbx_design* h);
 int bbx_design_set_timing(bbx_design* h, int enabled);
 /* Resolves all pending event pairs (synchronises the stream) and returns the
  * number of timed launches and their summed device time per kernel family:
- * which = 0 dot (X v), 1 Tdot (X^T w). */
+ * which = 0 dot (X v; for dense designs inside the CG loop: the single-pass
+ * operator kernel), 1 Tdot (X^T w, main kernel), 2 one whole application of
+ * the CG operator (dot + Tdot + epilogue; bracketed by two record commands,
+ * which adds ~2-3 us of dispatch to the interval). */
 int bbx_design_get_timing(bbx_design* h, int which, int64_t* n_launch,
                           double* total_ms);
 int bbx_design_reset_timing(bbx_design* h);

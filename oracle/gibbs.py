@@ -89,10 +89,17 @@ class OracleGibbs:
                  sd_for_intercept=float('inf'),
                  regularizing_slab_size=float('inf'),
                  gscale_shape=0., gscale_rate=0., add_intercept=True,
-                 center_predictor=True, use_scipy_cg=False):
+                 center_predictor=True, use_scipy_cg=False, omp_threads=None):
         self.family = family
-        self.design = make_design(X, add_intercept=add_intercept,
-                                  center_predictor=center_predictor)
+        if omp_threads is not None:
+            # multi-core baseline: OpenMP products and CG (omp_baseline.py)
+            from .omp_baseline import OmpSparseDesign
+            self.design = OmpSparseDesign(
+                X, center_predictor=center_predictor,
+                add_intercept=add_intercept, n_threads=omp_threads)
+        else:
+            self.design = make_design(X, add_intercept=add_intercept,
+                                      center_predictor=center_predictor)
         if family == 'logit':
             n_success, n_trial = outcome
             self.outcome = (np.asarray(n_success, dtype=np.float64),
@@ -170,9 +177,13 @@ class OracleGibbs:
         eta1 = np.random.randn(self.n)                   # cg_sampler.py:61-62
         eta2 = np.random.randn(self.P)
         atol = 10e-6 * np.sqrt(self.P)
-        coef, info = cg_sample(self.design, omega, phi, z, x0, sd, self.nu,
-                               eta1, eta2, 500, atol,
-                               use_scipy=self.use_scipy_cg)
+        if hasattr(self.design, 'cg_sample'):
+            coef, info = self.design.cg_sample(omega, phi, z, x0, sd, self.nu,
+                                               eta1, eta2, 500, atol)
+        else:
+            coef, info = cg_sample(self.design, omega, phi, z, x0, sd, self.nu,
+                                   eta1, eta2, 500, atol,
+                                   use_scipy=self.use_scipy_cg)
         summ.update(coef, gscale, lscale)
         if record is not None:
             record.append(dict(obs_prec=omega.copy(), prior_prec_sqrt=phi,

@@ -1,7 +1,7 @@
 """CPU, world_size 2 over gloo: the multi-chain plumbing (per-rank seeds, the
-single gather of samples at the end, max-over-ranks timing) that the 8-GPU
-bench runs over RCCL.  The data path has no collective; this covers the only
-exchange step."""
+single gather of samples at the end, max-over-ranks timing, the rank launcher)
+that the 8-GPU bench runs over RCCL.  The data path has no collective; this
+covers the only exchange step."""
 import os
 import subprocess
 import sys
@@ -44,17 +44,94 @@ WORKER = textwrap.dedent("""
 
 
 def test_two_rank_gather_over_gloo(tmp_path):
+    from bayesbridge_amd import chains
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ)
-    env["MASTER_ADDR"] = "127.0.0.1"
-    out = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-         "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
-         "29533", str(script)],
-        env=env, capture_output=True, text=True, timeout=300)
+    out = chains.launch_ranks(2, [str(script)], capture=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "GATHER_OK" in out.stdout
+
+
+RUN_CHAINS_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, os.path.join(%(root)r, "bayes-bridge_amd"))
+    import numpy as np
+    from bayesbridge_amd import chains
+
+    class FakeBridge:
+        # stands in for BayesBridge on a CPU-only box: gibbs() returns samples
+        # that depend on the seed only
+        def gibbs(self, n_iter, n_burnin, thin, seed=None, init=None,
+                  params_to_save=None, coef_sampler_type=None, options=None):
+            rng = np.random.default_rng(seed)
+            ns = (n_iter - n_burnin) // thin
+            s = {'coef': rng.standard_normal((6, ns)),
+                 'global_scale': rng.random(ns), 'logp': rng.random(ns)}
+            return s, {'_reg_coef_sampling_info':
+                       {'n_cg_iter': np.full(ns, float(seed))}, 'seed': seed}
+
+    rank, world, _ = chains.init_process_group_from_env(backend="gloo")
+    merged, infos = chains.run_chains(FakeBridge(), %(n_chain)d, 8, n_burnin=2,
+                                      thin=2, seed=111)
+    assert [i['chain'] for i in infos] == chains.split_chains(
+        %(n_chain)d, world, rank)
+    if rank == 0:
+        assert merged['coef'].shape == (%(n_chain)d, 6, 3)
+        for k in range(%(n_chain)d):
+            rng = np.random.default_rng(111 + k)
+            assert np.array_equal(merged['coef'][k],
+                                  rng.standard_normal((6, 3)))
+            assert np.all(merged['n_cg_iter'][k] == 111 + k)
+        print("CHAINS_OK")
+    else:
+        assert merged is None
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+""")
+
+
+def test_run_chains_shares_chains_over_two_ranks(tmp_path):
+    """config 5's plumbing: chain k gets seed 111 + k whichever rank runs it,
+    odd chain counts pad, one gather per saved parameter."""
+    from bayesbridge_amd import chains
+    for n_chain in (4, 5):
+        script = tmp_path / ("chains%d.py" % n_chain)
+        script.write_text(RUN_CHAINS_WORKER % {"root": ROOT,
+                                               "n_chain": n_chain})
+        out = chains.launch_ranks(2, [str(script)], capture=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "CHAINS_OK" in out.stdout
+    # and without a process group: all chains on this process
+    script = tmp_path / "chains_single.py"
+    script.write_text(RUN_CHAINS_WORKER % {"root": ROOT, "n_chain": 3})
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, str(script)], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "CHAINS_OK" in out.stdout
+
+
+def test_bench_rejects_a_gpus_world_size_mismatch():
+    """`--gpus` must equal the launcher's WORLD_SIZE; checked before torch or
+    HIP is touched, so this runs anywhere."""
+    env = dict(os.environ)
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"],
+        env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2
+    assert "does not match WORLD_SIZE" in out.stderr
+    assert out.stdout.strip() == ""
+
+
+def test_importing_the_launcher_does_not_import_torch():
+    code = ("import sys; sys.path.insert(0, %r); "
+            "import bayesbridge_amd.chains; "
+            "assert 'torch' not in sys.modules" %
+            os.path.join(ROOT, "bayes-bridge_amd"))
+    assert subprocess.run([sys.executable, "-c", code]).returncode == 0
 
 
 def test_single_process_helpers_need_no_group():
