@@ -66,6 +66,9 @@ def _declare(lib):
         "bbx_design_tdot": ([hp, c_void_p, c_void_p], c_int),
         "bbx_design_dot_dev": ([hp, c_void_p, c_void_p], c_int),
         "bbx_design_tdot_dev": ([hp, c_void_p, c_void_p], c_int),
+        "bbx_design_gram_matvec": ([hp, c_void_p, c_void_p, c_void_p], c_int),
+        "bbx_design_gram_matvec_dev": (
+            [hp, c_void_p, c_void_p, c_void_p], c_int),
         "bbx_design_stream": ([hp, POINTER(c_void_p)], c_int),
         "bbx_design_synchronize": ([hp], c_int),
         "bbx_cg_sample": (

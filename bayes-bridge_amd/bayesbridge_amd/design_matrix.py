@@ -161,6 +161,21 @@ class HipDesignMatrix():
         _lib.check(self._lib.bbx_design_tdot(self._h, _ptr(w), _ptr(out)))
         return out
 
+    def gram_matvec(self, obs_prec, v):
+        """X~^T (obs_prec * (X~ v)) in one library call: the data part of the
+        CG operator (cg_sampler.py:106-109), through the launches the CG loop
+        uses."""
+        n, P = self.shape
+        w = np.ascontiguousarray(np.broadcast_to(
+            np.asarray(obs_prec, dtype=np.float64), (n,)))
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        if v.shape != (P,):
+            raise ValueError("gram_matvec expects a vector of length %d" % P)
+        out = np.empty(P, dtype=np.float64)
+        _lib.check(self._lib.bbx_design_gram_matvec(
+            self._h, _ptr(w), _ptr(v), _ptr(out)))
+        return out
+
     def memoize_dot(self, flag=True):
         """abstract_matrix.py:41-47."""
         self.memoized = flag

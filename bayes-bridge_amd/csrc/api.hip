@@ -604,6 +604,48 @@ int bbx_design_tdot(bbx_design* h, const double* w, double* out) {
   return BBX_OK;
 }
 
+// out[P] = X~^T (obs_prec .* (X~ v)) through the launches the CG loop uses
+// (single-pass kernel for dense designs that qualify, else dot + Tdot).
+static int gram_matvec_device(bbx_design* h, const double* d_obs_prec,
+                              const double* d_v, double* d_out) {
+  TdotEpilogue ep;  // TD_PLAIN
+  if (!h->sparse) {
+    const int st = launch_operator_dense_fused(h, d_v, d_obs_prec, ep, d_out);
+    if (st <= 0) return st;
+  }
+  BBX_TRY(launch_prep_v(h, d_v, nullptr, nullptr, part_slot(h, PS_C)));
+  double* t = h->w_n[0].as<double>();
+  BBX_TRY(launch_dot(h, d_v, d_obs_prec, t, part_slot(h, PS_SUMW)));
+  return launch_tdot(h, t, part_slot(h, PS_SUMW), ep, d_out);
+}
+
+int bbx_design_gram_matvec_dev(bbx_design* h, const double* d_obs_prec,
+                               const double* d_v, double* d_out) {
+  BBX_TRY(check_handle(h));
+  if (!d_obs_prec || !d_v || !d_out) return fail(BBX_ERR_INVALID, "NULL vector");
+  BBX_HIP(hipSetDevice(h->device));
+  return gram_matvec_device(h, d_obs_prec, d_v, d_out);
+}
+
+int bbx_design_gram_matvec(bbx_design* h, const double* obs_prec,
+                           const double* v, double* out) {
+  BBX_TRY(check_handle(h));
+  if (!obs_prec || !v || !out) return fail(BBX_ERR_INVALID, "NULL vector");
+  BBX_HIP(hipSetDevice(h->device));
+  double* d_w = h->stage_n.as<double>();
+  double* d_v = h->stage_P.as<double>();
+  double* d_o = h->stage_P.as<double>() + h->P;
+  BBX_HIP(hipMemcpyAsync(d_w, obs_prec, sizeof(double) * (size_t)h->n,
+                         hipMemcpyHostToDevice, h->stream));
+  BBX_HIP(hipMemcpyAsync(d_v, v, sizeof(double) * (size_t)h->P,
+                         hipMemcpyHostToDevice, h->stream));
+  BBX_TRY(gram_matvec_device(h, d_w, d_v, d_o));
+  BBX_HIP(hipMemcpyAsync(out, d_o, sizeof(double) * (size_t)h->P,
+                         hipMemcpyDeviceToHost, h->stream));
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  return BBX_OK;
+}
+
 static int bbx_cg_sample_dev_impl(bbx_design* h, const double* d_obs_prec,
                       const double* d_prior_prec_sqrt, const double* d_z,
                       const double* d_x0, const double* d_precond_sd,

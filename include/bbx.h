@@ -186,6 +186,20 @@ int bbx_design_tdot(bbx_design* h, const double* w, double* out);
 int bbx_design_dot_dev(bbx_design* h, const double* d_v, double* d_out);
 int bbx_design_tdot_dev(bbx_design* h, const double* d_w, double* d_out);
 
+/*
+ * out[P] = X~^T (obs_prec .* (X~ v)): the data part of the CG operator
+ * (the closure at cg_sampler.py:106-109 without the diagonal scalings; also the
+ * Hessian-matvec of the likelihood, logistic_model.py:62-78), issued through
+ * the same launches the CG loop uses -- for dense designs that qualify this is
+ * the single-pass kernel, so the entry lets a test compare it with the two
+ * separate products.  Host pointers, synchronous; `_dev`: device pointers,
+ * asynchronous on the handle's stream.
+ */
+int bbx_design_gram_matvec(bbx_design* h, const double* obs_prec,
+                           const double* v, double* out);
+int bbx_design_gram_matvec_dev(bbx_design* h, const double* d_obs_prec,
+                               const double* d_v, double* d_out);
+
 /* The hipStream_t (as void*) every kernel of this handle is launched on, and a
  * blocking wait on it. */
 int bbx_design_stream(bbx_design* h, void** stream);

@@ -30,6 +30,10 @@ Files written (all small .npz/.npy):
       RNG chain).  The design itself is NOT stored: the tests regenerate it
       with bayesbridge_amd.simulate (an exact replay of the reference's RNG
       calls) and check it against the checksums kept here.
+  chain_linear_dense_4000x800_f32repr.npz
+      BASELINE config 4 scaled down (linear, dense N(0,1) 4000 x 800 with
+      f32-representable entries, demo prior, seed 111): all 10 samples of a
+      reference run, replayed through the f32-stored dense operator.
 """
 import os
 import sys
@@ -264,7 +268,39 @@ def config2_small_summary():
           'gscale mean', samples['global_scale'][n_burn:].mean())
 
 
+def config4_small():
+    """BASELINE config 4 scaled down 50x10 (linear, dense N(0,1) design whose
+    entries are f32-representable, so that an f32-stored operator holds the
+    same X): all 10 samples of a reference run with the demo prior."""
+    n, p = 4000, 800
+    np.random.seed(111)
+    X = np.random.randn(n, p).astype(np.float32).astype(np.float64)
+    beta = np.zeros(p)
+    beta[:5], beta[5:10], beta[10:15] = 1.5, 1., .5
+    y = refsim.simulate_outcome(X, beta, 'linear', seed=1)
+    bridge = BayesBridge(
+        RegressionModel(y, X.copy(), 'linear'),
+        RegressionCoefPrior(bridge_exponent=.5, regularizing_slab_size=2.))
+    samples, info = bridge.gibbs(10, 0, init={'global_scale': .01},
+                                 coef_sampler_type='cg', seed=111,
+                                 params_to_save='all')
+    np.savez_compressed(
+        os.path.join(HERE, 'chain_linear_dense_4000x800_f32repr.npz'),
+        shape=np.array([n, p]), X_head=X[:4, :4], X_sum=X.sum(),
+        y_head=y[:8], y_sum=y.sum(), coef_samples=samples['coef'],
+        global_scale_samples=samples['global_scale'],
+        obs_prec_samples=samples['obs_prec'], logp_samples=samples['logp'],
+        n_cg_iter=info['_reg_coef_sampling_info']['n_cg_iter'])
+    print('config 4 (scaled) chain written, n_cg',
+          info['_reg_coef_sampling_info']['n_cg_iter'])
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1:          # regenerate selected fixtures only
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
+    config4_small()
     golden_chain('linear', 'dense')
     golden_chain('logit', 'sparse')
     operator_cases()

@@ -137,3 +137,33 @@ def test_c_csr_products_match_scipy():
     w = np.random.default_rng(1).standard_normal(300)
     assert np.abs(orng.csr_matvec(X, v) - X @ v).max() <= 1e-12
     assert np.abs(orng.csr_rmatvec(X, w) - X.T @ w).max() <= 1e-12
+
+
+def config4_small_problem(golden_dir):
+    """The scaled BASELINE config 4 problem of
+    chain_linear_dense_4000x800_f32repr.npz (design regenerated, checked
+    against the fixture's heads and sums)."""
+    from bayesbridge_amd import simulate
+    g = _load(golden_dir, 'chain_linear_dense_4000x800_f32repr.npz')
+    n, p = (int(v) for v in g['shape'])
+    np.random.seed(111)
+    X = np.random.randn(n, p).astype(np.float32).astype(np.float64)
+    assert np.array_equal(X[:4, :4], g['X_head']) and X.sum() == g['X_sum']
+    y = simulate.simulate_outcome(X, simulate.demo_beta(p), 'linear', seed=1)
+    assert np.allclose(y[:8], g['y_head'], rtol=1e-14)
+    assert abs(y.sum() - g['y_sum']) <= 1e-9 * abs(g['y_sum'])
+    return g, X, y
+
+
+def test_config4_scaled_chain_through_the_oracle(golden_dir):
+    """Linear model, dense 4000 x 800 (config 4 scaled): the oracle chain with
+    the L-BFGS mode search reproduces the reference's 10 samples."""
+    g, X, y = config4_small_problem(golden_dir)
+    chain = OracleGibbs(y, X, 'linear', bridge_exponent=.5,
+                        regularizing_slab_size=2.)
+    res = chain.gibbs(10, seed=111, init={'global_scale': .01})
+    assert np.abs(res['n_cg_iter'] - g['n_cg_iter']).max() <= 2
+    assert np.allclose(res['coef'], g['coef_samples'], atol=1e-5)
+    assert np.allclose(res['global_scale'], g['global_scale_samples'],
+                       rtol=1e-5)
+    assert np.allclose(res['logp'], g['logp_samples'], rtol=1e-6)
