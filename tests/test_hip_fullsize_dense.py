@@ -171,7 +171,10 @@ def test_config4_linear_device_chain_runs_and_is_reproducible(full_dense):
     assert not np.array_equal(a['coef'], c['coef'])
     assert np.all(np.isfinite(a['coef'])) and np.all(np.isfinite(a['logp']))
     assert np.all(a['n_cg_iter'] > 0) and np.all(a['n_cg_iter'] < 500)
-    assert np.all(a['obs_prec'] > .5) and np.all(a['obs_prec'] < 2.)  # sigma=1
+    # noise sd is 1: after the first draw (made from coef = 0, where the
+    # residual still holds the whole signal) the precision sits at ~1
+    assert np.all(a['obs_prec'] > 0.)
+    assert np.all(np.abs(a['obs_prec'].ravel()[1:] - 1.) < .2)
     # the five large true effects are found after five iterations
     assert np.all(np.abs(a['coef'][-1][1:6] - 1.5) < .1)
 
