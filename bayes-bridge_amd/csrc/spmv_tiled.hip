@@ -39,6 +39,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.hpp"
+#include "tiled_layout.hpp"
 
 // -DBBX_TILED_INSTRUMENT=1 compiles the per-wave phase timers in (they cost
 // ~8 SGPRs, which the production kernel has no room for); BBX_TILED_DEBUG=N
@@ -58,59 +59,13 @@
 
 namespace bbx {
 
-// Workgroup geometry.  Default: one 1024-thread workgroup owns a CU's LDS.
-// -DBBX_TILE_THREADS=512 -DBBX_TILE_LDS_KB=80 -DBBX_TILE_W_MAX=7168 builds the
-// "two half-width workgroups per CU" variant measured in DESIGN.md 3.1.
-#ifndef BBX_TILE_THREADS
-#define BBX_TILE_THREADS 1024
+// Geometry constants, BatchDesc / FoldDesc / SliceMeta and the host-side
+// builder live in tiled_layout.hpp / tiled_layout.cpp (plain C++, CPU-testable).
+#ifndef BBX_TILE_MIN_WAVES
+#define BBX_TILE_MIN_WAVES 4  // waves per SIMD the register budget must allow
 #endif
-#ifndef BBX_TILE_LDS_KB
-#define BBX_TILE_LDS_KB 160
-#endif
-#ifndef BBX_TILE_W_MAX
-#define BBX_TILE_W_MAX 16128
-#endif
-constexpr int TILE_W_MAX = BBX_TILE_W_MAX;  // doubles of the vector slice in LDS
-constexpr int TILE_PR_MAX = 4096;  // row accumulators in LDS
-constexpr int TILE_THREADS = BBX_TILE_THREADS;
-constexpr int TILE_LDS_BYTES = BBX_TILE_LDS_KB * 1024;
-constexpr int TILE_WG_PER_CU = (160 / BBX_TILE_LDS_KB);
-constexpr int TILE_WG_PER_ROUND = 256 * TILE_WG_PER_CU;
-constexpr int TILE_WAVES = TILE_THREADS / WAVE;
-constexpr uint16_t NO_ROW = 0xFFFF;
-
-// Set-up only (the kernel derives the column block arithmetically).
-struct TileDesc {
-  int32_t col_block;
-  int32_t slice_begin;
-  int32_t slice_end;
-  int32_t pad;
-};
-
-constexpr int SLICE_ROWS = 2 * WAVE;  // two rows per lane
-
-struct SliceMeta {
-  uint32_t first_quad;  // offset into the id stream in units of 64 uint4
-  uint32_t n_quad;      // steps: 4 entries of row A + 4 of row B per lane
-};
-
-// One step of a wave's precomputed schedule: BATCH consecutive quads of one
-// slice.  The schedule of every (workgroup, wave) is laid out in processing
-// order, so the kernel's issue cursor is a single scalar index.
-struct BatchDesc {
-  uint32_t quad0;     // first step (units of 64 uint4 in the id stream)
-  uint32_t row_slot;  // slice * 64: where the slice's row-id pairs start
-  uint32_t info;      // bits 0-3 count, 8 last-of-slice, 9 tile-first, 10 end
-  uint32_t pad;
-};
-constexpr uint32_t BD_LAST = 1u << 8;
-constexpr uint32_t BD_TILE_FIRST = 1u << 9;
-constexpr uint32_t BD_END = 1u << 10;
-#ifndef BBX_BATCH_BIN
-#define BBX_BATCH_BIN 1
-#endif
-constexpr int BATCH_BIN = BBX_BATCH_BIN;  // steps per ring slot, value-free
-constexpr int BATCH_VAL = 1;   // steps per ring slot when values are stored
+constexpr int WAVE_CHECK = LANES == WAVE ? 1 : -1;
+static_assert(WAVE_CHECK == 1, "tiled layout is built for 64-lane wavefronts");
 
 // One orientation (X or X^T) in tiled form, device resident.
 struct TiledMatrix {
@@ -137,10 +92,6 @@ struct TiledMatrix {
   }
 };
 
-// Row r of a panel was split: acc[r] += acc[first .. first+count) at the end.
-struct FoldDesc {
-  uint16_t row, first, count, pad;
-};
 
 struct TiledPair {
   TiledMatrix x, xt;
@@ -241,7 +192,7 @@ __device__ __forceinline__ void asm_load_u32(unsigned& dst, unsigned off,
 constexpr int FILL_UNROLL = (TILE_W_MAX + TILE_THREADS - 1) / TILE_THREADS;
 
 template <bool VALS, bool PACK, bool WIDE>
-__global__ __launch_bounds__(TILE_THREADS, 4) void tiled_spmv_kernel(
+__global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_kernel(
     int64_t R, int64_t C, int W, int PR, int G, int blocks_per_group,
     const int32_t* __restrict__ wave_desc, int desc_stride,
     const BatchDesc* __restrict__ descs, const uint32_t* __restrict__ rowids,
@@ -602,448 +553,7 @@ __global__ __launch_bounds__(256) void tiled_dot_finalize_kernel(
   }
 }
 
-// ----------------------------------------------------------------- builder
-
-struct PanelBuild {
-  std::vector<uint4> ids;
-  std::vector<double> vals;
-  std::vector<SliceMeta> slices;  // first_quad local to the panel
-  std::vector<uint32_t> rowids;
-  std::vector<TileDesc> tiles;    // slice ids local to the panel
-  std::vector<int32_t> group_tile_count;
-  std::vector<FoldDesc> folds;    // split rows of this panel
-  int split_T = 0;
-  std::vector<BatchDesc> descs;   // quad0/row_slot local to the panel
-  std::vector<int32_t> wave_desc; // [G * TILE_WAVES] local start of each wave
-  // schedule statistics (BBX_TILED_STATS): per workgroup, in batches
-  std::vector<int64_t> wg_critical;  // sum over tiles of the busiest wave
-  std::vector<int64_t> wg_total;     // all waves, all tiles
-  int64_t dup_quads = 0;             // quads re-loaded to fill a batch
-};
-
-// Per-wave schedules of one panel: for every workgroup (group of column
-// blocks) and wave, the batches of its slices in processing order.  Inside a
-// tile the slices (sorted by decreasing length) go one by one to the wave with
-// the least work so far (longest-processing-time rule), which keeps the 16
-// waves of a workgroup within one slice of each other at the tile barrier.
-static void build_schedules(PanelBuild& pb, int G, int batch) {
-  pb.wave_desc.assign((size_t)G * TILE_WAVES, 0);
-  size_t tile_cursor = 0;
-  // The id stream is re-laid in the order it will be READ: workgroup, wave,
-  // tile, slice.  Every wave then walks one contiguous region of HBM front to
-  // back (consecutive 1 KiB loads, DRAM-page friendly) instead of hopping
-  // between the slices the dealing happened to give it.
-  const bool has_vals = !pb.vals.empty();
-  std::vector<uint4> new_ids;
-  std::vector<double> new_vals;
-  std::vector<uint32_t> new_rowids;
-  std::vector<SliceMeta> new_slices;
-  new_ids.reserve(pb.ids.size());
-  new_rowids.reserve(pb.rowids.size());
-  new_slices.reserve(pb.slices.size());
-  if (has_vals) new_vals.reserve(pb.vals.size());
-  for (int g = 0; g < G; ++g) {
-    const size_t t0 = tile_cursor, t1 = tile_cursor + pb.group_tile_count[g];
-    tile_cursor = t1;
-    // tile_deal[t - t0][w] = slices of tile t handled by wave w
-    std::vector<std::vector<std::vector<int>>> tile_deal(t1 - t0);
-    for (size_t t = t0; t < t1; ++t) {
-      const TileDesc& td = pb.tiles[t];
-      std::vector<std::vector<int>>& dl = tile_deal[t - t0];
-      dl.assign(TILE_WAVES, std::vector<int>());
-      int64_t load[TILE_WAVES];
-      for (int w = 0; w < TILE_WAVES; ++w) load[w] = 0;
-      for (int sl = td.slice_begin; sl < td.slice_end; ++sl) {
-        // rotate the tie-break with the tile index so that no wave is
-        // systematically first
-        int best = (int)((t + (size_t)sl) % TILE_WAVES);
-        for (int k = 0; k < TILE_WAVES; ++k) {
-          const int w = (int)((t + (size_t)k) % TILE_WAVES);
-          if (load[w] < load[best]) best = w;
-        }
-        dl[best].push_back(sl);
-        // cost: steps plus a per-slice overhead (row ids, flush)
-        load[best] += (int64_t)pb.slices[(size_t)sl].n_quad + 2;
-      }
-    }
-    {
-      int64_t crit = 0, total = 0;
-      for (size_t t = t0; t < t1; ++t) {
-        int64_t worst = 0;
-        for (int w = 0; w < TILE_WAVES; ++w) {
-          int64_t nb = 0;
-          for (int sl : tile_deal[t - t0][w]) {
-            const int64_t nq = pb.slices[(size_t)sl].n_quad;
-            const int64_t b = (nq + batch - 1) / batch;
-            nb += b;
-            pb.dup_quads += b * batch - nq;
-          }
-          worst = std::max(worst, nb);
-          total += nb;
-        }
-        crit += worst;
-      }
-      pb.wg_critical.push_back(crit);
-      pb.wg_total.push_back(total);
-    }
-    for (int w = 0; w < TILE_WAVES; ++w) {
-      pb.wave_desc[(size_t)g * TILE_WAVES + w] = (int32_t)pb.descs.size();
-      for (size_t t = t0; t < t1; ++t) {
-        bool first = true;
-        for (int sl : tile_deal[t - t0][w]) {
-          const SliceMeta& old = pb.slices[(size_t)sl];
-          // move the slice to the end of the re-laid stream
-          SliceMeta sm;
-          sm.first_quad = (uint32_t)(new_ids.size() / WAVE);
-          sm.n_quad = old.n_quad;
-          const uint32_t new_sl = (uint32_t)new_slices.size();
-          new_slices.push_back(sm);
-          const size_t src = (size_t)old.first_quad * WAVE;
-          const size_t cnt = (size_t)old.n_quad * WAVE;
-          new_ids.insert(new_ids.end(), pb.ids.begin() + src,
-                         pb.ids.begin() + src + cnt);
-          if (has_vals)
-            new_vals.insert(new_vals.end(), pb.vals.begin() + src * 8,
-                            pb.vals.begin() + (src + cnt) * 8);
-          new_rowids.insert(new_rowids.end(),
-                            pb.rowids.begin() + (size_t)sl * WAVE,
-                            pb.rowids.begin() + (size_t)(sl + 1) * WAVE);
-          for (uint32_t q0 = 0; q0 < sm.n_quad; q0 += (uint32_t)batch) {
-            BatchDesc d;
-            d.quad0 = sm.first_quad + q0;
-            d.row_slot = new_sl * WAVE;
-            const uint32_t left = sm.n_quad - q0;
-            d.info = left < (uint32_t)batch ? left : (uint32_t)batch;
-            if (left <= (uint32_t)batch) d.info |= BD_LAST;
-            if (first) d.info |= BD_TILE_FIRST;
-            d.pad = 0;
-            first = false;
-            pb.descs.push_back(d);
-          }
-        }
-        if (first) {  // no slice of this tile for this wave: barrier marker
-          BatchDesc d;
-          d.quad0 = 0;
-          d.row_slot = 0;
-          d.info = BD_TILE_FIRST;
-          d.pad = 0;
-          pb.descs.push_back(d);
-        }
-      }
-      BatchDesc endd;
-      endd.quad0 = 0;
-      endd.row_slot = 0;
-      endd.info = BD_END;
-      endd.pad = 0;
-      pb.descs.push_back(endd);
-    }
-  }
-  // TileDesc::slice_begin/end keep describing the sorted order (set-up only;
-  // the kernel reads col_block and the schedules).
-  pb.ids.swap(new_ids);
-  pb.vals.swap(new_vals);
-  pb.rowids.swap(new_rowids);
-  pb.slices.swap(new_slices);
-}
-
-struct VRow {
-  int32_t begin;  // first entry (index into colidx)
-  int32_t len;
-  uint16_t slot;  // accumulator slot in LDS (row, or extra slot of a chunk)
-  int32_t g_begin = 0;  // packed layout: first group in the tile's group list
-  int32_t steps = 0;    // steps this row needs (sort key)
-};
-
-// Groups of one (chunk of a) row in the packed layout; see packed_row().
-static int pack_groups(const int32_t* colidx, int32_t begin, int32_t len,
-                       int64_t col0, std::vector<uint64_t>& out) {
-  int n = 0;
-  int32_t i = 0;
-  while (i < len) {
-    int64_t prev = colidx[begin + i] - col0;
-    uint64_t g = (uint64_t)prev;
-    int k = 1;
-    while (k < 5 && i + k < len) {
-      const int64_t d = (colidx[begin + i + k] - col0) - prev;
-      if (d <= 0 || d > 4095) break;  // duplicate or long gap: new group
-      g |= (uint64_t)d << (14 + 12 * (k - 1));
-      prev += d;
-      ++k;
-    }
-    out.push_back(g);
-    i += k;
-    ++n;
-  }
-  return n;
-}
-
-static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
-                        const int32_t* colidx, const double* vals, int W,
-                        int n_block, int PR, int G, int extra_budget,
-                        int panel, bool packed, PanelBuild& pb) {
-  const int64_t row0 = (int64_t)panel * PR;
-  const int rows_here = (int)std::min<int64_t>(PR, R - row0);
-  // pass 1: segment of every row in every column block
-  std::vector<int32_t> seg_begin((size_t)rows_here * n_block),
-      seg_len((size_t)rows_here * n_block);
-  std::vector<int32_t> max_seg(rows_here, 0);
-  for (int r = 0; r < rows_here; ++r) {
-    int32_t k = rowptr[row0 + r];
-    const int32_t e = rowptr[row0 + r + 1];
-    for (int cb = 0; cb < n_block; ++cb) {
-      const int64_t col_end = std::min<int64_t>((int64_t)(cb + 1) * W, C);
-      const int32_t b = k;
-      while (k < e && colidx[k] < col_end) ++k;
-      seg_begin[(size_t)cb * rows_here + r] = b;
-      seg_len[(size_t)cb * rows_here + r] = k - b;
-      if (k - b > max_seg[r]) max_seg[r] = k - b;
-    }
-  }
-  // split threshold T: the smallest one whose extra accumulators fit
-  auto extras_for = [&](int T) {
-    int64_t ex = 0;
-    for (int r = 0; r < rows_here; ++r)
-      if (max_seg[r] > T) ex += (max_seg[r] + T - 1) / T - 1;
-    return ex;
-  };
-  int T = 0;  // 0 = no splitting
-  {
-    int longest = 0;
-    for (int r = 0; r < rows_here; ++r) longest = std::max(longest, max_seg[r]);
-    // never split below 3x the mean non-empty segment: balanced matrices
-    // (e.g. the rows of X) gain nothing and would only get more slices
-    int64_t seg_sum = 0, seg_cnt = 0;
-    for (int32_t v : seg_len)
-      if (v > 0) {
-        seg_sum += v;
-        ++seg_cnt;
-      }
-    int t_min = 32;
-    if (seg_cnt > 0) {
-      // Heavy-tailed segment lengths (the columns of simulate_data.py designs:
-      // longest ~15x the mean) leave the waves that drew the long slices
-      // streaming alone at the end of every tile; chunks of ~1.5x the mean
-      // bring the busiest wave from 2.0x to 1.3x the ideal load (Tdot at
-      // 1M x 50k: 60.8 -> 57.2 us).  Balanced rows (longest ~2.4x the mean)
-      // only get more slices from splitting (dot: 54.3 -> 57.4 us), so they
-      // keep the 3x rule.
-      const double mean_seg = (double)seg_sum / (double)seg_cnt;
-      double t_factor = (double)longest > 6. * mean_seg ? 1.5 : 3.;
-      static const char* t_env = getenv("BBX_TILED_TFACTOR");
-      if (t_env) t_factor = atof(t_env);
-      t_min = std::max<int>(t_min, (int)(t_factor * mean_seg));
-      // Small tiles: with fewer than ~1.5 slices per wave most of the 16
-      // waves of the workgroup have nothing to stream (100k x 10k: 4 slices
-      // per tile, busiest wave at 4-11x the ideal load).  There the split
-      // threshold is lowered until every tile has ~2 slices per wave; the
-      // chunks cost extra accumulators, which small panels have room for.
-      int64_t densest_rows = 0, densest_entries = 0;
-      for (int cb = 0; cb < n_block; ++cb) {
-        int64_t rows_cb = 0, ent_cb = 0;
-        for (int r = 0; r < rows_here; ++r) {
-          const int32_t v = seg_len[(size_t)cb * rows_here + r];
-          if (v > 0) {
-            ++rows_cb;
-            ent_cb += v;
-          }
-        }
-        if (ent_cb > densest_entries) {
-          densest_entries = ent_cb;
-          densest_rows = rows_cb;
-        }
-      }
-      const int64_t want_rows = 2 * TILE_WAVES * SLICE_ROWS;
-      if (densest_rows < (3 * TILE_WAVES * SLICE_ROWS) / 2 && !t_env) {
-        int t_par = (int)((densest_entries + want_rows - 1) / want_rows);
-        t_par = (t_par + 3) / 4 * 4;
-        if (t_par < 8) t_par = 8;
-        if (t_par < t_min) t_min = t_par;
-      }
-    }
-    if (extra_budget > 0 && longest > t_min) {
-      int lo = t_min, hi = longest;  // extras_for(hi) == 0
-      while (lo < hi) {
-        const int mid = (lo + hi) / 2;
-        if (extras_for(mid) <= extra_budget) hi = mid; else lo = mid + 1;
-      }
-      T = lo;
-      if (T >= longest) T = 0;
-    }
-  }
-  pb.split_T = T;
-  // extra slots of the split rows
-  std::vector<int32_t> extra_first(rows_here, -1);
-  int n_extra = 0;
-  if (T > 0)
-    for (int r = 0; r < rows_here; ++r)
-      if (max_seg[r] > T) {
-        const int k = (max_seg[r] + T - 1) / T;
-        extra_first[r] = PR + n_extra;
-        FoldDesc fd;
-        fd.row = (uint16_t)r;
-        fd.first = (uint16_t)(PR + n_extra);
-        fd.count = (uint16_t)(k - 1);
-        fd.pad = 0;
-        pb.folds.push_back(fd);
-        n_extra += k - 1;
-      }
-  // pass 2: tiles
-  pb.group_tile_count.assign(G, 0);
-  const int blocks_per_group = (n_block + G - 1) / G;
-  std::vector<VRow> vrows, sorted;
-  std::vector<int> bucket;
-  std::vector<uint64_t> groups;  // packed layout: groups of the tile's rows
-  for (int cb = 0; cb < n_block; ++cb) {
-    const int64_t col0 = (int64_t)cb * W;
-    vrows.clear();
-    int max_len = 0;
-    for (int r = 0; r < rows_here; ++r) {
-      const int32_t b = seg_begin[(size_t)cb * rows_here + r];
-      const int32_t len = seg_len[(size_t)cb * rows_here + r];
-      if (len == 0) continue;
-      if (T > 0 && len > T) {
-        const int k = (len + T - 1) / T;
-        const int base = len / k, rem = len % k;
-        int32_t at = b;
-        for (int c = 0; c < k; ++c) {
-          VRow v;
-          v.begin = at;
-          v.len = base + (c < rem ? 1 : 0);
-          v.slot = (uint16_t)(c == 0 ? r : extra_first[r] + c - 1);
-          at += v.len;
-          vrows.push_back(v);
-          max_len = std::max(max_len, v.len);
-        }
-      } else {
-        VRow v;
-        v.begin = b;
-        v.len = len;
-        v.slot = (uint16_t)r;
-        vrows.push_back(v);
-        max_len = std::max(max_len, len);
-      }
-    }
-    // sort key: steps the row needs (4 entries per step, or its packed groups)
-    groups.clear();
-    int max_key = 0;
-    for (VRow& v : vrows) {
-      if (packed) {
-        v.g_begin = (int32_t)groups.size();
-        v.steps = pack_groups(colidx, v.begin, v.len, col0, groups);
-      } else {
-        v.steps = (v.len + 3) / 4;
-      }
-      max_key = std::max(max_key, v.steps);
-    }
-    // by decreasing step count (counting sort, stable)
-    const int n_rows = (int)vrows.size();
-    bucket.assign((size_t)max_key + 2, 0);
-    for (const VRow& v : vrows) bucket[max_key - v.steps + 1] += 1;
-    for (int b = 1; b <= max_key + 1; ++b) bucket[b] += bucket[b - 1];
-    sorted.resize(vrows.size());
-    for (const VRow& v : vrows) sorted[bucket[max_key - v.steps]++] = v;
-    TileDesc td;
-    td.col_block = cb;
-    td.slice_begin = (int32_t)pb.slices.size();
-    td.pad = 0;
-    for (int base = 0; base < n_rows; base += SLICE_ROWS) {
-      const int rows_in = std::min(SLICE_ROWS, n_rows - base);
-      const uint32_t nq = (uint32_t)sorted[base].steps;  // longest row
-      SliceMeta sm;
-      sm.first_quad = (uint32_t)(pb.ids.size() / WAVE);
-      sm.n_quad = nq;
-      pb.slices.push_back(sm);
-      const size_t id0 = pb.ids.size();
-      pb.ids.resize(id0 + (size_t)nq * WAVE);
-      if (vals) pb.vals.resize((id0 + (size_t)nq * WAVE) * 8, 0.);
-      for (int l = 0; l < WAVE; ++l) {
-        // lane l owns sorted rows base + l (A) and base + 64 + l (B)
-        const VRow* vr[2] = {nullptr, nullptr};
-        if (l < rows_in) vr[0] = &sorted[base + l];
-        if (WAVE + l < rows_in) vr[1] = &sorted[base + WAVE + l];
-        pb.rowids.push_back((uint32_t)(vr[0] ? vr[0]->slot : NO_ROW) |
-                            ((uint32_t)(vr[1] ? vr[1]->slot : NO_ROW) << 16));
-        for (uint32_t q = 0; q < nq && packed; ++q) {
-          uint4 pk;
-          uint64_t gg[2];
-          for (int half = 0; half < 2; ++half) {
-            const VRow* v = vr[half];
-            gg[half] = (v && (int)q < v->steps) ? groups[(size_t)v->g_begin + q]
-                                                : (uint64_t)W;  // xs[W] == 0
-          }
-          pk.x = (uint32_t)gg[0];
-          pk.y = (uint32_t)(gg[0] >> 32);
-          pk.z = (uint32_t)gg[1];
-          pk.w = (uint32_t)(gg[1] >> 32);
-          pb.ids[id0 + (size_t)q * WAVE + l] = pk;
-        }
-        for (uint32_t q = 0; q < nq && !packed; ++q) {
-          uint16_t e[8];
-          for (int half = 0; half < 2; ++half) {
-            const VRow* v = vr[half];
-            for (int u = 0; u < 4; ++u) {
-              const int k = (int)q * 4 + u;
-              if (v && k < v->len) {
-                e[half * 4 + u] = (uint16_t)(colidx[v->begin + k] - col0);
-                if (vals)
-                  pb.vals[(id0 + (size_t)q * WAVE + l) * 8 + half * 4 + u] =
-                      vals[v->begin + k];
-              } else {
-                e[half * 4 + u] = (uint16_t)W;  // xs[W] == 0
-              }
-            }
-          }
-          uint4 packed;
-          packed.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
-          packed.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
-          packed.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
-          packed.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
-          pb.ids[id0 + (size_t)q * WAVE + l] = packed;
-        }
-      }
-    }
-    td.slice_end = (int32_t)pb.slices.size();
-    pb.tiles.push_back(td);
-    pb.group_tile_count[cb / blocks_per_group] += 1;
-  }
-  build_schedules(pb, G, vals ? BATCH_VAL : BATCH_BIN);
-}
-
-// Picks (PR, G): row panels x groups of column blocks.  One workgroup runs per
-// CU (it owns the CU's LDS), so the launch should be a single round of <= 256
-// workgroups of equal work.  Cost model fitted on MI355X (profiles/,
-// DESIGN.md): a tile costs ~4.3 us of fixed time (slice refill from L2, two
-// barriers, pipeline ramp) plus ~24 ps per stored entry streamed.
-static void choose_shape(int64_t R, int64_t C, int64_t nnz, int n_block, int W,
-                         int* PR_out, int* G_out) {
-  double best = 1e300;
-  int best_pr = 256, best_g = 1;
-  const int lds_rows = (int)((TILE_LDS_BYTES - 2048) / 8) - (W + 8);
-  int pr_cap = TILE_PR_MAX;
-  if (lds_rows - 256 < pr_cap) pr_cap = lds_rows - 256;  // room for extras
-  if (pr_cap < 128) pr_cap = 128;
-  for (int pr = 128; pr <= pr_cap; pr += 128) {
-    const int64_t n_panel = (R + pr - 1) / pr;
-    for (int g = 1; g <= n_block; ++g) {
-      const int bpg = (n_block + g - 1) / g;
-      if ((n_block + bpg - 1) / bpg != g) continue;  // not a distinct split
-      const double n_wg = (double)n_panel * g;
-      const double rounds = std::ceil(n_wg / (double)TILE_WG_PER_ROUND);
-      const double rows = (double)std::min<int64_t>(pr, R);
-      const double tile_nnz = (double)nnz * rows / (double)R / n_block;
-      const double per_tile = 4.3 + tile_nnz * 24e-6;            // us
-      double cost = rounds * bpg * per_tile + 6.;
-      if (g > 1) cost += (double)R * g * 16. / 4e6;              // slab pass
-      if (cost < best) {
-        best = cost;
-        best_pr = pr;
-        best_g = g;
-      }
-    }
-  }
-  *PR_out = best_pr;
-  *G_out = best_g;
-}
+// ------------------------------------------------------ upload of a layout
 
 static int upload(DevMem& dst, const void* src, size_t bytes) {
   BBX_TRY(dst.alloc(bytes > 0 ? bytes : 8));
@@ -1051,209 +561,44 @@ static int upload(DevMem& dst, const void* src, size_t bytes) {
   return BBX_OK;
 }
 
+// Builds one orientation on the host (tiled_layout.cpp) and moves it to HBM.
 static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
                      const int32_t* rowptr, const int32_t* colidx,
                      const double* vals) {
-  m.R = R;
-  m.C = C;
-  m.nnz = nnz;
-  m.has_vals = vals != nullptr;
-  {
-    // Opt-in (BBX_TILED_PACK=1).  Measured at 1M x 50k: 18.5 % fewer id bytes
-    // (233 -> 193 MB per product) but only 3-5 % less time (55.5 -> 53.9 us,
-    // 57.4 -> 54.7 us): the per-entry work (LDS gather, index arithmetic) does
-    // not shrink with the bytes, so the achieved HBM rate DROPS from 0.53 to
-    // 0.45-0.48 of peak.  Kept for footprint-bound uses, not the default.
-    static const char* pack_env = getenv("BBX_TILED_PACK");
-    m.packed = !m.has_vals && pack_env && atoi(pack_env) == 1;
-  }
-  m.n_block = (int)((C + TILE_W_MAX - 1) / TILE_W_MAX);
-  if (m.n_block < 1) m.n_block = 1;
-  int64_t w = (C + m.n_block - 1) / m.n_block;
-  w = (w + 63) / 64 * 64;
-  m.W = (int)w;
-  choose_shape(R, C, nnz, m.n_block, m.W, &m.PR, &m.G);
-  if (const char* e = getenv("BBX_TILED_PR")) m.PR = atoi(e);
-  if (const char* e = getenv("BBX_TILED_G")) m.G = atoi(e);
-  if (m.PR < 64) m.PR = 64;
-  if (m.PR > TILE_PR_MAX) m.PR = TILE_PR_MAX;
-  if (m.G < 1) m.G = 1;
-  if (m.G > m.n_block) m.G = m.n_block;
-  {  // normalise G so that every group is non-empty
-    const int bpg = (m.n_block + m.G - 1) / m.G;
-    m.G = (m.n_block + bpg - 1) / bpg;
-  }
-  m.n_panel = (int)((R + m.PR - 1) / m.PR);
-  // LDS left after the vector slice and the row accumulators pays for the
-  // extra accumulators of split rows (2 KB stay free for static LDS).
-  int extra_budget =
-      (int)((TILE_LDS_BYTES - 2048) / 8) - (m.W + 8) - m.PR;
-  if (extra_budget > 8192) extra_budget = 8192;
-  if (extra_budget < 0) extra_budget = 0;
-  if (const char* e = getenv("BBX_TILED_EXTRA")) extra_budget = atoi(e);
-
-  std::vector<PanelBuild> pbs((size_t)m.n_panel);
-  unsigned n_thr = std::thread::hardware_concurrency();
-  if (n_thr < 1) n_thr = 1;
-  if (n_thr > 64) n_thr = 64;
-  if ((unsigned)m.n_panel < n_thr) n_thr = (unsigned)m.n_panel;
-  std::vector<std::thread> pool;
-  std::vector<int> thread_status(n_thr, BBX_OK);
-  for (unsigned t = 0; t < n_thr; ++t)
-    pool.emplace_back([&, t]() {
-      // an exception must not leave a worker thread (std::terminate)
-      thread_status[t] = no_throw([&]() -> int {
-        for (int p = (int)t; p < m.n_panel; p += (int)n_thr)
-          build_panel(R, C, rowptr, colidx, vals, m.W, m.n_block, m.PR, m.G,
-                      extra_budget, p, m.packed, pbs[(size_t)p]);
-        return BBX_OK;
-      });
-    });
-  for (auto& th : pool) th.join();
-  for (int st_t : thread_status)
-    if (st_t < 0) return fail(BBX_ERR_INVALID, "out of host memory while tiling");
-
-  if (getenv("BBX_TILED_STATS")) {
-    int64_t crit_max = 0, total = 0, dup = 0, quads = 0, n_wg = 0, crit_sum = 0;
-    int stat_extra = 0, stat_T = 0;
-    for (auto& pb : pbs) {
-      for (size_t g = 0; g < pb.wg_critical.size(); ++g) {
-        crit_max = std::max(crit_max, pb.wg_critical[g]);
-        crit_sum += pb.wg_critical[g];
-        total += pb.wg_total[g];
-        ++n_wg;
-      }
-      dup += pb.dup_quads;
-      quads += (int64_t)(pb.ids.size() / WAVE);
-      int ex = 0;
-      for (const FoldDesc& fd : pb.folds) ex += fd.count;
-      stat_extra = std::max(stat_extra, ex);
-      if (pb.split_T > 0 && (stat_T == 0 || pb.split_T < stat_T))
-        stat_T = pb.split_T;
-    }
-    fprintf(stderr,
-            "[bbx tiled %lldx%lld] W=%d blocks=%d PR=%d G=%d split T=%d "
-            "extras=%d workgroups=%lld: "
-            "quads=%lld (+%lld re-loaded to fill batches, %.1f%%); batches per "
-            "wave: ideal %.1f, mean critical path %.1f, worst workgroup %lld "
-            "(%.1f%% over ideal)\n",
-            (long long)R, (long long)C, m.W, m.n_block, m.PR, m.G, stat_T,
-            stat_extra, (long long)n_wg, (long long)quads, (long long)dup,
-            100. * (double)dup / (double)std::max<int64_t>(quads, 1),
-            (double)total / (double)(n_wg * TILE_WAVES),
-            (double)crit_sum / (double)n_wg, (long long)crit_max,
-            100. * ((double)crit_max * n_wg * TILE_WAVES / (double)total - 1.));
-  }
-  // concatenate with offset fix-ups
-  size_t tot_ids = 0, tot_slices = 0, tot_tiles = 0, tot_descs = 0;
-  for (auto& pb : pbs) {
-    tot_ids += pb.ids.size();
-    tot_slices += pb.slices.size();
-    tot_tiles += pb.tiles.size();
-    tot_descs += pb.descs.size();
-  }
-  if (tot_ids / WAVE >= ((size_t)1 << 32))
-    return fail(BBX_ERR_INVALID, "matrix too large for the tiled format");
-  std::vector<uint4> ids(tot_ids);
-  std::vector<double> vv(m.has_vals ? tot_ids * 8 : 0);
-  std::vector<BatchDesc> descs(tot_descs);
-  std::vector<int32_t> wave_desc((size_t)m.n_panel * m.G * TILE_WAVES, 0);
-  std::vector<uint32_t> rowids(tot_slices * WAVE);
-  std::vector<FoldDesc> folds;
-  std::vector<int32_t> panel_fold((size_t)m.n_panel + 1, 0);
-  m.n_extra = 0;
-  m.split_T = 0;
-  size_t id_off = 0, sl_off = 0, de_off = 0;
-  for (int p = 0; p < m.n_panel; ++p) {
-    PanelBuild& pb = pbs[(size_t)p];
-    panel_fold[(size_t)p] = (int32_t)folds.size();
-    int extra_here = 0;
-    for (const FoldDesc& fd : pb.folds) {
-      folds.push_back(fd);
-      extra_here += fd.count;
-    }
-    if (extra_here > m.n_extra) m.n_extra = extra_here;
-    if (pb.split_T > 0 && (m.split_T == 0 || pb.split_T < m.split_T))
-      m.split_T = pb.split_T;
-    if (!pb.ids.empty())
-      memcpy(&ids[id_off], pb.ids.data(), pb.ids.size() * sizeof(uint4));
-    if (m.has_vals && !pb.vals.empty())
-      memcpy(&vv[id_off * 8], pb.vals.data(), pb.vals.size() * sizeof(double));
-    for (size_t k = 0; k < pb.descs.size(); ++k) {
-      BatchDesc d = pb.descs[k];
-      if (d.info & 15u) {
-        d.quad0 += (uint32_t)(id_off / WAVE);
-        d.row_slot += (uint32_t)(sl_off * WAVE);
-      }
-      descs[de_off + k] = d;
-    }
-    for (size_t k = 0; k < pb.wave_desc.size(); ++k)
-      wave_desc[(size_t)p * m.G * TILE_WAVES + k] =
-          pb.wave_desc[k] + (int32_t)de_off;
-    if (!pb.rowids.empty())
-      memcpy(&rowids[sl_off * WAVE], pb.rowids.data(),
-             pb.rowids.size() * sizeof(uint32_t));
-    id_off += pb.ids.size();
-    sl_off += pb.slices.size();
-    de_off += pb.descs.size();
-    std::vector<uint4>().swap(pb.ids);
-    std::vector<double>().swap(pb.vals);
-  }
-  panel_fold[(size_t)m.n_panel] = (int32_t)folds.size();
-  BBX_TRY(upload(m.folds, folds.data(), folds.size() * sizeof(FoldDesc)));
-  BBX_TRY(upload(m.panel_fold, panel_fold.data(),
-                 panel_fold.size() * sizeof(int32_t)));
-  m.n_quad = (int64_t)(tot_ids / WAVE);
-  m.n_slice = (int64_t)tot_slices;
-  m.n_tile = (int64_t)tot_tiles;
-  BBX_TRY(upload(m.ids, ids.data(), ids.size() * sizeof(uint4)));
+  TiledHost host;
+  std::string err;
+  if (build_tiled_host(R, C, nnz, rowptr, colidx, vals, TiledOptions::from_env(),
+                       &host, &err) != 0)
+    return fail(BBX_ERR_INVALID, err);
+  m.R = host.R;
+  m.C = host.C;
+  m.nnz = host.nnz;
+  m.W = host.W;
+  m.n_block = host.n_block;
+  m.PR = host.PR;
+  m.n_panel = host.n_panel;
+  m.G = host.G;
+  m.has_vals = host.has_vals;
+  m.packed = host.packed;
+  m.n_slice = host.n_slice;
+  m.n_quad = host.n_quad;
+  m.n_tile = host.n_tile;
+  m.n_desc = host.n_desc;
+  m.desc_stride = host.desc_stride;
+  m.n_extra = host.n_extra;
+  m.split_T = host.split_T;
+  BBX_TRY(upload(m.folds, host.folds.data(), host.folds.size() * sizeof(FoldDesc)));
+  BBX_TRY(upload(m.panel_fold, host.panel_fold.data(),
+                 host.panel_fold.size() * sizeof(int32_t)));
+  BBX_TRY(upload(m.ids, host.ids.data(), host.ids.size() * sizeof(Ids4)));
   if (m.has_vals)
-    BBX_TRY(upload(m.vals, vv.data(), vv.size() * sizeof(double)));
-  m.n_desc = (int64_t)tot_descs;
-  // the kernel addresses the streams with 32-bit byte offsets
-  if ((uint64_t)tot_ids * (m.has_vals ? 64u : 16u) >= ((uint64_t)1 << 32))
-    return fail(BBX_ERR_INVALID, "matrix too large for the tiled format");
-  if (tot_slices * WAVE >= ((size_t)1 << 31) || tot_descs >= ((size_t)1 << 31))
-    return fail(BBX_ERR_INVALID, "matrix too large for the tiled format");
-  {  // equal-stride schedules when the padding stays small
-    const size_t n_wave = wave_desc.size();
-    size_t max_len = 0;
-    for (size_t k = 0; k < n_wave; ++k) {
-      const size_t end = (k + 1 < n_wave) ? (size_t)wave_desc[k + 1] : tot_descs;
-      max_len = std::max(max_len, end - (size_t)wave_desc[k]);
-    }
-    const size_t stride = (max_len + WAVE - 1) / WAVE * WAVE;
-    m.desc_stride = 0;
-    if (n_wave > 0 && stride > 0 && n_wave * stride <= 2 * tot_descs + 65536 &&
-        n_wave * stride < ((size_t)1 << 31)) {
-      BatchDesc endd;
-      endd.quad0 = 0;
-      endd.row_slot = 0;
-      endd.info = BD_END;
-      endd.pad = 0;
-      std::vector<BatchDesc> padded(n_wave * stride, endd);
-      for (size_t k = 0; k < n_wave; ++k) {
-        const size_t b = (size_t)wave_desc[k];
-        const size_t end = (k + 1 < n_wave) ? (size_t)wave_desc[k + 1] : tot_descs;
-        std::copy(descs.begin() + b, descs.begin() + end,
-                  padded.begin() + k * stride);
-      }
-      descs.swap(padded);
-      m.desc_stride = (int)stride;
-    }
-  }
-  {  // the kernel prefetches descriptors in blocks of 64: keep reads in bounds
-    BatchDesc endd;
-    endd.quad0 = 0;
-    endd.row_slot = 0;
-    endd.info = BD_END;
-    endd.pad = 0;
-    descs.resize(descs.size() + 2 * WAVE, endd);
-  }
-  BBX_TRY(upload(m.descs, descs.data(), descs.size() * sizeof(BatchDesc)));
-  BBX_TRY(upload(m.wave_desc, wave_desc.data(),
-                 wave_desc.size() * sizeof(int32_t)));
-  BBX_TRY(upload(m.rowids, rowids.data(), rowids.size() * sizeof(uint32_t)));
+    BBX_TRY(upload(m.vals, host.vals.data(), host.vals.size() * sizeof(double)));
+  BBX_TRY(upload(m.descs, host.descs.data(),
+                 host.descs.size() * sizeof(BatchDesc)));
+  BBX_TRY(upload(m.wave_desc, host.wave_desc.data(),
+                 host.wave_desc.size() * sizeof(int32_t)));
+  BBX_TRY(upload(m.rowids, host.rowids.data(),
+                 host.rowids.size() * sizeof(uint32_t)));
   BBX_TRY(m.slab.alloc(sizeof(double) * (size_t)m.G * (size_t)R));
   return BBX_OK;
 }

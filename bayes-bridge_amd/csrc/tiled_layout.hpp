@@ -1,0 +1,133 @@
+// Host-side description of the LDS-tiled sparse layout (BBX_FORMAT_TILED):
+// the structs the kernel reads, the builder that produces them from a CSR
+// matrix, and a CPU emulator of the kernel's walk.  Plain C++17, no HIP: this
+// header and tiled_layout.cpp also build with g++ (sanitizers, CPU tests).
+// The layout itself is described at the top of spmv_tiled.hip and in DESIGN.md.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace bbx {
+
+// Workgroup geometry.  Default: one 1024-thread workgroup owns a CU's LDS.
+// -DBBX_TILE_THREADS=512 -DBBX_TILE_LDS_KB=80 -DBBX_TILE_W_MAX=7168 builds the
+// "two half-width workgroups per CU" variant measured in DESIGN.md 3.1.
+#ifndef BBX_TILE_THREADS
+#define BBX_TILE_THREADS 1024
+#endif
+#ifndef BBX_TILE_LDS_KB
+#define BBX_TILE_LDS_KB 160
+#endif
+#ifndef BBX_TILE_W_MAX
+#define BBX_TILE_W_MAX 16128
+#endif
+#ifndef BBX_BATCH_BIN
+#define BBX_BATCH_BIN 1
+#endif
+constexpr int LANES = 64;                   // gfx950 wavefront
+constexpr int TILE_W_MAX = BBX_TILE_W_MAX;  // doubles of the vector slice in LDS
+constexpr int TILE_PR_MAX = 4096;           // row accumulators in LDS
+constexpr int TILE_THREADS = BBX_TILE_THREADS;
+constexpr int TILE_LDS_BYTES = BBX_TILE_LDS_KB * 1024;
+constexpr int TILE_WG_PER_CU = (160 / BBX_TILE_LDS_KB);
+constexpr int TILE_WG_PER_ROUND = 256 * TILE_WG_PER_CU;
+constexpr int TILE_WAVES = TILE_THREADS / LANES;
+constexpr uint16_t NO_ROW = 0xFFFF;
+constexpr int SLICE_ROWS = 2 * LANES;  // two rows per lane
+constexpr int BATCH_BIN = BBX_BATCH_BIN;  // steps per ring slot, value-free
+constexpr int BATCH_VAL = 1;   // steps per ring slot when values are stored
+
+// 16 bytes of ids: one step of one lane (same layout as HIP's uint4).
+struct Ids4 {
+  uint32_t x, y, z, w;
+};
+static_assert(sizeof(Ids4) == 16, "one 16-byte lane load");
+
+// Set-up only (the kernel derives the column block arithmetically).
+struct TileDesc {
+  int32_t col_block;
+  int32_t slice_begin;
+  int32_t slice_end;
+  int32_t pad;
+};
+
+struct SliceMeta {
+  uint32_t first_quad;  // offset into the id stream in units of 64 x 16 bytes
+  uint32_t n_quad;      // steps: 4 entries of row A + 4 of row B per lane
+};
+
+// One step of a wave's precomputed schedule: BATCH consecutive quads of one
+// slice.  The schedule of every (workgroup, wave) is laid out in processing
+// order, so the kernel's issue cursor is a single scalar index.
+struct BatchDesc {
+  uint32_t quad0;     // first step (units of 64 x 16 bytes in the id stream)
+  uint32_t row_slot;  // slice * 64: where the slice's row-id pairs start
+  uint32_t info;      // bits 0-3 count, 8 last-of-slice, 9 tile-first, 10 end
+  uint32_t pad;
+};
+constexpr uint32_t BD_LAST = 1u << 8;
+constexpr uint32_t BD_TILE_FIRST = 1u << 9;
+constexpr uint32_t BD_END = 1u << 10;
+
+// Row r of a panel was split: acc[r] += acc[first .. first+count) at the end.
+struct FoldDesc {
+  uint16_t row, first, count, pad;
+};
+
+// Build-time choices that the environment can override (diagnostics, A/B).
+struct TiledOptions {
+  bool packed = false;       // BBX_TILED_PACK=1: 14-bit base + 4 x 12-bit deltas
+  int force_PR = 0;          // BBX_TILED_PR
+  int force_G = 0;           // BBX_TILED_G
+  int extra_budget = -1;     // BBX_TILED_EXTRA (< 0: what LDS leaves)
+  double t_factor = 0.;      // BBX_TILED_TFACTOR (0: automatic)
+  bool bank_aware = true;    // BBX_TILED_BANKS=0 switches the entry ordering off
+  bool stats = false;        // BBX_TILED_STATS=1
+  int max_threads = 64;
+  static TiledOptions from_env();
+};
+
+// One orientation (X or X^T) in tiled form, host resident.
+struct TiledHost {
+  int64_t R = 0, C = 0, nnz = 0;
+  int W = 0, n_block = 0, PR = 0, n_panel = 0, G = 0;
+  bool has_vals = false;
+  bool packed = false;
+  int64_t n_slice = 0, n_quad = 0, n_tile = 0, n_desc = 0;
+  int desc_stride = 0;  // > 0: wave k's schedule starts at k * desc_stride
+  int n_extra = 0;      // extra accumulators per panel (row splitting)
+  int split_T = 0;      // smallest split threshold used by any panel (0 = none)
+  std::vector<Ids4> ids;            // [n_quad * 64]
+  std::vector<double> vals;         // [n_quad * 64 * 8] when has_vals
+  std::vector<BatchDesc> descs;     // per-wave schedules (+ 2 blocks of END)
+  std::vector<int32_t> wave_desc;   // [n_panel * G * TILE_WAVES]
+  std::vector<uint32_t> rowids;     // [n_slice * 64]: panel-local rows A | B<<16
+  std::vector<FoldDesc> folds;
+  std::vector<int32_t> panel_fold;  // [n_panel + 1]
+  std::string stats;                // filled when TiledOptions::stats
+  int64_t lds_doubles() const { return (int64_t)W + 8 + PR + n_extra; }
+};
+
+// Builds the tiled form of an R x C CSR matrix (`vals` == nullptr: every
+// stored value is 1.0).  Returns 0, or -1 with *err set (too large for the
+// format's 32-bit offsets, tile does not fit in LDS, out of memory).
+int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
+                     const int32_t* colidx, const double* vals,
+                     const TiledOptions& opt, TiledHost* out, std::string* err);
+
+// CPU emulation of tiled_spmv_kernel's walk over the layout: every workgroup,
+// every wave's schedule, lane-private sums flushed into the panel's
+// accumulators at the end of each slice, split rows folded in descriptor
+// order.  slab[g * R + r] = partial sum of row r over the column blocks of
+// group g -- the same additions in the same order as the kernel, so a GPU
+// launch can be compared with it bit for bit.
+void emulate_tiled_spmv(const TiledHost& m, const double* x,
+                        std::vector<double>* slab);
+
+// LDS bank statistics of the gathers: over every (slice, step, entry position,
+// 32-lane half) the number of LDS cycles a ds_read_b64 needs (1 = conflict
+// free).  Returns the mean.
+double tiled_mean_gather_cycles(const TiledHost& m);
+
+}  // namespace bbx

@@ -55,3 +55,86 @@ def config2_small_problem(golden_dir):
     assert np.array_equal(n_success[:32], g['n_success_head'])
     assert np.array_equal(n_trial[:32], g['n_trial_head'])
     return g, X, (n_success, n_trial)
+
+
+def random_sparse_case(case):
+    """Randomised shapes and patterns (shared by the CPU layout tests and the
+    GPU operator tests): one to several column blocks (p around the
+    16128-column slice width), panels from a handful of rows to several
+    thousand, rows from empty to dense, binary and valued entries, duplicates.
+    Returns (X csr, binary flag, rng)."""
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.choice([3, 17, 130, 1000, 4097, 9000]))
+    p = int(rng.choice([2, 65, 900, 16128, 16130, 33000, 50000]))
+    density = float(rng.choice([.0005, .004, .03])) if p > 1000 \
+        else float(rng.choice([.02, .2, .7]))
+    nnz = max(1, int(n * p * density))
+    rows = rng.integers(0, n, nnz)
+    # skewed columns: a few hot ones, many rare ones
+    cols = np.minimum((p * rng.random(nnz) ** 3).astype(np.int64), p - 1)
+    binary = bool(case % 2)
+    vals = np.ones(nnz) if binary else rng.standard_normal(nnz)
+    X = sparse.coo_matrix((vals, (rows, cols)), shape=(n, p)).tocsr()
+    if not binary or case % 3 == 0:
+        X.sum_duplicates()
+    else:
+        # keep duplicates as separate stored entries (legal CSR, values add up)
+        order = np.lexsort((cols, rows))
+        indptr = np.zeros(n + 1, dtype=np.int32)
+        np.add.at(indptr, rows + 1, 1)
+        X = sparse.csr_matrix((vals[order], cols[order].astype(np.int32),
+                               np.cumsum(indptr).astype(np.int32)),
+                              shape=(n, p))
+    return X, binary, rng
+
+
+class TiledLayoutCpu:
+    """ctypes front of libbbx_layout.so: the host-side builder of the tiled
+    layout and the CPU emulator of tiled_spmv_kernel's walk (csrc/
+    tiled_layout.cpp built with g++, no GPU needed)."""
+
+    def __init__(self):
+        import ctypes
+        import os
+        import subprocess
+        from ctypes import POINTER, c_double, c_int, c_int64, c_void_p
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = os.path.join(root, 'bayes-bridge_amd', 'libbbx_layout.so')
+        if not os.path.exists(path):
+            subprocess.check_call(
+                ['make', '-C', os.path.join(root, 'bayes-bridge_amd', 'csrc'),
+                 '../libbbx_layout.so'], stdout=subprocess.DEVNULL)
+        self.lib = ctypes.CDLL(path)
+        self.lib.bbx_layout_emulate.argtypes = (
+            [c_int64] * 3 + [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 2
+            + [POINTER(c_int64), POINTER(c_double)])
+
+    def matvec(self, A, x, packed=False, bank_aware=True, force_PR=0,
+               force_G=0, threads=4):
+        """(A x, info dict) through the layout + emulator; A is R x C CSR
+        with ascending column indices inside each row."""
+        import ctypes
+        A = sparse.csr_matrix(A)
+        R, C = A.shape
+        indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+        if indices.size == 0:
+            indices = np.zeros(1, dtype=np.int32)
+        binary = bool(np.all(A.data == 1.))
+        data = None if binary else np.ascontiguousarray(A.data, np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty(R)
+        info = (ctypes.c_int64 * 8)()
+        cyc = ctypes.c_double()
+        st = self.lib.bbx_layout_emulate(
+            R, C, A.nnz, indptr.ctypes.data, indices.ctypes.data,
+            None if data is None else data.ctypes.data, int(packed),
+            int(bank_aware), int(force_PR), int(force_G), int(threads),
+            x.ctypes.data, out.ctypes.data, info, ctypes.byref(cyc))
+        if st != 0:
+            raise RuntimeError("tiled layout could not be built")
+        keys = ('W', 'n_block', 'PR', 'G', 'n_quad', 'n_slice', 'n_extra',
+                'split_T')
+        meta = dict(zip(keys, (int(v) for v in info)))
+        meta['gather_cycles'] = cyc.value
+        return out, meta

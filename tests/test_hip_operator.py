@@ -255,28 +255,9 @@ def test_random_shapes_and_patterns(case):
     several thousand, rows from empty to dense, binary and valued entries,
     duplicates, with and without intercept / centring."""
     from bayesbridge_amd import HipSparseDesignMatrix
-    rng = np.random.default_rng(1000 + case)
-    n = int(rng.choice([3, 17, 130, 1000, 4097, 9000]))
-    p = int(rng.choice([2, 65, 900, 16128, 16130, 33000, 50000]))
-    density = float(rng.choice([.0005, .004, .03])) if p > 1000 \
-        else float(rng.choice([.02, .2, .7]))
-    nnz = max(1, int(n * p * density))
-    rows = rng.integers(0, n, nnz)
-    # skewed columns: a few hot ones, many rare ones
-    cols = np.minimum((p * rng.random(nnz) ** 3).astype(np.int64), p - 1)
-    binary = bool(case % 2)
-    vals = np.ones(nnz) if binary else rng.standard_normal(nnz)
-    X = sparse.coo_matrix((vals, (rows, cols)), shape=(n, p)).tocsr()
-    if not binary or case % 3 == 0:
-        X.sum_duplicates()
-    else:
-        # keep duplicates as separate stored entries (legal CSR, values add up)
-        order = np.lexsort((cols, rows))
-        indptr = np.zeros(n + 1, dtype=np.int32)
-        np.add.at(indptr, rows + 1, 1)
-        X = sparse.csr_matrix((vals[order], cols[order].astype(np.int32),
-                               np.cumsum(indptr).astype(np.int32)),
-                              shape=(n, p))
+    from helpers import random_sparse_case
+    X, binary, rng = random_sparse_case(case)
+    n, p = X.shape
     center, intercept = bool(case & 4), bool(case & 8)
     from bayesbridge_amd.design_matrix import remove_intercept_indicator
     Xr = remove_intercept_indicator(X.copy())
@@ -298,3 +279,41 @@ def test_random_shapes_and_patterns(case):
         tol_w = 1e-11 * max(1., np.abs(ref_w).max())
         assert np.abs(hip.dot(v) - ref_v).max() <= tol_v, (storage, n, p)
         assert np.abs(hip.Tdot(w) - ref_w).max() <= tol_w, (storage, n, p)
+
+
+@pytest.mark.parametrize("shape", [(9000, 20000, .004), (700, 40000, .003),
+                                   (20000, 1000, .02)])
+def test_kernel_equals_cpu_emulator_bitwise(shape):
+    """tiled_spmv_kernel against the CPU emulator of its walk
+    (csrc/tiled_layout.cpp::emulate_tiled_spmv, also run without a GPU in
+    tests/test_tiled_layout_cpu.py): same layout, same additions in the same
+    order, so binary designs agree BIT FOR BIT on both products; valued ones
+    to rounding (the GPU contracts a*b + c into fused multiply-adds)."""
+    from bayesbridge_amd import HipSparseDesignMatrix, simulate
+    from helpers import TiledLayoutCpu
+    n, p, f = shape
+    layout = TiledLayoutCpu()
+    X = simulate.simulate_binary_csr_fast(n, p, f, seed=11)
+    rng = np.random.default_rng(3)
+    for binary in (True, False):
+        A = X.copy()
+        if not binary:
+            A.data = rng.standard_normal(A.nnz)
+        At = A.T.tocsr()
+        At.sort_indices()
+        hip = HipSparseDesignMatrix(A.copy(), center_predictor=False,
+                                    add_intercept=False, storage='tiled')
+        v, w = rng.standard_normal(p), rng.standard_normal(n)
+        emu_v, info_x = layout.matvec(A, v)
+        emu_w, info_t = layout.matvec(At, w)
+        geo = hip.tiled_info()
+        for side, info in (('X', info_x), ('Xt', info_t)):
+            for key in ('W', 'n_block', 'PR', 'G', 'n_quad', 'n_slice'):
+                assert geo[side][key] == info[key], (side, key)
+        got_v, got_w = hip.dot(v), hip.Tdot(w)
+        if binary:
+            assert np.array_equal(got_v, emu_v)
+            assert np.array_equal(got_w, emu_w)
+        else:
+            assert np.abs(got_v - emu_v).max() <= 1e-13 * np.abs(emu_v).max()
+            assert np.abs(got_w - emu_w).max() <= 1e-13 * np.abs(emu_w).max()

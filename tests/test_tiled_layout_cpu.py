@@ -1,0 +1,100 @@
+"""CPU: the host-side builder of the LDS-tiled layout and the emulator of the
+kernel's walk over it (csrc/tiled_layout.cpp, plain C++ built with g++):
+layout == SciPy on the randomised cases the GPU operator test uses, in every
+build variant, plus ASan/UBSan and TSan runs of the multi-threaded builder.
+The GPU test tests/test_hip_operator.py::test_kernel_equals_cpu_emulator_bitwise
+closes the loop: kernel == emulator bit for bit."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.sparse as sparse
+
+from conftest import ROOT
+from helpers import TiledLayoutCpu, random_sparse_case
+
+
+@pytest.fixture(scope="module")
+def layout():
+    return TiledLayoutCpu()
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_layout_emulation_equals_scipy(layout, case):
+    X, binary, rng = random_sparse_case(case)
+    X.sort_indices()
+    n, p = X.shape
+    v, w = rng.standard_normal(p), rng.standard_normal(n)
+    Xt = X.T.tocsr()
+    Xt.sort_indices()
+    ref_v, ref_w = X @ v, Xt @ w
+    tol_v = 1e-11 * max(1., np.abs(ref_v).max())
+    tol_w = 1e-11 * max(1., np.abs(ref_w).max())
+    variants = [dict(), dict(bank_aware=False)]
+    if case % 4 == 0:
+        variants.append(dict(force_PR=128, force_G=2, threads=3))
+    if binary:
+        variants.append(dict(packed=True))
+    for kw in variants:
+        out_v, info_v = layout.matvec(X, v, **kw)
+        out_w, info_w = layout.matvec(Xt, w, **kw)
+        assert np.abs(out_v - ref_v).max() <= tol_v, (kw, info_v)
+        assert np.abs(out_w - ref_w).max() <= tol_w, (kw, info_w)
+        # every layout fits the CU's LDS next to 2 KB of static use
+        for info in (info_v, info_w):
+            lds = 8 * (info['W'] + 8 + info['PR'] + info['n_extra'])
+            assert lds <= 160 * 1024 - 2048 + 8 * 8, info
+    # binary designs: the emulator adds whole numbers exactly
+    if binary and np.all(v == np.round(v)):
+        assert np.array_equal(out_v, ref_v)
+
+
+def test_integer_vectors_give_exact_sums(layout):
+    """With integer-valued inputs every partial sum is exact, so the layout
+    (row splitting, fold order, slab order) must reproduce SciPy bit for bit."""
+    from bayesbridge_amd import simulate
+    X = simulate.simulate_binary_csr_fast(9000, 20000, .004, seed=7)
+    rng = np.random.default_rng(1)
+    v = rng.integers(-50, 50, X.shape[1]).astype(np.float64)
+    w = rng.integers(-50, 50, X.shape[0]).astype(np.float64)
+    Xt = X.T.tocsr()
+    Xt.sort_indices()
+    for kw in (dict(), dict(packed=True), dict(force_PR=256, force_G=2)):
+        assert np.array_equal(layout.matvec(X, v, **kw)[0], X @ v)
+        assert np.array_equal(layout.matvec(Xt, w, **kw)[0], Xt @ w)
+
+
+def test_bank_aware_order_lowers_lds_conflicts(layout):
+    """The builder's entry order inside rows: fewer LDS cycles per gather
+    (1.0 = conflict free; ascending ids give ~3.4) and the same sums."""
+    from bayesbridge_amd import simulate
+    # big panels (4096 rows: two slices per wave, no chunking for occupancy),
+    # ~60 entries per row segment, like the tiles of the headline config
+    X = simulate.simulate_binary_csr_fast(16384, 16000, .004, seed=3)
+    Xt = X.T.tocsr()
+    Xt.sort_indices()
+    rng = np.random.default_rng(2)
+    for A in (X, Xt):
+        x = rng.standard_normal(A.shape[1])
+        plain, ip = layout.matvec(A, x, bank_aware=False, force_PR=4096)
+        tuned, it = layout.matvec(A, x, bank_aware=True, force_PR=4096)
+        assert np.abs(plain - tuned).max() <= 1e-12 * np.abs(plain).max()
+        assert ip['n_quad'] == it['n_quad']          # not a byte more
+        assert ip['gather_cycles'] > 2.5
+        assert it['gather_cycles'] < .7 * ip['gather_cycles'], (ip, it)
+
+
+def test_builder_under_address_undefined_and_thread_sanitizers():
+    """make sanitize: the self-test driver (random matrices, 4 builder threads,
+    plain/packed/valued layouts, emulation vs a plain CSR product) under
+    -fsanitize=address,undefined and -fsanitize=thread."""
+    res = subprocess.run(
+        ['make', '-C', os.path.join(ROOT, 'bayes-bridge_amd', 'csrc'),
+         'sanitize'], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert 'FAILED' not in res.stdout + res.stderr
+    assert 'WARNING: ThreadSanitizer' not in res.stderr
+    assert 'ERROR: AddressSanitizer' not in res.stderr
+    assert 'runtime error' not in res.stderr
+    assert res.stdout.count('max err') >= 14        # both binaries ran
