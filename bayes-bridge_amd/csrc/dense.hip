@@ -98,6 +98,81 @@ __global__ __launch_bounds__(256) void dense_dot_kernel(
   }
 }
 
+// The same GEMV on the matrix cores (opt-in, BBX_DENSE_MFMA=1): the A/B
+// measurement BASELINE.json's "MFMA-tiled GEMV for dense X" asks for.
+// v_mfma_f64_16x16x4_f64 computes D[16x16] += A[16x4] B[4x16]; a GEMV has ONE
+// right-hand side, so the 16 columns of B all carry the same slice of v and 15
+// of the 16 result columns are redundant (there is no way to give the columns
+// different k-slices: A is shared by all of them).  A wave owns 16 rows; lane
+// (i = l & 15, k = l >> 4) loads 16 bytes X[i][16c + 4k .. 4k+3] (the four
+// lanes of a row cover one 64-byte segment), converts to f64 and feeds four
+// MFMAs per load.  Operand maps (cdna_hip_programming.md, "f64 MFMA"):
+// A[l&15][l>>4], B[l>>4][l&15], D col = l & 15, row = (l >> 4) + 4 reg.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void dense_dot_mfma_kernel(
+    int64_t n, int64_t P, int64_t ld, const float* __restrict__ X,
+    const double* __restrict__ v, const double* __restrict__ rowscale,
+    double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double vs[];
+  for (int64_t j = threadIdx.x; j < ld + 16; j += 256) vs[j] = (j < P) ? v[j] : 0.;
+  __syncthreads();
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int i = lane & 15, k = lane >> 4;
+  const int64_t blk0 = (int64_t)blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+  const int64_t n_wave = (int64_t)gridDim.x * (256 / WAVE);
+  const int64_t n_blk = (n + 15) / 16;
+  const int64_t n_chunk = (ld + 15) / 16;
+  for (int64_t blk = blk0; blk < n_blk; blk += n_wave) {
+    int64_t row = blk * 16 + i;
+    const bool live = row < n;
+    if (!live) row = n - 1;
+    const float* __restrict__ xr = X + row * ld + 4 * k;
+    mfma_d4 acc = {0., 0., 0., 0.};
+    int64_t c = 0;
+    for (; c + 3 < n_chunk; c += 4) {
+      float4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t col = 16 * (c + u) + 4 * k;
+        x[u] = (col < ld) ? stream_load(reinterpret_cast<const float4*>(
+                                xr + 16 * (c + u)))
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* b = vs + 16 * (c + u) + 4 * k;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].x, b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].y, b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].z, b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].w, b[3], acc, 0, 0, 0);
+      }
+    }
+    for (; c < n_chunk; ++c) {
+      const int64_t col = 16 * c + 4 * k;
+      const float4 x0 = (col < ld) ? stream_load(reinterpret_cast<const float4*>(
+                                         xr + 16 * c))
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      const double* b = vs + col;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x0.x, b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x0.y, b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x0.z, b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x0.w, b[3], acc, 0, 0, 0);
+    }
+    // every column of D holds the result; column 0 lives in lanes 0, 16, 32, 48
+    if (i == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t orow = blk * 16 + k + 4 * r;
+        if (orow < n) {
+          double a = acc[r];
+          if (rowscale) a *= rowscale[orow];
+          out[orow] = a;
+        }
+      }
+    }
+  }
+}
+
 // slab[chunk][j] = sum over the chunk's rows of X[i, j] w[i]
 template <typename T>
 __global__ __launch_bounds__(256) void dense_tdot_kernel(
@@ -322,8 +397,15 @@ int launch_dot_dense(bbx_design* h, const double* d_v,
   const size_t lds = sizeof(double) * (size_t)h->dense_ld;
   if (lds > 150 * 1024)
     return fail(BBX_ERR_INVALID, "dense operator: more than 19200 columns");
+  // opt-in matrix-core variant (A/B only: DESIGN.md 3.3)
+  static const bool use_mfma =
+      getenv("BBX_DENSE_MFMA") && atoi(getenv("BBX_DENSE_MFMA")) == 1;
   BBX_TRY(timer_begin(h, 0));
-  if (h->dense_dtype == BBX_F32)
+  if (h->dense_dtype == BBX_F32 && use_mfma)
+    hipLaunchKernelGGL(dense_dot_mfma_kernel, dim3(1024), dim3(256),
+                       lds + 16 * sizeof(double), h->stream, h->n, h->P,
+                       h->dense_ld, h->dense.as<float>(), d_v, d_rowscale, d_t);
+  else if (h->dense_dtype == BBX_F32)
     hipLaunchKernelGGL(dense_dot_kernel<float>, dim3((unsigned)nb), dim3(256),
                        lds, h->stream, h->n, h->P, h->dense_ld,
                        h->dense.as<float>(), d_v, d_rowscale, d_t);
@@ -467,6 +549,9 @@ static int create_dense_common(int64_t n, int64_t p, const void* X,
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     BBX_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&dense_dot_kernel<double>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    BBX_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&dense_dot_mfma_kernel),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return BBX_OK;
   };

@@ -205,3 +205,23 @@ def test_config4_scaled_reference_chain_through_f32_storage(golden_dir):
                            rtol=1e-5)
         assert np.allclose(s['obs_prec'], g['obs_prec_samples'], rtol=1e-6)
         assert np.allclose(s['logp'], g['logp_samples'], rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(4097, 801), (20000, 4000), (513, 16)])
+def test_matrix_core_gemv_variant_gives_the_same_product(shape):
+    """The opt-in MFMA GEMV (dense_dot_mfma_kernel, BBX_DENSE_MFMA=1; the A/B
+    of DESIGN.md 3.3) against torch f64 on the stored values -- the script
+    asserts <= 1e-11 relative -- for shapes with ragged row blocks / column
+    chunks.  The environment switch is read once per process, hence the
+    subprocess."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    for flag in ("1", "0"):
+        env = dict(os.environ, BBX_DENSE_MFMA=flag)
+        res = subprocess.run(
+            [sys.executable, os.path.join(ROOT, "scripts", "ab_dense_mfma.py"),
+             str(shape[0]), str(shape[1]), "3"],
+            env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        assert "BBX_DENSE_MFMA=%s" % flag in res.stdout
