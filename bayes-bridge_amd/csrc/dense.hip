@@ -127,7 +127,10 @@ __global__ __launch_bounds__(256) void dense_dot_mfma_kernel(
     const bool live = row < n;
     if (!live) row = n - 1;
     const float* __restrict__ xr = X + row * ld + 4 * k;
-    mfma_d4 acc = {0., 0., 0., 0.};
+    // four independent accumulators: back-to-back MFMAs on ONE accumulator
+    // serialise on its 8-pass latency (measured: 1.67 ms instead of the rate
+    // below); they are added once at the end
+    mfma_d4 acc = {0., 0., 0., 0.}, acc1 = acc, acc2 = acc, acc3 = acc;
     int64_t c = 0;
     for (; c + 3 < n_chunk; c += 4) {
       float4 x[4];
@@ -142,9 +145,9 @@ __global__ __launch_bounds__(256) void dense_dot_mfma_kernel(
       for (int u = 0; u < 4; ++u) {
         const double* b = vs + 16 * (c + u) + 4 * k;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].x, b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].y, b[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].z, b[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].w, b[3], acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].y, b[1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].z, b[2], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x[u].w, b[3], acc3, 0, 0, 0);
       }
     }
     for (; c < n_chunk; ++c) {
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(256) void dense_dot_mfma_kernel(
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x0.z, b[2], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)x0.w, b[3], acc, 0, 0, 0);
     }
+    acc = (acc + acc1) + (acc2 + acc3);
     // every column of D holds the result; column 0 lives in lanes 0, 16, 32, 48
     if (i == 0) {
 #pragma unroll

@@ -46,12 +46,15 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--burnin", type=int, default=40,
+    ap.add_argument("--burnin", type=int, default=None,
                     help="untimed Gibbs iterations run as part of the chain's "
                          "initialisation (the reference runs an L-BFGS mode "
-                         "search there, bayesbridge.py:333), so that the CG "
-                         "warm start / preconditioner summaries are "
-                         "stationary when the W warm-up steps begin")
+                         "search there, bayesbridge.py:333) so that the chain "
+                         "is past its transient when the W warm-up steps "
+                         "begin: tau, logp and n_cg are stationary after "
+                         "~250-300 iterations at config 3 "
+                         "(profiles/r02_ncg_trajectory.txt).  Default: 300 for "
+                         "the sparse configs, 10 for config4")
     ap.add_argument("--config", default="config3", choices=sorted(CONFIGS))
     ap.add_argument("--storage", default="auto",
                     choices=["auto", "csr", "tiled"])
@@ -272,6 +275,8 @@ def main():
     chain.init_obs_prec()
 
     K, W, B = args.steps, args.warmup, args.burnin
+    if B is None:
+        B = 10 if dense else 300
     ncg_b = chain.run_device(B)[2] if B > 0 else np.zeros(0)
     ncg_w = chain.run_device(W)[2] if W > 0 else np.zeros(0)
     # state after warm-up (for the CPU baselines)
