@@ -1,5 +1,6 @@
 // extern "C" entry points of libbbx.so (declared in include/bbx.h): handle
 // life cycle, host-pointer wrappers, format dispatch, kernel timers.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -87,8 +88,7 @@ static int timer_collect(bbx_design* h) {
     for (auto& pr : h->timer.pending[which]) {
       float ms = 0.f;
       BBX_HIP(hipEventElapsedTime(&ms, pr.a, pr.b));
-      h->timer.total_ms[which] += (double)ms;
-      h->timer.n_launch[which] += 1;
+      h->timer.samples[which].push_back(ms);
       h->timer.pool.push_back(pr);
     }
     h->timer.pending[which].clear();
@@ -780,8 +780,24 @@ static int bbx_design_get_timing_impl(bbx_design* h, int which, int64_t* n_launc
     return fail(BBX_ERR_INVALID, "which must be 0, 1 or 2");
   BBX_HIP(hipSetDevice(h->device));
   BBX_TRY(timer_collect(h));
-  if (n_launch) *n_launch = h->timer.n_launch[which];
-  if (total_ms) *total_ms = h->timer.total_ms[which];
+  // real executions only: drop samples below half the median (launches that
+  // found the solve's stop flag set and returned at entry)
+  std::vector<float> v = h->timer.samples[which];
+  int64_t cnt = 0;
+  double tot = 0.;
+  if (!v.empty()) {
+    std::vector<float> sorted = v;
+    std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2,
+                     sorted.end());
+    const float floor_ms = .5f * sorted[sorted.size() / 2];
+    for (float ms : v)
+      if (ms >= floor_ms) {
+        ++cnt;
+        tot += (double)ms;
+      }
+  }
+  if (n_launch) *n_launch = cnt;
+  if (total_ms) *total_ms = tot;
   return BBX_OK;
 }
 
@@ -797,10 +813,8 @@ int bbx_design_reset_timing(bbx_design* h) {
   BBX_TRY(check_handle(h));
   BBX_HIP(hipSetDevice(h->device));
   BBX_TRY(timer_collect(h));
-  for (int which = 0; which < KernelTimer::FAMILIES; ++which) {
-    h->timer.n_launch[which] = 0;
-    h->timer.total_ms[which] = 0.;
-  }
+  for (int which = 0; which < KernelTimer::FAMILIES; ++which)
+    h->timer.samples[which].clear();
   return BBX_OK;
 }
 

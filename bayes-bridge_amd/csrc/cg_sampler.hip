@@ -191,9 +191,23 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
       use_fused && h->P <= (int64_t)NPART * VEC_BLOCK * 4;  // FUSED_EMAX
   int k = 0;
   bool done = false;
-  // Enqueue close to the previous solve's iteration count before the first
-  // poll, then poll every other iteration.
-  int next_poll = h->last_cg_iter > 2 ? h->last_cg_iter - 1 : 1;
+  // From here on the operator kernels look at the stop flag and exit at entry
+  // once it is set, so an iteration enqueued past the stopping one costs a few
+  // microseconds of empty launches instead of two passes over the matrix.
+  // That makes running ahead cheap: enqueue a little MORE than the previous
+  // solve needed before the first look at the flag (a look is a stream sync:
+  // the GPU idles until the host has refilled the queue), then every other
+  // iteration.
+  struct SkipScope {
+    bbx_design* h;
+    ~SkipScope() { h->skip_flag = nullptr; }
+  } skip_scope{h};
+  static const bool no_skip =
+      getenv("BBX_CG_NO_SKIP") && atoi(getenv("BBX_CG_NO_SKIP")) == 1;
+  h->skip_flag = no_skip ? nullptr : &st->done;
+  int next_poll = h->last_cg_iter > 2
+                      ? h->last_cg_iter + (no_skip ? -1 : 2)
+                      : 1;
   if (fused) {
     // direction(0) on its own; afterwards ONE vector launch per iteration does
     // the Tdot epilogue, the update and the next direction (vecops.hip).

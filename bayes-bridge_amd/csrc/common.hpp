@@ -103,8 +103,10 @@ struct KernelTimer {
   };
   std::vector<Pair> pending[FAMILIES];
   std::vector<Pair> pool;
-  int64_t n_launch[FAMILIES] = {0, 0, 0};
-  double total_ms[FAMILIES] = {0., 0., 0.};
+  // every resolved sample; the totals reported leave out launches that exited
+  // at entry because their CG solve had already stopped (see skip_flag): they
+  // take a few microseconds and are not executions of the kernel
+  std::vector<float> samples[FAMILIES];
 };
 
 }  // namespace bbx
@@ -158,6 +160,11 @@ struct bbx_design {
 
   int64_t n_dot = 0, n_tdot = 0;
   int last_cg_iter = 0;  // iterations of the previous solve (poll scheduling)
+  // Set around the CG loop: device address of CGState::done.  The host
+  // enqueues operator applications ahead of the stop test; once the rule has
+  // fired the big kernels see the flag and exit at entry instead of streaming
+  // the matrix for an iteration that does not exist.
+  const int* skip_flag = nullptr;
   bbx::KernelTimer timer;
 };
 

@@ -238,7 +238,9 @@ template <typename T, int KQ, int RB>
 __global__ __launch_bounds__(1024) void dense_fused_kernel(
     int64_t n, int64_t P, int64_t ld, int64_t rows_per_wg,
     const T* __restrict__ X, const double* __restrict__ v,
-    const double* __restrict__ rowscale, double* __restrict__ slab) {
+    const double* __restrict__ rowscale, double* __restrict__ slab,
+    const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;  // the CG solve has already stopped
   __shared__ double red[2][RB][1024 / WAVE];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const int64_t ldq = ld / 4;
@@ -355,7 +357,7 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
   hipLaunchKernelGGL((dense_fused_kernel<TT, KQ, RB>), dim3(wgs), dim3(1024),  \
                      0, h->stream, h->n, h->P, h->dense_ld, rows_per_wg,       \
                      h->dense.as<TT>(), d_v, d_rowscale,                       \
-                     h->dense_fused_slab.as<double>())
+                     h->dense_fused_slab.as<double>(), h->skip_flag)
   if (h->dense_dtype != BBX_F32) {
     BBX_FUSED_LAUNCH(double, 1, 2);
   } else if (kq1) {

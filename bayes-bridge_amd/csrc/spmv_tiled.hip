@@ -205,7 +205,10 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     double* __restrict__ slab, int n_acc,
     const int32_t* __restrict__ panel_fold, const FoldDesc* __restrict__ folds,
     double* __restrict__ out_sum_part, int ablate,
-    unsigned long long* dbg) {
+    unsigned long long* dbg, const int* __restrict__ skip_flag) {
+  // (scalar load, issued first; checked below once the descriptor loads that
+  // every launch needs anyway have been issued, so it adds no round trip)
+  const int skip = skip_flag ? *skip_flag : 0;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* xs = lds;               // W + 8 doubles; xs[W] == 0 (padding target)
   double* acc = lds + (W + 8);    // n_acc = PR + extra doubles
@@ -251,6 +254,15 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   uint4 dnxt = desc4[blk + WAVE + lane];
   // Retire every compiler-visible load before the ring starts (see ISSUE).
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+  if (skip) return;  // the CG solve this launch belongs to has already stopped
+  // (Round 2 tried to move the FIRST slice fill up here, next to the descriptor
+  // loads, and to enter the loop with the ring primed but not waited for: the
+  // kernel then faulted intermittently.  Without the vmcnt(0) of the first
+  // tile switch the compiler's loop-entry copies of the ring registers can run
+  // before the asm loads have landed; a landing load then overwrites a
+  // register the compiler has re-used, e.g. for an address.  With a vmcnt(0)
+  // after the priming the start-up is two dependent round trips again --
+  // descriptors, then ids -- exactly as below, so nothing is gained.)
   v4u e[RING][BATCH];
   v2d ev[RING][BATCH][NV];
   unsigned rid[RING];
@@ -704,7 +716,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                      m.ids.as<uint4>(), VALPTR, x, c_part, x0_ptr, rowscale,   \
                      out, slab, m.PR + m.n_extra,                              \
                      m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),       \
-                     out_sum_part, ablate, dbg)
+                     out_sum_part, ablate, dbg, h->skip_flag)
 #define BBX_TILED_LAUNCH(VV, PP, VALPTR)                                       \
   do {                                                                         \
     if (wide) BBX_TILED_LAUNCH_W(VV, PP, true, VALPTR);                        \

@@ -269,7 +269,10 @@ int bbx_design_set_timing(bbx_design* h, int enabled);
  * which = 0 dot (X v; for dense designs inside the CG loop: the single-pass
  * operator kernel), 1 Tdot (X^T w, main kernel), 2 one whole application of
  * the CG operator (dot + Tdot + epilogue; bracketed by two record commands,
- * which adds ~2-3 us of dispatch to the interval). */
+ * which adds ~2-3 us of dispatch to the interval).  Launches that returned at
+ * entry because their CG solve had already stopped (the host enqueues ahead
+ * of the stop test) are not executions and are left out: samples below half
+ * the family's median are dropped. */
 int bbx_design_get_timing(bbx_design* h, int which, int64_t* n_launch,
                           double* total_ms);
 int bbx_design_reset_timing(bbx_design* h);
