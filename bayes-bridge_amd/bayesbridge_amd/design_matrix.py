@@ -25,18 +25,25 @@ def _ptr(a):
 
 
 def remove_intercept_indicator(X):
-    """Drops zero-variance columns (abstract_matrix.py:93-107)."""
+    """Columns that are constant over the rows (an intercept the caller added
+    by hand, or numerically the same thing) are dropped: the operator adds its
+    own intercept and a constant column would be collinear with it.  Same rule
+    as the reference (abstract_matrix.py:93-107): population variance below
+    n_rows * 2**-52."""
+    n_rows = X.shape[0]
     if sparse.issparse(X):
-        col_variance = np.squeeze(np.array(
-            X.power(2).mean(axis=0) - np.power(X.mean(axis=0), 2)))
+        first = np.asarray(X.mean(axis=0)).ravel()
+        second = np.asarray(X.multiply(X).mean(axis=0)).ravel()
+        variance = second - first ** 2
     else:
-        col_variance = np.var(X, axis=0)
-    has_zero_variance = (col_variance < X.shape[0] * 2 ** -52)
-    if np.any(has_zero_variance):
+        variance = np.var(X, axis=0)
+    constant = variance < n_rows * 2. ** -52
+    if constant.any():
         warnings.warn(
-            "Intercept column (or numerically indistinguishable from "
-            "such) detected. Do not add intercept manually. Removing....")
-        X = X[:, np.logical_not(has_zero_variance)]
+            "%d constant column(s) found in the design matrix and removed: "
+            "the intercept is added by the model, not by the caller."
+            % int(constant.sum()))
+        X = X[:, ~constant]
     return X
 
 

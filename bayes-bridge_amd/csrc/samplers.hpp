@@ -45,27 +45,30 @@ BBX_HD inline double pos_pow(double x, double y) {
 #endif
 }
 
-// log of the standard normal cdf.  The reference vendors Cephes' log_ndtr
-// (random/polya_gamma/scipy_ndtr.c:367): log(ndtr(a)) above -20 and an
-// asymptotic series below; same split here on top of erfc.
+// log Phi(a), the log of the standard normal cdf (the reference calls the
+// log_ndtr it vendors from SciPy, random/polya_gamma/scipy_ndtr.c:367, at
+// polya_gamma.pyx:188-189).  Own formulation:
+//   a >  6        Phi = 1 - Q, Q = erfc(a/sqrt2)/2 < 1e-9, log(1 - Q) = -Q to
+//                 better than Q^2/2 < 1e-18;
+//   -20 < a <= 6  log(erfc(-a/sqrt2)/2) directly: erfc does not underflow here;
+//   a <= -20      Mills-ratio asymptotic expansion (Abramowitz & Stegun 26.2.12)
+//                   Phi(a) = phi(a)/(-a) * sum_k (-1)^k (2k-1)!! / a^(2k),
+//                 whose terms shrink by the factor (2k-1)/a^2 <= 1/400 * (2k-1);
+//                 summed until a term no longer changes the sum.
 BBX_HD inline double log_norm_cdf(double a) {
-  if (a > 6.) return -0.5 * erfc(a * 0.70710678118654752440);  // log(1-e) ~ -e
-  if (a > -20.) return log(0.5 * erfc(-a * 0.70710678118654752440));
-  const double log_lhs = -0.5 * a * a - log(-a) - 0.91893853320467274178;
-  const double denom_factor = 1.0 / (a * a);
-  double last_total = 0., right_hand_side = 1., numerator = 1.;
-  double denom_cons = 1.;
-  long sign = 1, i = 0;
-  while (fabs(last_total - right_hand_side) > 2.220446049250313e-16) {
-    i += 1;
-    last_total = right_hand_side;
-    sign = -sign;
-    denom_cons *= denom_factor;
-    numerator *= (double)(2 * i - 1);
-    right_hand_side += (double)sign * numerator * denom_cons;
-    if (i > 50) break;
+  constexpr double kInvSqrt2 = 0.70710678118654752440;
+  constexpr double kHalfLog2Pi = 0.91893853320467274178;
+  if (a > 6.) return -0.5 * erfc(a * kInvSqrt2);
+  if (a > -20.) return log(0.5 * erfc(-a * kInvSqrt2));
+  const double inv_a2 = 1. / (a * a);
+  double series = 1., term = 1.;
+  for (int k = 1; k <= 50; ++k) {
+    term *= -(double)(2 * k - 1) * inv_a2;
+    const double next = series + term;
+    if (next == series) break;
+    series = next;
   }
-  return log_lhs + log(right_hand_side);
+  return -0.5 * a * a - log(-a) - kHalfLog2Pi + log(series);
 }
 
 // ------------------------------------------------------------ Polya-Gamma
