@@ -576,11 +576,11 @@ static int upload(DevMem& dst, const void* src, size_t bytes) {
 // Builds one orientation on the host (tiled_layout.cpp) and moves it to HBM.
 static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
                      const int32_t* rowptr, const int32_t* colidx,
-                     const double* vals) {
+                     const double* vals, bool transpose) {
   TiledHost host;
   std::string err;
-  if (build_tiled_host(R, C, nnz, rowptr, colidx, vals, TiledOptions::from_env(),
-                       &host, &err) != 0)
+  if (build_tiled_host(R, C, nnz, rowptr, colidx, vals,
+                       TiledOptions::from_env(transpose), &host, &err) != 0)
     return fail(BBX_ERR_INVALID, err);
   m.R = host.R;
   m.C = host.C;
@@ -644,7 +644,7 @@ int build_tiled(bbx_design* h) {
   if (!tp) return fail(BBX_ERR_INVALID, "out of host memory");
   h->tiled = tp;
   BBX_TRY(build_one(tp->x, n, p, nnz, rowptr.data(), colidx.data(),
-                    h->binary ? nullptr : vals.data()));
+                    h->binary ? nullptr : vals.data(), false));
   // transpose orientation from the CSR of X^T built on the device
   rowptr.assign((size_t)p + 1, 0);
   BBX_HIP(hipMemcpy(rowptr.data(), h->t_indptr.ptr, sizeof(int32_t) * (size_t)(p + 1),
@@ -656,7 +656,7 @@ int build_tiled(bbx_design* h) {
     BBX_HIP(hipMemcpy(vals.data(), h->t_data.ptr, sizeof(double) * (size_t)nnz,
                       hipMemcpyDeviceToHost));
   BBX_TRY(build_one(tp->xt, p, n, nnz, rowptr.data(), colidx.data(),
-                    h->binary ? nullptr : vals.data()));
+                    h->binary ? nullptr : vals.data(), true));
   for (const TiledMatrix* m : {&tp->x, &tp->xt}) {
     const size_t lb = lds_bytes(*m);
     if (lb > (size_t)TILE_LDS_BYTES)

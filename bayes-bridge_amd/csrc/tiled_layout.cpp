@@ -12,11 +12,18 @@
 
 namespace bbx {
 
-TiledOptions TiledOptions::from_env() {
+TiledOptions TiledOptions::from_env(bool transpose) {
   TiledOptions o;
+  auto geti = [&](const char* name, int* dst) {
+    std::string key(name);
+    const char* e = transpose ? getenv((key + "_T").c_str()) : nullptr;
+    if (!e) e = getenv(name);
+    if (e) *dst = atoi(e);
+  };
   if (const char* e = getenv("BBX_TILED_PACK")) o.packed = atoi(e) == 1;
-  if (const char* e = getenv("BBX_TILED_PR")) o.force_PR = atoi(e);
-  if (const char* e = getenv("BBX_TILED_G")) o.force_G = atoi(e);
+  geti("BBX_TILED_PR", &o.force_PR);
+  geti("BBX_TILED_G", &o.force_G);
+  geti("BBX_TILED_BLOCKS", &o.force_blocks);
   if (const char* e = getenv("BBX_TILED_EXTRA")) o.extra_budget = atoi(e);
   if (const char* e = getenv("BBX_TILED_TFACTOR")) o.t_factor = atof(e);
   if (const char* e = getenv("BBX_TILED_BANKS")) o.bank_aware = atoi(e) != 0;
@@ -624,7 +631,11 @@ static void choose_shape(int64_t R, int64_t C, int64_t nnz, int n_block, int W,
   double best = 1e300;
   int best_pr = 256, best_g = 1;
   const int lds_rows = (int)((TILE_LDS_BYTES - 2048) / 8) - (W + 8);
-  int pr_cap = TILE_PR_MAX;
+  // (panels beyond 4096 rows only through BBX_TILED_PR[_T]: at 1M x 50k the
+  // X^T geometries PR = 6272 x 96 blocks x G = 32 and PR = 5056 x 75 x 25 ran
+  // the main kernel in 46.9 / 49.7 us against 48.5 us, with twice the slab
+  // traffic for the epilogue kernel -- profiles/r02_ab_geometry.txt)
+  int pr_cap = TILE_PR_MAX < 4096 ? TILE_PR_MAX : 4096;
   if (lds_rows - 256 < pr_cap) pr_cap = lds_rows - 256;  // room for extras
   if (pr_cap < 128) pr_cap = 128;
   for (int pr = 128; pr <= pr_cap; pr += 128) {
@@ -669,6 +680,7 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   // bytes, so the achieved HBM rate DROPS.  Kept for footprint-bound uses.
   m.packed = !m.has_vals && opt.packed;
   m.n_block = (int)((C + TILE_W_MAX - 1) / TILE_W_MAX);
+  if (opt.force_blocks > m.n_block) m.n_block = opt.force_blocks;
   if (m.n_block < 1) m.n_block = 1;
   int64_t w = (C + m.n_block - 1) / m.n_block;
   w = (w + 63) / 64 * 64;

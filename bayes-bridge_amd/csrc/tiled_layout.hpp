@@ -27,7 +27,7 @@ namespace bbx {
 #endif
 constexpr int LANES = 64;                   // gfx950 wavefront
 constexpr int TILE_W_MAX = BBX_TILE_W_MAX;  // doubles of the vector slice in LDS
-constexpr int TILE_PR_MAX = 4096;           // row accumulators in LDS
+constexpr int TILE_PR_MAX = 8192;           // row accumulators in LDS
 constexpr int TILE_THREADS = BBX_TILE_THREADS;
 constexpr int TILE_LDS_BYTES = BBX_TILE_LDS_KB * 1024;
 constexpr int TILE_WG_PER_CU = (160 / BBX_TILE_LDS_KB);
@@ -80,12 +80,14 @@ struct TiledOptions {
   bool packed = false;       // BBX_TILED_PACK=1: 14-bit base + 4 x 12-bit deltas
   int force_PR = 0;          // BBX_TILED_PR
   int force_G = 0;           // BBX_TILED_G
+  int force_blocks = 0;      // BBX_TILED_BLOCKS: number of column blocks
   int extra_budget = -1;     // BBX_TILED_EXTRA (< 0: what LDS leaves)
   double t_factor = 0.;      // BBX_TILED_TFACTOR (0: automatic)
   bool bank_aware = true;    // BBX_TILED_BANKS=0 switches the entry ordering off
   bool stats = false;        // BBX_TILED_STATS=1
   int max_threads = 64;
-  static TiledOptions from_env();
+  // transpose: the X^T orientation reads BBX_TILED_PR_T / _G_T / _BLOCKS_T first
+  static TiledOptions from_env(bool transpose = false);
 };
 
 // One orientation (X or X^T) in tiled form, host resident.
