@@ -191,6 +191,7 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
       use_fused && h->P <= (int64_t)NPART * VEC_BLOCK * 4;  // FUSED_EMAX
   int k = 0;
   bool done = false;
+  bool finished_at_poll = false;
   // From here on the operator kernels look at the stop flag and exit at entry
   // once it is set, so an iteration enqueued past the stopping one costs a few
   // microseconds of empty launches instead of two passes over the matrix.
@@ -261,11 +262,18 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     // with the next direction kernel; peek at the flag it left behind.
     BBX_TRY(launch_cg_direction(h, k, st, part_slot(h, PS_RR), r, pvec, s, sp,
                                 part_slot(h, PS_C)));
+    // coef = s .* x goes out BEFORE the look at the flag: if the rule has
+    // fired (the common case: the first look comes a little after the
+    // previous solve's count) the draw is complete when the host wakes up and
+    // nothing more has to be launched or waited for; if not, it is simply
+    // overwritten at the end.
+    BBX_TRY(launch_cg_finish(h, s, x, d_coef));
     BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,
                            h->stream));
     BBX_HIP(hipStreamSynchronize(h->stream));
     if (host_st->done) {
       done = true;
+      finished_at_poll = true;  // host_st is final: later kernels exit at entry
       break;
     }
     // direction(k) already ran: finish iteration k, then continue.
@@ -276,10 +284,12 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     next_poll = k + 2;
   }
   }
-  BBX_TRY(launch_cg_finish(h, s, x, d_coef));
-  BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,
-                         h->stream));
-  BBX_HIP(hipStreamSynchronize(h->stream));
+  if (!finished_at_poll) {
+    BBX_TRY(launch_cg_finish(h, s, x, d_coef));
+    BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,
+                           h->stream));
+    BBX_HIP(hipStreamSynchronize(h->stream));
+  }
   const int n_iter = host_st->n_iter;
   // Operator applications enqueued past the stopping iteration exited at entry
   // (their kernels see `done`): they are not matvecs and do not count
