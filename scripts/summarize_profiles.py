@@ -16,8 +16,10 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    files = glob.glob(os.path.join(src, pattern))
-    return pd.read_csv(files[0]) if files else None
+    # gpurun merges every call's output into the same directories: the newest
+    # file of a pass is the one that belongs to the current code
+    files = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
+    return pd.read_csv(files[-1]) if files else None
 
 
 def short(name):
@@ -45,8 +47,14 @@ def trace_summary(sub, pattern):
     t["short"] = t.Kernel_Name.map(short)
     for (name, g, wg), sel in t.groupby(["short", "Grid_Size_X",
                                          "Workgroup_Size_X"]):
+        # launches that found their CG solve already stopped return at entry
+        # (a few microseconds): they are not executions of the kernel
+        floor_us = .5 * sel.dur_us.median()
+        n_all = len(sel)
+        sel = sel[sel.dur_us >= floor_us]
         out["%s grid=%d" % (name.split("::")[-1], g // wg)] = dict(
-            launches=int(len(sel)), avg_us=float(sel.dur_us.mean()),
+            launches=int(len(sel)), returned_at_entry=int(n_all - len(sel)),
+            avg_us=float(sel.dur_us.mean()),
             median_us=float(sel.dur_us.median()),
             min_us=float(sel.dur_us.min()),
             vgpr=int(sel.VGPR_Count.iloc[0]), sgpr=int(sel.SGPR_Count.iloc[0]))
@@ -60,6 +68,8 @@ def pmc(sub, pattern, wg=1024):
         return out
     d = d[d.Kernel_Name.str.contains(pattern)]
     for (grid, cname), grp in d.groupby(["Grid_Size", "Counter_Name"]):
+        # (same filter: dispatches that returned at entry move no bytes)
+        grp = grp[grp.Counter_Value >= .5 * grp.Counter_Value.median()]
         out.setdefault("grid=%d" % (grid // wg), {})[cname] = dict(
             mean=float(grp.Counter_Value.mean()),
             min=float(grp.Counter_Value.min()),
