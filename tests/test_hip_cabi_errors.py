@@ -122,3 +122,99 @@ def test_chain_argument_checks(design):
     assert lib.bbx_chain_set_iteration(c, -1) == ERR_INVALID
     assert lib.bbx_chain_destroy(c) == 0
     assert lib.bbx_chain_get_state(None, None, None, None, None) == ERR_INVALID
+
+
+def test_round2_entry_points_argument_checks(design):
+    """The entry points added in round 2: gram_matvec, timed / fused bytes,
+    device, chain seed / gscale mode / eta / logp, device normals."""
+    from ctypes import c_double, c_int64, c_uint64
+    from bayesbridge_amd import _lib
+    lib = _lib.load()
+    h = design.handle
+    n, P = design.shape
+    om, v, out = np.ones(n), np.ones(P), np.empty(P)
+    assert lib.bbx_design_gram_matvec(None, _p(om), _p(v), _p(out)) == ERR_INVALID
+    assert lib.bbx_design_gram_matvec(h, None, _p(v), _p(out)) == ERR_INVALID
+    assert lib.bbx_design_gram_matvec(h, _p(om), _p(v), None) == ERR_INVALID
+    assert lib.bbx_design_gram_matvec(h, _p(om), _p(v), _p(out)) == 0
+    assert np.allclose(out, design.Tdot(design.dot(v)), rtol=1e-12, atol=1e-10)
+    a, b = c_int64(), c_int64()
+    assert lib.bbx_design_timed_bytes(None, byref(a), byref(b)) == ERR_INVALID
+    assert lib.bbx_design_timed_bytes(h, byref(a), byref(b)) == 0
+    wa, wb = c_int64(), c_int64()
+    assert lib.bbx_design_matvec_bytes(h, byref(wa), byref(wb)) == 0
+    assert 0 < a.value <= wa.value and 0 < b.value <= wb.value
+    assert lib.bbx_design_fused_operator_bytes(h, byref(a)) == 0
+    assert a.value == 0                         # sparse: no single-pass kernel
+    dev = c_int(-7)
+    assert lib.bbx_design_device(None, byref(dev)) == ERR_INVALID
+    assert lib.bbx_design_device(h, byref(dev)) == 0 and dev.value == 0
+    # which = 2 is the whole operator application; 3 does not exist
+    cnt, ms = c_int64(), c_double()
+    assert lib.bbx_design_get_timing(h, 2, byref(cnt), byref(ms)) == 0
+    assert lib.bbx_design_get_timing(h, 3, byref(cnt), byref(ms)) == ERR_INVALID
+
+    y, nt, sdu = np.zeros(n), np.ones(n), np.array([np.inf])
+    c = c_void_p()
+    assert lib.bbx_chain_create(h, _lib.MODEL_LOGIT, _p(y), _p(nt), 1, _p(sdu),
+                                .5, 1., 0., 0., 77, byref(c)) == 0
+    seed = c_uint64()
+    assert lib.bbx_chain_get_seed(c, byref(seed)) == 0 and seed.value == 77
+    assert lib.bbx_chain_set_seed(c, 78) == 0
+    assert lib.bbx_chain_get_seed(c, byref(seed)) == 0 and seed.value == 78
+    assert lib.bbx_chain_set_seed(None, 1) == ERR_INVALID
+    assert lib.bbx_chain_set_gscale_update(c, 3) == ERR_INVALID
+    assert 'mode' in _lib.last_error()
+    assert lib.bbx_chain_set_gscale_update(c, _lib.GSCALE_FIXED) == 0
+    e1, e2 = np.empty(n), np.empty(P)
+    assert lib.bbx_chain_eta(c, -1, _p(e1), _p(e2)) == ERR_INVALID
+    assert lib.bbx_chain_eta(None, 0, _p(e1), _p(e2)) == ERR_INVALID
+    assert lib.bbx_chain_eta(c, 0, _p(e1), None) == 0     # either may be NULL
+    assert lib.bbx_chain_eta(c, 0, None, _p(e2)) == 0
+    assert np.all(np.isfinite(e1)) and np.all(np.isfinite(e2))
+    ll, lp = c_double(), c_double()
+    assert lib.bbx_chain_get_logp(None, byref(ll), byref(lp)) == ERR_INVALID
+    assert lib.bbx_chain_get_logp(c, byref(ll), None) == 0
+    assert lib.bbx_chain_destroy(c) == 0
+    z = np.empty(8)
+    assert lib.bbx_device_normal(0, 1, 1, -1, _p(z)) == ERR_INVALID
+    assert lib.bbx_device_normal(9, 1, 1, 8, _p(z)) == ERR_INVALID   # device
+    assert lib.bbx_device_normal(0, 1, 1, 8, None) == ERR_INVALID
+    assert lib.bbx_device_normal(0, 1, 1, 0, None) == 0              # nothing
+    assert lib.bbx_device_normal(0, 1, 1, 8, _p(z)) == 0
+    assert np.all(np.isfinite(z)) and len(np.unique(z)) == 8
+
+
+def test_auto_format_falls_back_to_the_reference_layout():
+    """BBX_FORMAT_AUTO = "tiled when it applies, else csr" (AUTO
+    propagated the tiled builder's failure).  The builder's refusal is forced
+    here by an override the layout cannot honour (a subprocess: the builder
+    reads its environment once)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = """
+import sys
+sys.path.insert(0, %r)
+import numpy as np, scipy.sparse as sp
+from bayesbridge_amd import HipSparseDesignMatrix, BbxError
+X = sp.random(300, 40000, density=.01, random_state=1, format='csr')
+auto = HipSparseDesignMatrix(X, storage='auto')
+assert auto.storage_format == 'csr', auto.storage_format
+ref = HipSparseDesignMatrix(X, storage='csr')
+v = np.linspace(-1., 1., auto.shape[1])
+assert auto.shape == ref.shape
+assert np.array_equal(auto.dot(v), ref.dot(v))
+try:
+    HipSparseDesignMatrix(X, storage='tiled')
+except BbxError as e:
+    assert 'LDS' in str(e)
+    print('FALLBACK_OK')
+""" % os.path.join(ROOT, 'bayes-bridge_amd')
+    # 8192-row panels next to a 16000-column slice do not fit the CU's LDS
+    env = dict(os.environ, BBX_TILED_PR='8192')
+    res = subprocess.run([sys.executable, '-c', code], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert 'FALLBACK_OK' in res.stdout
