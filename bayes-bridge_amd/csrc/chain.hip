@@ -323,46 +323,76 @@ template <class Store>
 __device__ inline void tilted_stable_block(int64_t base, int64_t count,
                                            double a, uint64_t seed,
                                            uint64_t stream,
-                                           const double* s_tilt, Store store) {
+                                           const double* s_tilt,
+                                           double cost_threshold, Store store) {
   // s_tilt[i]: tilt of local item i (< count <= TS_BLOCK), already in LDS
+  //
+  // The two regimes of the sampler (plain rejection when tilt^a < 2, double
+  // rejection otherwise) are different code of very different length; lanes of
+  // both kinds in one wavefront execute both, one after the other.  The list
+  // of pending items is therefore kept PARTITIONED -- double-rejection items
+  // first, plain-rejection items after them -- so that all but one wavefront
+  // of a round run a single regime.  Which lane evaluates which (item, trial)
+  // pair has no influence on the draw (each pair has its own Philox
+  // sub-stream and the lowest accepted trial wins).
   __shared__ int s_pending[TS_BLOCK];
-  __shared__ int s_next[TS_BLOCK];
+  __shared__ int s_next_dr[TS_BLOCK];
+  __shared__ int s_next_dc[TS_BLOCK];
   __shared__ unsigned s_tried[TS_BLOCK];   // candidates already evaluated
   __shared__ int s_winner[TS_BLOCK];       // lowest accepted copy this round
-  __shared__ int s_m, s_m_next;
+  __shared__ int s_n_dr, s_n_dc;
   const int tid = threadIdx.x;
   const double odds = (1. - a) / a;
-  if (tid < count) {
-    s_pending[tid] = tid;
-    s_tried[tid] = 0u;
+  if (tid == 0) {
+    s_n_dr = 0;
+    s_n_dc = 0;
   }
-  if (tid == 0) s_m = (int)count;
+  __syncthreads();
+  if (tid < count) {
+    s_tried[tid] = 0u;
+    const bool cheap = pos_pow(s_tilt[tid], a) < fabs(cost_threshold);
+    if (cheap)
+      s_next_dc[atomicAdd(&s_n_dc, 1)] = tid;
+    else
+      s_next_dr[atomicAdd(&s_n_dr, 1)] = tid;
+  }
   __syncthreads();
   for (;;) {
-    const int m = s_m;
+    // pending = [double-rejection items | plain-rejection items]
+    const int n_dr = s_n_dr, m = n_dr + s_n_dc;
     if (m == 0) break;
+    if (tid < m)
+      s_pending[tid] = tid < n_dr ? s_next_dr[tid] : s_next_dc[tid - n_dr];
+    __syncthreads();
     int copies = TS_BLOCK / m;
     if (copies > TS_MAX_COPIES) copies = TS_MAX_COPIES;
+    // lane -> (item slot q, candidate c): consecutive lanes take consecutive
+    // slots, so a wavefront covers one stretch of the partitioned list
     const int q = tid % m, c = tid / m;
     const bool active = c < copies;
     const int item = s_pending[q];
     if (tid < m) s_winner[s_pending[tid]] = 0x7fffffff;
-    if (tid == 0) s_m_next = 0;
+    if (tid == 0) {
+      s_n_dr = 0;
+      s_n_dc = 0;
+    }
     __syncthreads();
-    bool ok = false;
+    bool ok = false, cheap = false;
     double val = 0.;
     if (active) {
       const double tilt = s_tilt[item];
       const double tilt_pow = pos_pow(tilt, a);
+      cheap = tilt_pow < fabs(cost_threshold);
       unsigned trial = s_tried[item] + (unsigned)c;
       if (trial > TS_MAX_TRIAL) trial = TS_MAX_TRIAL;
       Philox rng(seed, stream, (uint64_t)(base + item), trial);
-      if (tilt_pow < TiltedStable::kCostThreshold) {
+      if (cheap) {
         // tilt^a < 2 => a single part, c = 1 (tilted_stable.pyx:138-140)
         ok = TiltedStable::dc_trial(rng, a, tilt, 1., val);
       } else {
         double x;
-        ok = TiltedStable::dr_trial(rng, a, tilt_pow, x);
+        ok = (cost_threshold < 0.) ? TiltedStable::dr_trial(rng, a, tilt_pow, x)
+                                   : TiltedStable::dr_trial_flat(rng, a, tilt_pow, x);
         val = pos_pow(x, -odds);
       }
       if (trial >= TS_MAX_TRIAL) ok = true;  // budget exhausted: keep it
@@ -374,12 +404,12 @@ __device__ inline void tilted_stable_block(int64_t base, int64_t count,
       const int it = s_pending[tid];
       if (s_winner[it] == 0x7fffffff) {
         s_tried[it] += (unsigned)copies;
-        s_next[atomicAdd(&s_m_next, 1)] = it;
+        if (tid < n_dr)
+          s_next_dr[atomicAdd(&s_n_dr, 1)] = it;
+        else
+          s_next_dc[atomicAdd(&s_n_dc, 1)] = it;
       }
     }
-    __syncthreads();
-    if (tid < s_m_next) s_pending[tid] = s_next[tid];
-    if (tid == 0) s_m = s_m_next;
     __syncthreads();
   }
 }
@@ -391,7 +421,7 @@ __device__ inline void tilted_stable_block(int64_t base, int64_t count,
 __global__ __launch_bounds__(TS_BLOCK) void chain_lscale_kernel(
     int64_t n_shrunk, int nu, double alpha, uint64_t seed, uint64_t stream,
     ChainScalars* __restrict__ sc, const double* __restrict__ coef,
-    double* __restrict__ lscale, int items) {
+    double* __restrict__ lscale, int items, double cost_threshold) {
   __shared__ double s_tilt[TS_BLOCK];
   const double g = sc->gscale;
   for (int64_t base = (int64_t)blockIdx.x * items; base < n_shrunk;
@@ -408,7 +438,7 @@ __global__ __launch_bounds__(TS_BLOCK) void chain_lscale_kernel(
     }
     __syncthreads();
     tilted_stable_block(base, count, alpha / 2., seed, stream, s_tilt,
-                        [&](int item, double ts) {
+                        cost_threshold, [&](int item, double ts) {
                           double l = sqrt(.5 / ts);
                           if (l == 0.) {
                             l = 10e-16;  // bayesbridge.py:470-472
@@ -454,7 +484,7 @@ __global__ __launch_bounds__(256) void dev_pg_kernel(
 
 __global__ __launch_bounds__(TS_BLOCK) void dev_ts_kernel(
     int64_t n, uint64_t seed, double a, const double* __restrict__ tilt,
-    double* __restrict__ out) {
+    double* __restrict__ out, double cost_threshold) {
   __shared__ double s_tilt[TS_BLOCK];
   for (int64_t base = (int64_t)blockIdx.x * TS_BLOCK; base < n;
        base += (int64_t)gridDim.x * TS_BLOCK) {
@@ -462,6 +492,7 @@ __global__ __launch_bounds__(TS_BLOCK) void dev_ts_kernel(
     if (threadIdx.x < count) s_tilt[threadIdx.x] = tilt[base + threadIdx.x];
     __syncthreads();
     tilted_stable_block(base, count, a, seed, STREAM_LSCALE, s_tilt,
+                        cost_threshold,
                         [&](int item, double ts) { out[base + item] = ts; });
     __syncthreads();
   }
@@ -477,6 +508,24 @@ __global__ __launch_bounds__(256) void dev_gamma_kernel(
 }
 
 // ------------------------------------------------------------ host helpers
+
+// Where the tilted-stable sampler switches from plain rejection (expected
+// e^{tilt^a} proposals of ~1 us-equivalents each, evaluated many at a time) to
+// Devroye's double rejection (a bounded number of MUCH longer proposals with
+// inner rejection loops).  The reference switches at tilt^a = 2
+// (tilted_stable.pyx:53,99-104), a figure tuned for one scalar core; both
+// methods are exact samplers of the same law, so the switch point is a pure
+// cost choice.  Measured on MI355X, 50 000 draws at one tilt (ts_regimes.py):
+// plain rejection 33 / 45 / 71 us at tilt^a = .1 / 1 / 1.9, double rejection
+// 290-380 us at 2.1-4 and 130 / 110 us at 16 / 100.  BBX_TS_THRESHOLD overrides.
+static double ts_cost_threshold() {
+  static const double v = [] {
+    // (a negative value selects the in-place inner loop of dr_trial: A/B only)
+    const char* e = getenv("BBX_TS_THRESHOLD");
+    return e ? atof(e) : TiltedStable::kCostThreshold;
+  }();
+  return v;
+}
 
 static inline uint64_t iter_stream(uint64_t stream, int64_t iter) {
   return stream | ((uint64_t)iter << 8);
@@ -592,7 +641,8 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
     hipLaunchKernelGGL(chain_lscale_kernel, dim3((unsigned)nb), dim3(TS_BLOCK),
                        0, s, n_shrunk, nu, c->bridge_exp, c->seed,
                        iter_stream(STREAM_LSCALE, c->iter), sc,
-                       c->coef.as<double>(), c->lscale.as<double>(), items);
+                       c->coef.as<double>(), c->lscale.as<double>(), items,
+                       ts_cost_threshold());
   }
   BBX_HIP(hipGetLastError());
   c->iter += 1;
@@ -1096,7 +1146,7 @@ static int bbx_device_tilted_stable_impl(int device, uint64_t seed, int64_t n_dr
                     hipMemcpyHostToDevice));
   hipLaunchKernelGGL(dev_ts_kernel, dim3(grid_for(n_draw, 4096)), dim3(256), 0,
                      0, n_draw, seed, char_exp, dt.as<double>(),
-                     dout.as<double>());
+                     dout.as<double>(), bbx::ts_cost_threshold());
   BBX_HIP(hipGetLastError());
   BBX_HIP(hipMemcpy(out, dout.ptr, sizeof(double) * (size_t)n_draw,
                     hipMemcpyDeviceToHost));

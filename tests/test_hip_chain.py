@@ -66,7 +66,11 @@ def test_device_tilted_stable_laplace_transform_and_ks():
     # X ~ exp(-lam x) f_a(x) / E, f_a positive stable with E exp(-s S) =
     # exp(-s^a):  E exp(-s X) = exp(-((s + lam)^a - lam^a))
     n = 200000
-    for a, lam in [(.25, .5), (.25, 30.), (.5, 4.), (.125, 200.)]:
+    # tilt^a = .84, 2.3, 2, 1.9 and -- deep in the double-rejection regime,
+    # whose inner loop the device flattens (samplers.hpp dr_trial_flat) --
+    # 4.2, 8.4, 20
+    for a, lam in [(.25, .5), (.25, 30.), (.5, 4.), (.125, 200.),
+                   (.25, 300.), (.25, 5000.), (.5, 400.)]:
         x = _dev_ts(9, a, np.full(n, lam))
         assert np.all(x > 0) and np.all(np.isfinite(x))
         for s in (.3, 2.):
@@ -75,9 +79,34 @@ def test_device_tilted_stable_laplace_transform_and_ks():
             assert abs(got.mean() - want) < 6 * got.std() / np.sqrt(n)
     from bayesbridge_amd.hostrng import ReferenceRandom
     host = ReferenceRandom(4)
-    tl = np.full(50000, 3.)
-    assert stats.ks_2samp(_dev_ts(2, .25, tl),
-                          host.tilted_stable(.25, tl)).pvalue > 1e-3
+    for lam in (3., 100., 2000.):        # tilt^a = 1.3 (plain), 3.2, 6.7
+        tl = np.full(50000, lam)
+        assert stats.ks_2samp(_dev_ts(2, .25, tl),
+                              host.tilted_stable(.25, tl)).pvalue > 1e-3, lam
+
+
+def test_device_tilted_stable_mixed_tilts_match_the_host_sampler():
+    """One launch with tilts spread over both regimes (what the chain's
+    local-scale update looks like: plain rejection and the flattened double
+    rejection side by side in every block), compared bin by bin with the host
+    sampler that is bit-pinned to the reference."""
+    from bayesbridge_amd.hostrng import ReferenceRandom
+    rng = np.random.default_rng(0)
+    n, a = 240000, .25
+    tp = np.concatenate((rng.uniform(.05, 9., n // 2),
+                         rng.uniform(9., 150., n // 2)))     # tilt^a
+    tilt = tp ** (1 / a)
+    dev = _dev_ts(5, a, tilt)
+    host = ReferenceRandom(6).tilted_stable(a, tilt)
+    assert np.all(dev > 0) and np.all(np.isfinite(dev))
+    scale = tilt ** .5                   # brings the bins to comparable ranges
+    for lo, hi in [(0, 1), (1, 2), (2, 2.5), (2.5, 3), (3, 4), (4, 6), (6, 9),
+                   (9, 40), (40, 150)]:
+        m = (tp >= lo) & (tp < hi)
+        x, y = scale[m] / np.sqrt(dev[m]), scale[m] / np.sqrt(host[m])
+        assert stats.ks_2samp(x, y).pvalue > 1e-3, (lo, hi)
+        assert abs(np.log(x).mean() - np.log(y).mean()) < \
+            5 * np.log(y).std() * np.sqrt(2. / m.sum()), (lo, hi)
 
 
 def test_device_gamma_moments():

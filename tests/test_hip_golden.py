@@ -195,7 +195,14 @@ def test_config2_scaled_exact_seed_and_device_rng(golden_dir):
     n_cg = info['_reg_coef_sampling_info']['n_cg_iter']
     assert np.abs(n_cg - g['n_cg_iter'][:10]).max() <= 2
 
-    n_iter, burn = int(g['n_iter']), int(g['n_burnin'])
+    # The chain needs ~90 +- 25 iterations to leave its start (tau climbs from
+    # .003 to its stationary ~.045; 80 seeded runs: longest 180), which is
+    # where the reference's burn-in of 100 happens to sit.  The device chain
+    # (another random stream) therefore discards 200 iterations and is then
+    # compared with the reference's 300 post-burn-in draws.
+    n_keep = int(g['n_iter']) - int(g['n_burnin'])
+    burn = 200
+    n_iter = burn + n_keep
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         d, dinfo = _bridge(outcome, X, 'logit', **kw).gibbs(
@@ -228,4 +235,4 @@ def test_config2_scaled_exact_seed_and_device_rng(golden_dir):
     ref_lg_sd = g['global_scale_sd'] / g['global_scale_mean']
     assert abs(lg.mean() - np.log(g['global_scale_mean'])) < ref_lg_sd + .1
     m_cg = dinfo['_reg_coef_sampling_info']['n_cg_iter'].mean()
-    assert abs(m_cg - g['n_cg_iter'][burn:].mean()) < 5
+    assert abs(m_cg - g['n_cg_iter'][int(g['n_burnin']):].mean()) < 5
