@@ -277,7 +277,10 @@ def main():
     K, W, B = args.steps, args.warmup, args.burnin
     if B is None:
         B = 10 if dense else 300
+    torch.cuda.synchronize()
+    t_b = time.perf_counter()
     ncg_b = chain.run_device(B)[2] if B > 0 else np.zeros(0)
+    burnin_ms = 1e3 * (time.perf_counter() - t_b) / max(B, 1)
     ncg_w = chain.run_device(W)[2] if W > 0 else np.zeros(0)
     # state after warm-up (for the CPU baselines)
     state = None
@@ -415,6 +418,11 @@ def main():
                 if W > 0 else None,
                 "mean_n_cg_iter_burnin": round(float(ncg_b.mean()), 2)
                 if B > 0 else None,
+                # the chain's transient, for comparison with `ms_per_step`
+                # (same code, more CG iterations per draw)
+                "burnin_ms_per_step": round(burnin_ms, 4) if B > 0 else None,
+                "first_50_n_cg_iter": round(float(ncg_b[:50].mean()), 2)
+                if B >= 50 else None,
                 "parallelism": "chains=%d" % world,
                 "devices": min(world, n_dev),
                 "backend": backend,
