@@ -203,11 +203,15 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     bbx_design* h;
     ~SkipScope() { h->skip_flag = nullptr; }
   } skip_scope{h};
-  static const bool no_skip =
+  static const bool no_skip_env =
       getenv("BBX_CG_NO_SKIP") && atoi(getenv("BBX_CG_NO_SKIP")) == 1;
-  h->skip_flag = no_skip ? nullptr : &st->done;
+  // (every operator kernel of every format reads the flag; BBX_CG_NO_SKIP=1
+  // restores round 1's careful schedule: first look one iteration BEFORE the
+  // previous solve's count, no flag)
+  const bool can_skip = !no_skip_env;
+  h->skip_flag = can_skip ? &st->done : nullptr;
   int next_poll = h->last_cg_iter > 2
-                      ? h->last_cg_iter + (no_skip ? -1 : 2)
+                      ? h->last_cg_iter + (can_skip ? 2 : -1)
                       : 1;
   if (fused) {
     // direction(0) on its own; afterwards ONE vector launch per iteration does
@@ -294,7 +298,7 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
   // Operator applications enqueued past the stopping iteration exited at entry
   // (their kernels see `done`): they are not matvecs and do not count
   // (abstract_matrix.py:61-72 counts products that ran).
-  if (k > n_iter) {
+  if (k > n_iter && can_skip) {
     h->n_dot -= (k - n_iter);
     h->n_tdot -= (k - n_iter);
   }

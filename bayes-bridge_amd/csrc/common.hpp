@@ -260,6 +260,7 @@ int launch_tdot_finalize_dense(bbx_design* h, const TdotEpilogue& ep,
 int launch_operator_dense_fused(bbx_design* h, const double* d_v,
                                 const double* d_rowscale,
                                 const TdotEpilogue& ep, double* d_out);
+bool dense_fused_applies(const bbx_design* h);
 int build_tiled(bbx_design* h);
 void destroy_tiled(bbx_design* h);
 // timed_only: count what the timed kernel of each family moves (tiled Tdot:

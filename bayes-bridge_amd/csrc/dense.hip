@@ -53,7 +53,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void dense_dot_kernel(
     int64_t n, int64_t P, int64_t ld, const T* __restrict__ X,
     const double* __restrict__ v, const double* __restrict__ rowscale,
-    double* __restrict__ out) {
+    double* __restrict__ out, const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;  // the CG solve has already stopped
   using V4 = typename Vec4<T>::type;
   extern __shared__ __attribute__((aligned(16))) double vs[];
   for (int64_t j = threadIdx.x; j < ld; j += 256) vs[j] = (j < P) ? v[j] : 0.;
@@ -181,7 +182,9 @@ __global__ __launch_bounds__(256) void dense_dot_mfma_kernel(
 template <typename T>
 __global__ __launch_bounds__(256) void dense_tdot_kernel(
     int64_t n, int64_t ld, int64_t rows_per_chunk, const T* __restrict__ X,
-    const double* __restrict__ w, double* __restrict__ slab) {
+    const double* __restrict__ w, double* __restrict__ slab,
+    const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;  // the CG solve has already stopped
   using V4 = typename Vec4<T>::type;
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;  // column quad
   if (q * 4 >= ld) return;
@@ -332,16 +335,21 @@ __global__ __launch_bounds__(1024) void dense_fused_kernel(
     if (has[k]) dst[tid + 1024 * k] = g[k];
 }
 
+// Does the single-pass operator kernel apply to this design?
+bool dense_fused_applies(const bbx_design* h) {
+  static const bool off =
+      getenv("BBX_DENSE_FUSED") && atoi(getenv("BBX_DENSE_FUSED")) == 0;
+  // f64 storage: 8 registers per column group and row, one group per thread
+  const int64_t ld_max = h->dense_dtype == BBX_F32 ? 8192 : 4096;
+  return !(off || h->sparse || h->dense_ld > ld_max || h->n < 4096);
+}
+
 int launch_operator_dense_fused(bbx_design* h, const double* d_v,
                                 const double* d_rowscale,
                                 const TdotEpilogue& ep, double* d_out) {
-  static const bool off =
-      getenv("BBX_DENSE_FUSED") && atoi(getenv("BBX_DENSE_FUSED")) == 0;
   static const int rb_env =
       getenv("BBX_DENSE_FUSED_RB") ? atoi(getenv("BBX_DENSE_FUSED_RB")) : 2;
-  // f64 storage: 8 registers per column group and row, one group per thread
-  const int64_t ld_max = h->dense_dtype == BBX_F32 ? 8192 : 4096;
-  if (off || h->sparse || h->dense_ld > ld_max || h->n < 4096) return 1;
+  if (!dense_fused_applies(h)) return 1;
   const int wgs = 256;
   if (h->dense_fused_wgs != wgs) {
     BBX_TRY(h->dense_fused_slab.alloc(sizeof(double) * (size_t)wgs *
@@ -414,11 +422,12 @@ int launch_dot_dense(bbx_design* h, const double* d_v,
   else if (h->dense_dtype == BBX_F32)
     hipLaunchKernelGGL(dense_dot_kernel<float>, dim3((unsigned)nb), dim3(256),
                        lds, h->stream, h->n, h->P, h->dense_ld,
-                       h->dense.as<float>(), d_v, d_rowscale, d_t);
+                       h->dense.as<float>(), d_v, d_rowscale, d_t, h->skip_flag);
   else
     hipLaunchKernelGGL(dense_dot_kernel<double>, dim3((unsigned)nb), dim3(256),
                        lds, h->stream, h->n, h->P, h->dense_ld,
-                       h->dense.as<double>(), d_v, d_rowscale, d_t);
+                       h->dense.as<double>(), d_v, d_rowscale, d_t,
+                       h->skip_flag);
   BBX_TRY(timer_end(h, 0));
   BBX_HIP(hipGetLastError());
   return BBX_OK;
@@ -433,11 +442,12 @@ static int launch_tdot_slabs_dense(bbx_design* h, const double* d_w) {
   if (h->dense_dtype == BBX_F32)
     hipLaunchKernelGGL(dense_tdot_kernel<float>, grid, dim3(256), 0, h->stream,
                        h->n, ld, rows_per_chunk, h->dense.as<float>(), d_w,
-                       h->dense_slab.as<double>());
+                       h->dense_slab.as<double>(), h->skip_flag);
   else
     hipLaunchKernelGGL(dense_tdot_kernel<double>, grid, dim3(256), 0,
                        h->stream, h->n, ld, rows_per_chunk,
-                       h->dense.as<double>(), d_w, h->dense_slab.as<double>());
+                       h->dense.as<double>(), d_w, h->dense_slab.as<double>(),
+                       h->skip_flag);
   BBX_TRY(timer_end(h, 1));
   BBX_HIP(hipGetLastError());
   return BBX_OK;

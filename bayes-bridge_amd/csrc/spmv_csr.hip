@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void csr_dot_kernel(
     const int32_t* __restrict__ indices, const double* __restrict__ data,
     const double* __restrict__ v, int intercept,
     const double* __restrict__ c_part, const double* __restrict__ rowscale,
-    double* __restrict__ out) {
+    double* __restrict__ out, const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;  // the CG solve has already stopped
   const double csum = sum_partials(c_part);
   const double c = (intercept ? v[0] : 0.) - csum;
   const double* __restrict__ vm = v + intercept;
@@ -78,7 +79,9 @@ __global__ __launch_bounds__(256) void csr_tdot_chunk_kernel(
     const int32_t* __restrict__ chunk_begin,
     const int32_t* __restrict__ t_indptr,
     const int32_t* __restrict__ t_indices, const double* __restrict__ t_data,
-    const double* __restrict__ w, double* __restrict__ partial) {
+    const double* __restrict__ w, double* __restrict__ partial,
+    const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;  // the CG solve has already stopped
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t c = (int64_t)blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
   if (c >= n_chunk) return;
@@ -250,7 +253,7 @@ static void launch_csr_dot_g(bbx_design* h, int G, int grid, const double* d_v,
 #define BBX_LAUNCH_G(GG)                                                       \
   hipLaunchKernelGGL((csr_dot_kernel<GG, BIN>), dim3(grid), dim3(256), 0,      \
                      h->stream, h->n, ip, ix, da, d_v, h->intercept, cp,       \
-                     d_rowscale, d_t)
+                     d_rowscale, d_t, h->skip_flag)
   switch (G) {
     case 4: BBX_LAUNCH_G(4); break;
     case 8: BBX_LAUNCH_G(8); break;
@@ -318,7 +321,7 @@ static int launch_tdot_chunks_csr(bbx_design* h, const double* d_w) {
                          h->t_chunk_begin.as<int32_t>(),
                          h->t_indptr.as<int32_t>(), h->t_indices.as<int32_t>(),
                          h->t_data.as<double>(), d_w,
-                         h->t_partial.as<double>());
+                         h->t_partial.as<double>(), h->skip_flag);
     else
       hipLaunchKernelGGL(csr_tdot_chunk_kernel<false>, dim3((unsigned)nb),
                          dim3(256), 0, h->stream, h->n_tchunk,
@@ -326,7 +329,7 @@ static int launch_tdot_chunks_csr(bbx_design* h, const double* d_w) {
                          h->t_chunk_begin.as<int32_t>(),
                          h->t_indptr.as<int32_t>(), h->t_indices.as<int32_t>(),
                          h->t_data.as<double>(), d_w,
-                         h->t_partial.as<double>());
+                         h->t_partial.as<double>(), h->skip_flag);
   }
   BBX_TRY(timer_end(h, 1));
   BBX_HIP(hipGetLastError());

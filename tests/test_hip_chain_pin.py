@@ -138,6 +138,8 @@ def test_device_chain_iteration_equals_oracle(family, kind, storage):
         # Tdot and the linear predictor of the Omega update
         after = hip.get_dot_count()
         warm = 1 if np.any(x0 != 0.) else 0
+        # (iterations enqueued past the stopping one return at entry -- every
+        # operator kernel reads the solve's stop flag -- and are not counted)
         assert after[0] - before[0] == n_cg + warm + 1
         assert after[1] - before[1] == n_cg + warm + 1
         # ---- summaries after the update (chain_summary_kernel)
