@@ -105,19 +105,23 @@ int launch_tdot_dense(bbx_design* h, const double* d_w,
                       double* d_out);
 int launch_dot_tiled(bbx_design* h, const double* d_v,
                      const double* d_rowscale, double* d_t,
-                     double* d_sum_part, int* sum_done);
+                     double* d_sum_part, int* sum_done, double* d_twt_part,
+                     int* twt_done);
 int launch_tdot_tiled(bbx_design* h, const double* d_w,
                       const double* d_sumw_part, const TdotEpilogue& ep,
                       double* d_out);
 
 int launch_dot(bbx_design* h, const double* d_v, const double* d_rowscale,
-               double* d_t, double* d_sum_part) {
+               double* d_t, double* d_sum_part, double* d_twt_part,
+               int* twt_done) {
   h->n_dot += 1;
   int sum_done = 0;
+  if (twt_done) *twt_done = 0;
   if (!h->sparse) {
     BBX_TRY(launch_dot_dense(h, d_v, d_rowscale, d_t));
   } else if (h->format == BBX_FORMAT_TILED) {
-    BBX_TRY(launch_dot_tiled(h, d_v, d_rowscale, d_t, d_sum_part, &sum_done));
+    BBX_TRY(launch_dot_tiled(h, d_v, d_rowscale, d_t, d_sum_part, &sum_done,
+                             d_twt_part, twt_done));
   } else {
     BBX_TRY(launch_dot_csr(h, d_v, d_rowscale, d_t));
   }

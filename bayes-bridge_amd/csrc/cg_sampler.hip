@@ -28,7 +28,8 @@ int launch_cg_init_resid(bbx_design* h, const double* b, const double* q,
                          double* r, double* rr_part);
 int launch_cg_direction(bbx_design* h, int k, CGState* st,
                         const double* rr_part, const double* r, double* pvec,
-                        const double* s, double* sp, double* c_part);
+                        const double* s, double* sp, double* c_part,
+                        const double* d = nullptr, double* pdp_part = nullptr);
 int launch_cg_update(bbx_design* h, int k, CGState* st, const double* pq_part,
                      const double* pvec, const double* q, double* x, double* r,
                      double* rr_part);
@@ -70,24 +71,59 @@ int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,
 // One application of  q = d x + s X~^T (Omega (X~ (s x)))  given sp = s.*x and
 // the partials of <offset, sp[1:]> already in PS_C.  Leaves partials of x.q in
 // PS_PQ.
+//
+// With `upd` set (inside the CG loop, x == search direction p) the CG update of
+// iteration upd->k rides in the Tdot epilogue whenever the format's dot kernel
+// can deliver <t, Omega t>, t = X~ (s p):  p.Ap = <p, d p> + <t, Omega t>
+// (algebraically SciPy's dotprod(p, q); a sum of non-negative terms), so alpha
+// is known BEFORE q exists and q never has to be stored or re-read:
+//   x += alpha p ; r -= alpha q ; partials of r.r -> PS_RR ; n_iter = k + 1.
+// *upd->merged says whether that happened; if not, the caller runs
+// cg_update_kernel on q as before.  One P-vector launch less per iteration.
+struct CGUpdate {
+  int k;
+  CGState* st;
+  double* x;
+  double* r;
+  bool* merged;
+};
 static int apply_operator(bbx_design* h, const double* d_omega,
                           const double* sp, const double* x, const double* s,
-                          const double* d, double* q) {
+                          const double* d, double* q,
+                          const CGUpdate* upd = nullptr) {
   TdotEpilogue ep;
   ep.mode = TD_OPER;
   ep.s = s;
   ep.d = d;
   ep.x = x;
   ep.dot_part = part_slot(h, PS_PQ);
+  auto merge = [&]() {
+    ep.mode = TD_OPER_UPD;
+    ep.dot_part = part_slot(h, PS_RR);
+    ep.cg_x = upd->x;
+    ep.cg_r = upd->r;
+    ep.cg_state = upd->st;
+    ep.cg_k = upd->k;
+    ep.pdp_part = part_slot(h, PS_PDP);
+    ep.twt_part = part_slot(h, PS_TWT);
+    *upd->merged = true;
+  };
+  if (upd) *upd->merged = false;
   BBX_TRY(timer_begin(h, 2));  // family 2: the whole application (sampled)
-  if (!h->sparse) {
+  if (!h->sparse && dense_fused_applies(h)) {
     // f32 dense designs: both products in one pass over the matrix
-    const int st = launch_operator_dense_fused(h, sp, d_omega, ep, q);
+    if (upd) merge();
+    const int st = launch_operator_dense_fused(
+        h, sp, d_omega, ep, q, upd ? part_slot(h, PS_TWT) : nullptr);
     if (st < 0) return st;
     if (st == 0) return timer_end(h, 2);
+    return fail(BBX_ERR_STATE, "single-pass dense operator refused its design");
   }
   double* t = h->w_n[0].as<double>();
-  BBX_TRY(launch_dot(h, sp, d_omega, t, part_slot(h, PS_SUMW)));
+  int twt_done = 0;
+  BBX_TRY(launch_dot(h, sp, d_omega, t, part_slot(h, PS_SUMW),
+                     upd ? part_slot(h, PS_TWT) : nullptr, &twt_done));
+  if (upd && twt_done) merge();
   BBX_TRY(launch_tdot(h, t, part_slot(h, PS_SUMW), ep, q));
   return timer_end(h, 2);
 }
@@ -252,20 +288,33 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
       }
     }
   } else {
+  // BBX_CG_MERGE_UPDATE=0: keep the update as its own launch (A/B)
+  static const bool merge_update =
+      !(getenv("BBX_CG_MERGE_UPDATE") && atoi(getenv("BBX_CG_MERGE_UPDATE")) == 0);
+  double* pdp = merge_update ? part_slot(h, PS_PDP) : nullptr;
+  bool merged = false;
+  // one CG iteration after its direction kernel: q = A p and the update
+  auto operator_and_update = [&](int kk) -> int {
+    CGUpdate upd{kk, st, x, r, &merged};
+    BBX_TRY(apply_operator(h, d_omega, sp, pvec, s, d, q,
+                           merge_update ? &upd : nullptr));
+    if (!merged)
+      BBX_TRY(launch_cg_update(h, kk, st, part_slot(h, PS_PQ), pvec, q, x, r,
+                               part_slot(h, PS_RR)));
+    return BBX_OK;
+  };
   while (!done) {
     const int stop = (next_poll < maxiter) ? next_poll : maxiter;
     for (; k < stop; ++k) {
       BBX_TRY(launch_cg_direction(h, k, st, part_slot(h, PS_RR), r, pvec, s, sp,
-                                  part_slot(h, PS_C)));
-      BBX_TRY(apply_operator(h, d_omega, sp, pvec, s, d, q));
-      BBX_TRY(launch_cg_update(h, k, st, part_slot(h, PS_PQ), pvec, q, x, r,
-                               part_slot(h, PS_RR)));
+                                  part_slot(h, PS_C), d, pdp));
+      BBX_TRY(operator_and_update(k));
     }
     if (k >= maxiter) break;
     // Stop test of iteration k (SciPy checks at the loop top) rides along
     // with the next direction kernel; peek at the flag it left behind.
     BBX_TRY(launch_cg_direction(h, k, st, part_slot(h, PS_RR), r, pvec, s, sp,
-                                part_slot(h, PS_C)));
+                                part_slot(h, PS_C), d, pdp));
     // coef = s .* x goes out BEFORE the look at the flag: if the rule has
     // fired (the common case: the first look comes a little after the
     // previous solve's count) the draw is complete when the host wakes up and
@@ -281,9 +330,7 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
       break;
     }
     // direction(k) already ran: finish iteration k, then continue.
-    BBX_TRY(apply_operator(h, d_omega, sp, pvec, s, d, q));
-    BBX_TRY(launch_cg_update(h, k, st, part_slot(h, PS_PQ), pvec, q, x, r,
-                             part_slot(h, PS_RR)));
+    BBX_TRY(operator_and_update(k));
     ++k;
     next_poll = k + 2;
   }

@@ -178,7 +178,9 @@ enum PartSlot {
   PS_RR = 3,    // r.r
   PS_MISC = 4,  // 4, 5, 6: scratch triples
   PS_ZERO = 7,  // never written: NPART zeros
-  PS_COUNT = 8
+  PS_PDP = 8,   // <p, d .* p> of the current search direction
+  PS_TWT = 9,   // <t, Omega t>, t = X~ (s .* p): with PS_PDP the curvature p.Ap
+  PS_COUNT = 10
 };
 
 inline double* part_slot(const bbx_design* h, int slot) {
@@ -189,13 +191,22 @@ inline double* part_slot(const bbx_design* h, int slot) {
 // t[n] = rowscale ? rowscale .* (X~ v) : X~ v ;  v is a device P-vector.
 // `c_part` must hold the NPART partials of <offset, v[1:]> (see launch_prep_v).
 // If sum_part != nullptr the NPART partial sums of t are written there.
+// If d_twt_part != nullptr and the format's dot kernel can produce them, the
+// NPART partials of sum_i rowscale_i t_i^2 (t before scaling) are written there
+// and *twt_done is set to 1; otherwise *twt_done is 0 and nothing is written.
 int launch_dot(bbx_design* h, const double* d_v, const double* d_rowscale,
-               double* d_t, double* d_sum_part);
+               double* d_t, double* d_sum_part, double* d_twt_part = nullptr,
+               int* twt_done = nullptr);
 // Modes of the Tdot epilogue.
 enum TdotMode {
   TD_PLAIN = 0,  // out = g
   TD_OPER = 1,   // out = d .* x + s .* g            (cg_sampler.py:107-108)
-  TD_RHS = 2     // out = s .* (z + g + phi .* eta2) (cg_sampler.py:66-68)
+  TD_RHS = 2,    // out = s .* (z + g + phi .* eta2) (cg_sampler.py:66-68)
+  // q = d .* p + s .* g as TD_OPER, then the CG update in the same pass:
+  //   alpha = rho / p.Ap ; x += alpha p ; r -= alpha q ; partials of r.r
+  // with p.Ap = <p, d p> + <t, Omega t> taken from two partial-sum slots (q is
+  // not stored).  SciPy's cg: `alpha = rho_cur / dotprod(p, q)`.
+  TD_OPER_UPD = 3
 };
 struct TdotEpilogue {
   int mode = TD_PLAIN;
@@ -206,6 +217,14 @@ struct TdotEpilogue {
   const double* phi = nullptr;
   const double* eta2 = nullptr;
   double* dot_part = nullptr;  // TD_OPER: partials of x.out ; TD_RHS: of out.out
+                               // TD_OPER_UPD: partials of the new r.r
+  // TD_OPER_UPD only (x above is the search direction p):
+  double* cg_x = nullptr;      // iterate, updated in place
+  double* cg_r = nullptr;      // residual, updated in place
+  CGState* cg_state = nullptr;
+  int cg_k = 0;
+  const double* pdp_part = nullptr;
+  const double* twt_part = nullptr;
 };
 // Where the raw main product X_main^T w of the last Tdot launch can be read
 // from (per orientation/format), for epilogues that run in a later kernel.
@@ -259,7 +278,8 @@ int launch_tdot_finalize_dense(bbx_design* h, const TdotEpilogue& ep,
 // Returns 1 when the fused path does not apply (caller runs the two passes).
 int launch_operator_dense_fused(bbx_design* h, const double* d_v,
                                 const double* d_rowscale,
-                                const TdotEpilogue& ep, double* d_out);
+                                const TdotEpilogue& ep, double* d_out,
+                                double* d_twt_part = nullptr);
 bool dense_fused_applies(const bbx_design* h);
 int build_tiled(bbx_design* h);
 void destroy_tiled(bbx_design* h);

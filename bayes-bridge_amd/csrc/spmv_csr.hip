@@ -132,7 +132,11 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
     int mode, const double* __restrict__ s, const double* __restrict__ d,
     const double* __restrict__ x, const double* __restrict__ z,
     const double* __restrict__ phi, const double* __restrict__ eta2,
-    double* __restrict__ out, double* __restrict__ dot_part) {
+    double* __restrict__ out, double* __restrict__ dot_part,
+    // TD_OPER_UPD (x is the search direction p):
+    double* __restrict__ cg_x, double* __restrict__ cg_r,
+    CGState* __restrict__ cg_state, int cg_k,
+    const double* __restrict__ pdp_part, const double* __restrict__ twt_part) {
   const int64_t P = p + intercept;
   const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
   const int64_t jj0 = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x;
@@ -155,11 +159,24 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
                 ? gfull[(int64_t)u * slab_stride + jm0] : 0.;
   const double off0 = main0 ? offset[jm0] : 0.;
   double e0 = 0., e1 = 0., e2 = 0., e3 = 0.;
+  // TD_OPER_UPD: the two halves of the curvature p.Ap and the CG scalars
+  double pa[NPART / WAVE], pb[NPART / WAVE];
+  double rho = 0.;
+  if (mode == TD_OPER_UPD) {
+#pragma unroll
+    for (int k = 0; k < NPART / WAVE; ++k) {
+      pa[k] = pdp_part[(threadIdx.x & (WAVE - 1)) + k * WAVE];
+      pb[k] = twt_part[(threadIdx.x & (WAVE - 1)) + k * WAVE];
+    }
+    rho = cg_state->rho[cg_k & 1];
+    if (cg_state->done) return;  // the stop rule has fired (uniform)
+  }
   if (has0) {
-    if (mode == TD_OPER) {
+    if (mode == TD_OPER || mode == TD_OPER_UPD) {
       e0 = x[jj0];
       e1 = d[jj0];
       e2 = s[jj0];
+      if (mode == TD_OPER_UPD) e3 = cg_r[jj0];
     } else if (mode == TD_RHS) {
       e0 = z[jj0];
       e1 = phi[jj0];
@@ -168,16 +185,29 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
     }
   }
   // sum(w): same adds in the same order as sum_partials()
-  __shared__ double s_sumw;
+  __shared__ double s_sumw, s_pap;
   if (threadIdx.x < WAVE) {
     double a = 0.;
 #pragma unroll
     for (int k = 0; k < NPART / WAVE; ++k) a += pw[k];
     a = wave_sum(a);
     if (threadIdx.x == 0) s_sumw = a;
+    if (mode == TD_OPER_UPD) {
+      // <p, d p> and <t, Omega t>, each summed like sum_partials(), then added
+      double b = 0., c = 0.;
+#pragma unroll
+      for (int k = 0; k < NPART / WAVE; ++k) {
+        b += pa[k];
+        c += pb[k];
+      }
+      b = wave_sum(b);
+      c = wave_sum(c);
+      if (threadIdx.x == 0) s_pap = b + c;
+    }
   }
   __syncthreads();
   const double sumw = s_sumw;
+  const double alpha = (mode == TD_OPER_UPD) ? rho / s_pap : 0.;
   double dacc = 0.;
   for (int64_t jj = jj0; jj < P; jj += stride) {
     const bool first = jj == jj0;
@@ -217,6 +247,14 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
       const double xj = first ? e0 : x[jj];
       r = (first ? e1 : d[jj]) * xj + (first ? e2 : s[jj]) * g;
       dacc += xj * r;
+    } else if (mode == TD_OPER_UPD) {
+      const double pj = first ? e0 : x[jj];
+      const double q = (first ? e1 : d[jj]) * pj + (first ? e2 : s[jj]) * g;
+      cg_x[jj] += alpha * pj;
+      r = (first ? e3 : cg_r[jj]) - alpha * q;
+      cg_r[jj] = r;
+      dacc += r * r;
+      continue;
     } else if (mode == TD_RHS) {
       r = (first ? e3 : s[jj]) *
           ((first ? e0 : z[jj]) +
@@ -231,6 +269,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
     const double tot = block_sum_256(dacc);
     if (threadIdx.x == 0) dot_part[blockIdx.x] = tot;
   }
+  if (mode == TD_OPER_UPD && blockIdx.x == 0 && threadIdx.x == 0)
+    cg_state->n_iter = cg_k + 1;
 }
 
 // ------------------------------------------------------------------ launches
@@ -289,7 +329,8 @@ int launch_tdot_finalize(bbx_design* h, const double* d_gfull, int n_slab,
                      h->t_row_chunk_ptr.as<int32_t>(),
                      h->t_partial.as<double>(), d_gfull, n_slab, h->p,
                      h->offset.as<double>(), d_sumw_part, ep.mode, ep.s, ep.d,
-                     ep.x, ep.z, ep.phi, ep.eta2, d_out, ep.dot_part);
+                     ep.x, ep.z, ep.phi, ep.eta2, d_out, ep.dot_part, ep.cg_x,
+                     ep.cg_r, ep.cg_state, ep.cg_k, ep.pdp_part, ep.twt_part);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }
@@ -305,7 +346,8 @@ int launch_tdot_finalize_dense(bbx_design* h, const TdotEpilogue& ep,
                      d_slab ? n_slab : h->dense_chunks, h->dense_ld,
                      h->offset.as<double>(), part_slot(h, PS_ZERO), ep.mode,
                      ep.s, ep.d, ep.x, ep.z, ep.phi, ep.eta2, d_out,
-                     ep.dot_part);
+                     ep.dot_part, ep.cg_x, ep.cg_r, ep.cg_state, ep.cg_k,
+                     ep.pdp_part, ep.twt_part);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }

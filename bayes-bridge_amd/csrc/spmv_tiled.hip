@@ -204,7 +204,7 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     const double* __restrict__ rowscale, double* __restrict__ out,
     double* __restrict__ slab, int n_acc,
     const int32_t* __restrict__ panel_fold, const FoldDesc* __restrict__ folds,
-    double* __restrict__ out_sum_part, int ablate,
+    double* __restrict__ out_sum_part, int twt_off, int ablate,
     unsigned long long* dbg, const int* __restrict__ skip_flag) {
   // (scalar load, issued first; checked below once the descriptor loads that
   // every launch needs anyway have been issued, so it adds no round trip)
@@ -502,34 +502,50 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     }
     __syncthreads();
     const double c = xs[0];
-    double tsum = 0.;
+    double tsum = 0., t2sum = 0.;
 #pragma unroll
     for (int u = 0; u < EPI_UNROLL; ++u) {
       const int r = tid + u * TILE_THREADS;
       if (r < rows_here) {
-        double v = c + acc[r];
+        const double t = c + acc[r];
+        double v = t;
         if (rowscale) v *= rs_pre[u];
         out[row0 + r] = v;
         tsum += v;
+        t2sum += v * t;
       }
     }
     if (out_sum_part) {
       // partial sum of this panel's outputs (feeds the intercept / centring
-      // terms of the following Tdot); fixed order: lanes, then waves
+      // terms of the following Tdot); fixed order: lanes, then waves.
+      // twt_off != 0: also the partial of sum_i rowscale_i t_i^2 = <t, Omega t>,
+      // the data part of the CG curvature p.Ap (cg_sampler.hip), written
+      // twt_off doubles after the sum's slot.
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1)
+      for (int off = 32; off > 0; off >>= 1) {
         tsum += __shfl_down(tsum, off, WAVE);
+        t2sum += __shfl_down(t2sum, off, WAVE);
+      }
       __syncthreads();
-      if (lane == 0) xs[wave] = tsum;
+      if (lane == 0) {
+        xs[wave] = tsum;
+        xs[TILE_WAVES + wave] = t2sum;
+      }
       __syncthreads();
       if (tid == 0) {
-        double tot = 0.;
-        for (int wv = 0; wv < TILE_WAVES; ++wv) tot += xs[wv];
+        double tot = 0., tot2 = 0.;
+        for (int wv = 0; wv < TILE_WAVES; ++wv) {
+          tot += xs[wv];
+          tot2 += xs[TILE_WAVES + wv];
+        }
         out_sum_part[blockIdx.x] = tot;
+        if (twt_off) out_sum_part[twt_off + (int)blockIdx.x] = tot2;
       }
       // consumers add NPART slots: the first workgroup clears the unused ones
-      if (blockIdx.x == 0 && (int)gridDim.x + tid < NPART)
+      if (blockIdx.x == 0 && (int)gridDim.x + tid < NPART) {
         out_sum_part[gridDim.x + tid] = 0.;
+        if (twt_off) out_sum_part[twt_off + (int)gridDim.x + tid] = 0.;
+      }
     }
   } else {
     double* dst = slab + (int64_t)group * R + row0;
@@ -687,7 +703,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                         const double* c_part, const double* x0_ptr,
                         const double* rowscale, double* out, double* slab,
                         double* out_sum_part, hipEvent_t ev_begin = nullptr,
-                        hipEvent_t ev_end = nullptr) {
+                        hipEvent_t ev_end = nullptr, int twt_off = 0) {
   const unsigned grid = (unsigned)(m.n_panel * m.G);
   const size_t lb = lds_bytes(m);
   static const int ablate = getenv("BBX_ABLATE") ? atoi(getenv("BBX_ABLATE")) : 0;
@@ -716,7 +732,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                      m.ids.as<uint4>(), VALPTR, x, c_part, x0_ptr, rowscale,   \
                      out, slab, m.PR + m.n_extra,                              \
                      m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),       \
-                     out_sum_part, ablate, dbg, h->skip_flag)
+                     out_sum_part, twt_off, ablate, dbg, h->skip_flag)
 #define BBX_TILED_LAUNCH(VV, PP, VALPTR)                                       \
   do {                                                                         \
     if (wide) BBX_TILED_LAUNCH_W(VV, PP, true, VALPTR);                        \
@@ -764,22 +780,30 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
 // produced by the kernel itself (no separate reduction pass needed).
 int launch_dot_tiled(bbx_design* h, const double* d_v,
                      const double* d_rowscale, double* d_t,
-                     double* d_sum_part, int* sum_done) {
+                     double* d_sum_part, int* sum_done, double* d_twt_part,
+                     int* twt_done) {
   TiledPair* tp = static_cast<TiledPair*>(h->tiled);
   const TiledMatrix& m = tp->x;
   const double* x = d_v + h->intercept;
   const double* x0 = h->intercept ? d_v : nullptr;
   if (sum_done) *sum_done = 0;
+  if (twt_done) *twt_done = 0;
   if (m.G == 1) {
     double* fused = nullptr;
+    int twt_off = 0;
     if (d_sum_part && m.n_panel <= NPART) {
       fused = d_sum_part;
       if (sum_done) *sum_done = 1;
+      // <t, Omega t> partials ride along (both slots live in bbx_design::part)
+      if (d_twt_part && twt_done && d_twt_part != d_sum_part) {
+        twt_off = (int)(d_twt_part - d_sum_part);
+        *twt_done = 1;
+      }
     }
     hipEvent_t ea, eb;
     BBX_TRY(timer_arm(h, 0, &ea, &eb));
     return launch_tiled(h, m, x, part_slot(h, PS_C), x0, d_rowscale, d_t,
-                        nullptr, fused, ea, eb);
+                        nullptr, fused, ea, eb, twt_off);
   }
   // G > 1: two kernels in the family, bracketed by a pair of record commands
   BBX_TRY(timer_begin(h, 0));

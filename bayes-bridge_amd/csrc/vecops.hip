@@ -179,18 +179,20 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_direction_kernel(
     const double* __restrict__ rr_part, const double* __restrict__ r,
     double* __restrict__ pvec, const double* __restrict__ s,
     const double* __restrict__ offset, double* __restrict__ sp,
-    double* __restrict__ c_part) {
+    double* __restrict__ c_part, const double* __restrict__ d,
+    double* __restrict__ pdp_part) {
   // every load that does not depend on another one goes out first
   const PartLoad pl = part_issue(rr_part);
   const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
   const int64_t j0 = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x;
   const bool has0 = j0 < P;
-  double r0 = 0., p0 = 0., s0 = 0., o0 = 0.;
+  double r0 = 0., p0 = 0., s0 = 0., o0 = 0., d0 = 0.;
   if (has0) {
     r0 = r[j0];
     if (k > 0) p0 = pvec[j0];
     s0 = s[j0];
     if (j0 >= intercept) o0 = offset[j0 - intercept];
+    if (pdp_part) d0 = d[j0];
   }
   const int was_done = st->done;
   const double atol = st->atol;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_direction_kernel(
     return;
   }
   const double beta = (k > 0) ? rho / rho_prev : 0.;
-  double acc = 0.;
+  double acc = 0., acc_d = 0.;
   if (has0) {
     double pj = r0;
     if (k > 0) pj += beta * p0;
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_direction_kernel(
     const double v = s0 * pj;
     sp[j0] = v;
     if (j0 >= intercept) acc += o0 * v;
+    acc_d += d0 * pj * pj;
   }
   for (int64_t jj = j0 + stride; jj < P; jj += stride) {
     double pj = r[jj];
@@ -222,8 +225,11 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_direction_kernel(
     const double v = s[jj] * pj;
     sp[jj] = v;
     if (jj >= intercept) acc += offset[jj - intercept] * v;
+    if (pdp_part) acc_d += d[jj] * pj * pj;
   }
   block_store_partial(acc, c_part);
+  // <p, d p>: the diagonal half of the curvature p.Ap (TD_OPER_UPD epilogue)
+  if (pdp_part) block_store_partial(acc_d, pdp_part);
   if (blockIdx.x == 0 && threadIdx.x == 0) st->rho[k & 1] = rho;
 }
 
@@ -502,10 +508,11 @@ int launch_cg_init_resid(bbx_design* h, const double* b, const double* q,
 
 int launch_cg_direction(bbx_design* h, int k, CGState* st,
                         const double* rr_part, const double* r, double* pvec,
-                        const double* s, double* sp, double* c_part) {
+                        const double* s, double* sp, double* c_part,
+                        const double* d, double* pdp_part) {
   hipLaunchKernelGGL(cg_direction_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
                      h->stream, h->P, h->intercept, k, st, rr_part, r, pvec, s,
-                     h->offset.as<double>(), sp, c_part);
+                     h->offset.as<double>(), sp, c_part, d, pdp_part);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }

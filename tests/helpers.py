@@ -12,12 +12,13 @@ def mixed_design(n, p, binary_frac=.5, freq=.1, seed=0):
                                         binary_pred_freq=freq, seed=seed)
 
 
-def cg_inputs(n, P, n_unshrunk=1, seed=0, flat_intercept=True):
+def cg_inputs(n, P, n_unshrunk=1, seed=0, flat_intercept=True,
+              lam_log_sd=1.5):
     """Plausible inputs of one CG draw: Omega ~ PG-like positives, prior
     precisions spanning several decades (bridge prior), a warm start."""
     rng = np.random.default_rng(seed)
     omega = rng.gamma(2., .15, n) + 1e-3
-    lam = np.exp(rng.normal(0., 1.5, P))
+    lam = np.exp(rng.normal(0., lam_log_sd, P))
     sd_prior = .05 * lam / np.sqrt(1 + (.05 * lam / 2.) ** 2)
     phi = 1. / sd_prior
     if flat_intercept and n_unshrunk > 0:

@@ -192,3 +192,51 @@ def test_cg_sample_dense_single_pass_operator(n, p, dtype):
     _assert_close(c_h, i_h, c_o, i_o)
     # matvec counters: the single pass counts as one dot and one Tdot
     assert hip.get_dot_count()[0] == hip.get_dot_count()[1] - 1
+
+
+@pytest.mark.parametrize("kind,n,p", [("sparse", 20000, 2000),
+                                      ("sparse", 3000, 300),
+                                      ("dense", 20000, 900),
+                                      ("dense", 5000, 4500)])
+def test_update_in_the_tdot_epilogue_equals_the_separate_update(tmp_path, kind,
+                                                                n, p):
+    """The CG loop's default folds `alpha = rho / p.Ap; x += alpha p;
+    r -= alpha q` into the Tdot epilogue, with p.Ap = <p, d p> + <t, Omega t>
+    (cg_sampler.hip, apply_operator).  BBX_CG_MERGE_UPDATE=0 runs SciPy's
+    literal `dotprod(p, q)` in cg_update_kernel instead.  Same recurrence, the
+    curvature rounded differently in the last bits:
+      * stopped after 1 iteration the iterates agree to 1e-13 of their scale
+        (the algebra is exact), after 3 to 1e-9 (the flat-prior intercept
+        gives the preconditioned system an eigenvalue ~1e5 times the others;
+        a last-bit difference in alpha comes back multiplied by it);
+      * run to convergence both stop within one iteration of each other and
+        agree to the bound this file uses against the oracle (these systems
+        amplify a 1e-16 perturbation of one alpha to 1e-8 over 20-70
+        iterations, as they do between the oracle and either variant).
+    The switch is read once per process: subprocesses."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+
+    def draw(flag, maxiter):
+        out = os.path.join(str(tmp_path), "draw%s_%d.npz" % (flag, maxiter))
+        env = dict(os.environ, BBX_CG_MERGE_UPDATE=flag)
+        run = subprocess.run(
+            [sys.executable, os.path.join(ROOT, "scripts", "cg_variant_draw.py"),
+             out, kind, str(n), str(p), "3", str(maxiter)],
+            env=env, capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+        return np.load(out)
+    for maxiter, tol in ((1, 1e-13), (3, 1e-9)):
+        a, b = draw("0", maxiter), draw("1", maxiter)
+        assert int(a['n_iter']) == int(b['n_iter']) == maxiter
+        assert np.array_equal(a['counts'], b['counts'])
+        scale = max(1., np.abs(a['coef']).max())
+        assert np.abs(a['coef'] - b['coef']).max() <= tol * scale
+    a, b = draw("0", 500), draw("1", 500)
+    assert abs(int(a['n_iter']) - int(b['n_iter'])) <= 1
+    assert 3 < int(a['n_iter']) < 500
+    scale = max(1., np.abs(a['coef']).max())
+    tol = 1e-6 if int(a['n_iter']) == int(b['n_iter']) else 1e-5
+    assert np.abs(a['coef'] - b['coef']).max() <= tol * scale
