@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void dense_tdot_kernel(
   dst[3] = a3;
 }
 
-// ---- one pass over X for  g = X^T (rowscale .* (X v))  (f32 storage) -------
+// ---- one pass over X for  g = X^T (rowscale .* (X v)) ----------------------
 //
 // A CG iteration on a dense design reads the matrix twice (dot, then Tdot):
 // 2 x 6.4 GB at 200k x 8k.  Here a 1024-thread workgroup owns a contiguous
@@ -234,17 +234,61 @@ __global__ __launch_bounds__(256) void dense_tdot_kernel(
 //   p_i = <X[i, own cols], v[own cols]>       lane-private
 //   t_i = sum over the 1024 threads of p_i     shuffles, LDS, ONE barrier
 //   g[own cols] += X[i, own cols] * (rowscale_i * t_i)
-// and the next RB rows are requested before the reduction starts, so HBM keeps
-// streaming through the barrier.  Per-workgroup results go to slabs that the
-// common Tdot epilogue adds in workgroup order (fixed order, no atomics).
+// Per-workgroup results go to slabs that the common Tdot epilogue adds in
+// workgroup order (fixed order, no atomics), and sum_i rowscale_i t_i^2 -- the
+// data half of the CG curvature p.Ap, see cg_sampler.hip -- to one partial
+// per workgroup.  Two kernels share the arithmetic below (explicit fma, so that
+// they agree bit for bit whatever the compiler would contract):
+//   dense_fused_kernel       the next RB rows are prefetched into REGISTERS
+//                            before the reduction starts (f32 and f64 storage);
+//   dense_fused_ring_kernel  the stream goes through an LDS ring filled by
+//                            LDS-DMA, D blocks ahead (f32 storage).
+template <typename V4, int KQ>
+__device__ __forceinline__ double fused_row_dot(const V4 (&x)[KQ],
+                                                const double4 (&vo)[KQ]) {
+  double a0 = 0., a1 = 0.;
+#pragma unroll
+  for (int k = 0; k < KQ; ++k) {
+    a0 = fma((double)x[k].x, vo[k].x, a0);
+    a1 = fma((double)x[k].y, vo[k].y, a1);
+    a0 = fma((double)x[k].z, vo[k].z, a0);
+    a1 = fma((double)x[k].w, vo[k].w, a1);
+  }
+  double p = a0 + a1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) p += __shfl_down(p, off, WAVE);
+  return p;  // valid in lane 0
+}
+
+template <typename V4, int KQ>
+__device__ __forceinline__ void fused_row_axpy(const V4 (&x)[KQ], double wi,
+                                               double4 (&g)[KQ]) {
+#pragma unroll
+  for (int k = 0; k < KQ; ++k) {
+    g[k].x = fma((double)x[k].x, wi, g[k].x);
+    g[k].y = fma((double)x[k].y, wi, g[k].y);
+    g[k].z = fma((double)x[k].z, wi, g[k].z);
+    g[k].w = fma((double)x[k].w, wi, g[k].w);
+  }
+}
+
+// sum of the 16 wave partials of one row, in wave order
+__device__ __forceinline__ double fused_row_total(const double* red16) {
+  double t = 0.;
+#pragma unroll
+  for (int w = 0; w < 1024 / WAVE; ++w) t += red16[w];
+  return t;
+}
+
 template <typename T, int KQ, int RB>
 __global__ __launch_bounds__(1024) void dense_fused_kernel(
     int64_t n, int64_t P, int64_t ld, int64_t rows_per_wg,
     const T* __restrict__ X, const double* __restrict__ v,
     const double* __restrict__ rowscale, double* __restrict__ slab,
-    const int* __restrict__ skip_flag) {
+    const int* __restrict__ skip_flag, double* __restrict__ twt_part) {
   if (skip_flag && *skip_flag) return;  // the CG solve has already stopped
   __shared__ double red[2][RB][1024 / WAVE];
+  double twt = 0.;  // sum_i rowscale_i t_i^2 over this workgroup's rows
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const int64_t ldq = ld / 4;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
@@ -287,38 +331,18 @@ __global__ __launch_bounds__(1024) void dense_fused_kernel(
   int buf = 0;
   for (int64_t r = r0; r < r1; r += RB) {
     load_block(r + RB, xn, sn);  // in flight across the reduction below
-    double p[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      double a0 = 0., a1 = 0.;
-#pragma unroll
-      for (int k = 0; k < KQ; ++k) {
-        a0 += (double)xc[i][k].x * vo[k].x + (double)xc[i][k].z * vo[k].z;
-        a1 += (double)xc[i][k].y * vo[k].y + (double)xc[i][k].w * vo[k].w;
-      }
-      p[i] = a0 + a1;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1)
-        p[i] += __shfl_down(p[i], off, WAVE);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < RB; ++i) red[buf][i][wave] = p[i];
+      const double p = fused_row_dot<V4, KQ>(xc[i], vo);
+      if (lane == 0) red[buf][i][wave] = p;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      double t = 0.;
-#pragma unroll
-      for (int w = 0; w < 1024 / WAVE; ++w) t += red[buf][i][w];
+      const double t = fused_row_total(red[buf][i]);
       const double wi = sc[i] * t;
-#pragma unroll
-      for (int k = 0; k < KQ; ++k) {
-        g[k].x += (double)xc[i][k].x * wi;
-        g[k].y += (double)xc[i][k].y * wi;
-        g[k].z += (double)xc[i][k].z * wi;
-        g[k].w += (double)xc[i][k].w * wi;
-      }
+      twt = fma(wi, t, twt);
+      fused_row_axpy<V4, KQ>(xc[i], wi, g);
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
@@ -333,6 +357,160 @@ __global__ __launch_bounds__(1024) void dense_fused_kernel(
 #pragma unroll
   for (int k = 0; k < KQ; ++k)
     if (has[k]) dst[tid + 1024 * k] = g[k];
+  if (twt_part && tid == 0) twt_part[blockIdx.x] = twt;
+}
+
+// ---- the same pass with the prefetch in LDS instead of registers -----------
+//
+// dense_fused_kernel keeps ONE block of RB rows in flight per thread (its
+// registers hold the current block, the next one and the thread's slices of v
+// and g: 114 VGPRs at KQ = 2, a deeper register prefetch spills), and every
+// block ends at a workgroup barrier, i.e. waits for the SLOWEST of the
+// workgroup's outstanding loads.  Here the stream goes through an LDS ring
+// filled by LDS-DMA (global_load_lds_dwordx4, no register destination): D
+// blocks of RB rows are in flight ahead of the one being computed, the
+// registers hold only the current block (93 VGPRs).  A thread reads back
+// exactly the bytes its own DMA instructions wrote (lane-linear image), so the
+// only ordering the data needs is the issuing wave's counted vmcnt -- the one
+// barrier per block is still the row-sum exchange, and it is a raw s_barrier:
+// a __syncthreads() would be free to drain the DMAs.
+// Measured at 200k x 8k (profiles/r02_ab_dense_fused.txt): 1.165 vs 1.195 ms
+// on one box; what is left above the 1.07 ms floor of this launch shape (the
+// same kernel with no arithmetic at all) is the reduction chain per block, not
+// the bytes in flight.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+template <int KQ, int RB, int D>
+__global__ __launch_bounds__(1024) void dense_fused_ring_kernel(
+    int64_t n, int64_t P, int64_t ld, int64_t rows_per_wg,
+    const float* __restrict__ X, const double* __restrict__ v,
+    const double* __restrict__ rowscale, double* __restrict__ slab,
+    const int* __restrict__ skip_flag, double* __restrict__ twt_part) {
+  if (skip_flag && *skip_flag) return;  // the CG solve has already stopped
+  double twt = 0.;  // sum_i rowscale_i t_i^2 over this workgroup's rows
+  constexpr int SLOT_Q = KQ * 1024;     // 16-byte units per row slot
+  constexpr int NWAVE = 1024 / WAVE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fused_smem[];
+  float4* ring = reinterpret_cast<float4*>(fused_smem);  // [D * RB][SLOT_Q]
+  double* red = reinterpret_cast<double*>(fused_smem + (size_t)D * RB * SLOT_Q * 16);
+  double* rs = red + 2 * RB * NWAVE;                     // [rows_per_wg + RB]
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+  const int64_t ldq = ld / 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = (r0 + rows_per_wg < n) ? r0 + rows_per_wg : n;
+  double4 vo[KQ], g[KQ];
+  bool has[KQ];
+  int64_t qs[KQ];  // source quad of this thread (clamped: every lane issues)
+#pragma unroll
+  for (int k = 0; k < KQ; ++k) {
+    const int64_t q = tid + 1024 * k;
+    has[k] = q < ldq;
+    qs[k] = has[k] ? q : ldq - 1;
+    vo[k] = make_double4(0., 0., 0., 0.);
+    g[k] = make_double4(0., 0., 0., 0.);
+    if (has[k]) {
+      const int64_t c = q * 4;
+      vo[k].x = (c + 0 < P) ? v[c + 0] : 0.;
+      vo[k].y = (c + 1 < P) ? v[c + 1] : 0.;
+      vo[k].z = (c + 2 < P) ? v[c + 2] : 0.;
+      vo[k].w = (c + 3 < P) ? v[c + 3] : 0.;
+    }
+  }
+  double4* __restrict__ dst =
+      reinterpret_cast<double4*>(slab + (int64_t)blockIdx.x * ld);
+  if (r0 >= r1) {  // no rows: a zero slab
+#pragma unroll
+    for (int k = 0; k < KQ; ++k)
+      if (has[k]) dst[tid + 1024 * k] = g[k];
+    if (twt_part && tid == 0) twt_part[blockIdx.x] = 0.;
+    return;
+  }
+  const int n_rows = (int)(r1 - r0);
+  const int n_blk = (n_rows + RB - 1) / RB;
+  for (int j = tid; j < n_blk * RB; j += 1024)
+    rs[j] = j < n_rows ? (rowscale ? rowscale[r0 + j] : 1.) : 0.;
+  // every compiler-visible load is retired before the counted ring starts
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+  __syncthreads();
+  const float4* __restrict__ X4 = reinterpret_cast<const float4*>(X);
+  const unsigned ring_lds = (unsigned)(uintptr_t)ring;
+  // Rows past the end are clamped to the last row (their scale is 0): every
+  // wave issues exactly RB * KQ DMA instructions per block, which is what the
+  // counted waits below assume.
+  auto issue = [&](int b, int slot) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int64_t row = r0 + (int64_t)b * RB + i;
+      if (row >= r1) row = r1 - 1;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) {
+        const unsigned dst_lds = __builtin_amdgcn_readfirstlane(
+            ring_lds + (unsigned)(((slot * RB + i) * SLOT_Q + k * 1024 + wave * WAVE) * 16));
+        glds16(X4 + row * ldq + qs[k], dst_lds);
+      }
+    }
+  };
+  constexpr int PER_BLOCK = RB * KQ;
+#pragma unroll
+  for (int b = 0; b < D; ++b)
+    if (b < n_blk) issue(b, b);
+  int slot = 0, buf = 0;
+  for (int b = 0; b < n_blk; ++b) {
+    // block b has landed once at most the younger blocks' DMAs are pending
+    if (b + D <= n_blk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PER_BLOCK) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    float4 xc[RB][KQ];
+    double sc[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      sc[i] = rs[b * RB + i];
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) {
+        xc[i][k] = ring[(size_t)(slot * RB + i) * SLOT_Q + k * 1024 + tid];
+        if (!has[k]) xc[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    // the slot's bytes are in registers: refill it D blocks ahead
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (b + D < n_blk) issue(b + D, slot);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const double p = fused_row_dot<float4, KQ>(xc[i], vo);
+      if (lane == 0) red[(buf * RB + i) * NWAVE + wave] = p;
+    }
+    // LDS writes visible, then the barrier; the DMAs in flight are NOT waited for
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const double t = fused_row_total(red + (buf * RB + i) * NWAVE);
+      const double wi = sc[i] * t;
+      twt = fma(wi, t, twt);
+      fused_row_axpy<float4, KQ>(xc[i], wi, g);
+    }
+    buf ^= 1;
+    slot = (slot + 1 == D) ? 0 : slot + 1;
+  }
+#pragma unroll
+  for (int k = 0; k < KQ; ++k)
+    if (has[k]) dst[tid + 1024 * k] = g[k];
+  if (twt_part && tid == 0) twt_part[blockIdx.x] = twt;
+}
+
+static size_t fused_ring_lds(int KQ, int RB, int D, int64_t rows_per_wg) {
+  return (size_t)D * RB * KQ * 1024 * 16 + sizeof(double) * 2 * RB * 16 +
+         sizeof(double) * (size_t)(rows_per_wg + 8);
 }
 
 // Does the single-pass operator kernel apply to this design?
@@ -346,9 +524,14 @@ bool dense_fused_applies(const bbx_design* h) {
 
 int launch_operator_dense_fused(bbx_design* h, const double* d_v,
                                 const double* d_rowscale,
-                                const TdotEpilogue& ep, double* d_out) {
-  static const int rb_env =
-      getenv("BBX_DENSE_FUSED_RB") ? atoi(getenv("BBX_DENSE_FUSED_RB")) : 2;
+                                const TdotEpilogue& ep, double* d_out,
+                                double* d_twt_part) {
+  static_assert(NPART == 256, "one <t, Omega t> partial per workgroup");
+  // BBX_DENSE_FUSED_RING=0 keeps the register-prefetch kernel everywhere;
+  // unset: the LDS-DMA ring for f32 storage from 64 rows per workgroup on (its
+  // prologue costs more than it saves on short row ranges)
+  static const int ring_env =
+      getenv("BBX_DENSE_FUSED_RING") ? atoi(getenv("BBX_DENSE_FUSED_RING")) : -1;
   if (!dense_fused_applies(h)) return 1;
   const int wgs = 256;
   if (h->dense_fused_wgs != wgs) {
@@ -365,15 +548,38 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
   hipLaunchKernelGGL((dense_fused_kernel<TT, KQ, RB>), dim3(wgs), dim3(1024),  \
                      0, h->stream, h->n, h->P, h->dense_ld, rows_per_wg,       \
                      h->dense.as<TT>(), d_v, d_rowscale,                       \
-                     h->dense_fused_slab.as<double>(), h->skip_flag)
+                     h->dense_fused_slab.as<double>(), h->skip_flag,           \
+                     d_twt_part)
+#define BBX_RING_LAUNCH(KQ, RB, D)                                             \
+  do {                                                                         \
+    const size_t lb = fused_ring_lds(KQ, RB, D, rows_per_wg);                  \
+    static bool attr_set = false;                                              \
+    if (!attr_set) {                                                           \
+      BBX_HIP(hipFuncSetAttribute(                                             \
+          reinterpret_cast<const void*>(&dense_fused_ring_kernel<KQ, RB, D>),  \
+          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));            \
+      attr_set = true;                                                         \
+    }                                                                          \
+    hipLaunchKernelGGL((dense_fused_ring_kernel<KQ, RB, D>), dim3(wgs),        \
+                       dim3(1024), lb, h->stream, h->n, h->P, h->dense_ld,     \
+                       rows_per_wg, h->dense.as<float>(), d_v, d_rowscale,     \
+                       h->dense_fused_slab.as<double>(), h->skip_flag,         \
+                       d_twt_part);                                            \
+  } while (0)
+  const bool ring = h->dense_dtype == BBX_F32 && ring_env != 0 &&
+                    (ring_env > 0 || rows_per_wg >= 64) &&
+                    fused_ring_lds(2, 2, 2, rows_per_wg) <= 160 * 1024;
   if (h->dense_dtype != BBX_F32) {
     BBX_FUSED_LAUNCH(double, 1, 2);
+  } else if (ring) {
+    if (kq1) BBX_RING_LAUNCH(1, 2, 2); else BBX_RING_LAUNCH(2, 2, 2);
   } else if (kq1) {
-    if (rb_env >= 4) BBX_FUSED_LAUNCH(float, 1, 4); else BBX_FUSED_LAUNCH(float, 1, 2);
+    BBX_FUSED_LAUNCH(float, 1, 2);
   } else {
     BBX_FUSED_LAUNCH(float, 2, 2);
   }
 #undef BBX_FUSED_LAUNCH
+#undef BBX_RING_LAUNCH
   BBX_TRY(timer_end(h, 0));
   BBX_HIP(hipGetLastError());
   return launch_tdot_finalize_dense(h, ep, d_out,

@@ -225,3 +225,30 @@ def test_matrix_core_gemv_variant_gives_the_same_product(shape):
             env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
         assert "BBX_DENSE_MFMA=%s" % flag in res.stdout
+
+
+@pytest.mark.parametrize("shape", [(20001, 4001), (16500, 5000), (65537, 801)])
+def test_lds_ring_variant_of_the_single_pass_operator_is_bit_identical(shape):
+    """dense_fused_ring_kernel (LDS-DMA ring, the default for f32 storage from
+    64 rows per workgroup on) against dense_fused_kernel (register prefetch,
+    BBX_DENSE_FUSED_RING=0): same arithmetic in the same order, so the script's
+    SHA-256 of the product must agree; it also checks the product against the
+    two separate passes (<= 1e-10).  Ragged row ranges, one and two column
+    groups per thread.  The switch is read once per process: subprocesses."""
+    import re
+    import subprocess
+    import sys
+    from conftest import ROOT
+    digest = {}
+    for flag in ("0", "22"):
+        env = dict(os.environ, BBX_DENSE_FUSED_RING=flag)
+        res = subprocess.run(
+            [sys.executable, os.path.join(ROOT, "scripts", "ab_dense_fused.py"),
+             str(shape[0]), str(shape[1]), "3"],
+            env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        m = re.search(r"BBX_DENSE_FUSED_RING=%s .* sha256 ([0-9a-f]+)" % flag,
+                      res.stdout)
+        assert m, res.stdout[-2000:]
+        digest[flag] = m.group(1)
+    assert digest["0"] == digest["22"]
