@@ -49,11 +49,7 @@ struct bbx_chain {
 
 namespace bbx {
 
-__device__ inline double wsum(double x) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
-  return x;
-}
+__device__ inline double wsum(double x) { return wave_allsum(x); }
 
 __device__ inline double block_total_256(double x) {
   __shared__ double s_w[256 / WAVE];

@@ -21,6 +21,43 @@ constexpr int WAVE = 64;
 constexpr int NPART = 256;
 constexpr int VEC_BLOCK = 256;
 
+#if defined(__HIPCC__)
+// Wave-level sums WITHOUT LDS traffic.  __shfl_down on a double is two
+// ds_bpermute_b32 per step: a 64-lane tree costs 12 LDS round trips (~1.3k
+// cycles of pure latency), which is most of what a latency-bound P-vector
+// kernel or the row-sum exchange of the dense single-pass kernel waits for.
+// Here: DPP moves inside a row of 16 lanes (v_mov_b32 row_ror:8/4/2/1), then
+// v_readlane across the four rows.  Every lane returns the same value (the
+// rotations pair the same operands in every lane and IEEE + commutes); fixed
+// order, so bitwise reproducible like the tree it replaces.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// every lane of a row of 16 lanes gets the sum over its row
+__device__ __forceinline__ double row16_allsum(double m) {
+  m += dpp_move<0x128>(m);  // row_ror:8
+  m += dpp_move<0x124>(m);  // row_ror:4
+  m += dpp_move<0x122>(m);  // row_ror:2
+  m += dpp_move<0x121>(m);  // row_ror:1
+  return m;
+}
+__device__ __forceinline__ double lane_value(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, the same value in every lane
+__device__ __forceinline__ double wave_allsum(double x) {
+  const double m = row16_allsum(x);
+  return (lane_value(m, 0) + lane_value(m, 16)) +
+         (lane_value(m, 32) + lane_value(m, 48));
+}
+#endif
+
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 

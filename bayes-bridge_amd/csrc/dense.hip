@@ -89,9 +89,7 @@ __global__ __launch_bounds__(256) void dense_dot_kernel(
       a0 += (double)x0.x * w0.x + (double)x0.z * w0.z;
       a1 += (double)x0.y * w0.y + (double)x0.w * w0.w;
     }
-    double a = a0 + a1;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, WAVE);
+    double a = wave_allsum(a0 + a1);
     if (lane == 0) {
       if (rowscale) a *= rowscale[row];
       out[row] = a;
@@ -254,10 +252,37 @@ __device__ __forceinline__ double fused_row_dot(const V4 (&x)[KQ],
     a0 = fma((double)x[k].z, vo[k].z, a0);
     a1 = fma((double)x[k].w, vo[k].w, a1);
   }
-  double p = a0 + a1;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) p += __shfl_down(p, off, WAVE);
-  return p;  // valid in lane 0
+  return a0 + a1;  // this lane's part of the row's inner product
+}
+
+// The row sums cross lanes without LDS traffic (common.hpp: row16_allsum,
+// lane_value), plus gfx950's v_permlane32_swap between the halves of the
+// wavefront.  With __shfl_down (two ds_bpermute_b32 per step and double: 24
+// LDS round trips per block of two rows, on the critical path in front of the
+// workgroup barrier) the ring kernel ran 1.17 ms at 200k x 8k; with these 0.92.
+// Wave totals of two lane-private values at once (uniform results): after the
+// swap lanes 0-31 hold p0[l] + p0[l+32] and lanes 32-63 p1[l-32] + p1[l]; one
+// 16-lane all-sum then serves both rows.  Fixed order.
+typedef unsigned fused_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wave_sum_pair(double p0, double p1, double& t0,
+                                              double& t1) {
+  const fused_v2u lo = __builtin_amdgcn_permlane32_swap(
+      (unsigned)__double2loint(p0), (unsigned)__double2loint(p1), false, false);
+  const fused_v2u hi = __builtin_amdgcn_permlane32_swap(
+      (unsigned)__double2hiint(p0), (unsigned)__double2hiint(p1), false, false);
+  const double m = row16_allsum(__hiloint2double((int)hi.x, (int)lo.x) +
+                                __hiloint2double((int)hi.y, (int)lo.y));
+  t0 = lane_value(m, 0) + lane_value(m, 16);
+  t1 = lane_value(m, 32) + lane_value(m, 48);
+}
+// Totals of two rows over the workgroup's 16 waves: red2 = [row 0: 16 wave
+// partials | row 1: 16 wave partials]; lanes 0-15 / 16-31 take one partial each
+// (one LDS read per lane instead of 32), the 16-lane all-sum does the rest.
+__device__ __forceinline__ void block_sum_pair(const double* red2, int lane,
+                                               double& t0, double& t1) {
+  const double m = row16_allsum(red2[lane & 31]);
+  t0 = lane_value(m, 0);
+  t1 = lane_value(m, 16);
 }
 
 template <typename V4, int KQ>
@@ -270,14 +295,6 @@ __device__ __forceinline__ void fused_row_axpy(const V4 (&x)[KQ], double wi,
     g[k].z = fma((double)x[k].z, wi, g[k].z);
     g[k].w = fma((double)x[k].w, wi, g[k].w);
   }
-}
-
-// sum of the 16 wave partials of one row, in wave order
-__device__ __forceinline__ double fused_row_total(const double* red16) {
-  double t = 0.;
-#pragma unroll
-  for (int w = 0; w < 1024 / WAVE; ++w) t += red16[w];
-  return t;
 }
 
 template <typename T, int KQ, int RB>
@@ -331,17 +348,20 @@ __global__ __launch_bounds__(1024) void dense_fused_kernel(
   int buf = 0;
   for (int64_t r = r0; r < r1; r += RB) {
     load_block(r + RB, xn, sn);  // in flight across the reduction below
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const double p = fused_row_dot<V4, KQ>(xc[i], vo);
-      if (lane == 0) red[buf][i][wave] = p;
+    static_assert(RB == 2, "the row sums are exchanged two rows at a time");
+    double t[RB];
+    wave_sum_pair(fused_row_dot<V4, KQ>(xc[0], vo),
+                  fused_row_dot<V4, KQ>(xc[1], vo), t[0], t[1]);
+    if (lane == 0) {
+      red[buf][0][wave] = t[0];
+      red[buf][1][wave] = t[1];
     }
     __syncthreads();
+    block_sum_pair(&red[buf][0][0], lane, t[0], t[1]);
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const double t = fused_row_total(red[buf][i]);
-      const double wi = sc[i] * t;
-      twt = fma(wi, t, twt);
+      const double wi = sc[i] * t[i];
+      twt = fma(wi, t[i], twt);
       fused_row_axpy<V4, KQ>(xc[i], wi, g);
     }
 #pragma unroll
@@ -485,18 +505,21 @@ __global__ __launch_bounds__(1024) void dense_fused_ring_kernel(
     // the slot's bytes are in registers: refill it D blocks ahead
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (b + D < n_blk) issue(b + D, slot);
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const double p = fused_row_dot<float4, KQ>(xc[i], vo);
-      if (lane == 0) red[(buf * RB + i) * NWAVE + wave] = p;
+    static_assert(RB == 2, "the row sums are exchanged two rows at a time");
+    double t[RB];
+    wave_sum_pair(fused_row_dot<float4, KQ>(xc[0], vo),
+                  fused_row_dot<float4, KQ>(xc[1], vo), t[0], t[1]);
+    if (lane == 0) {
+      red[(buf * RB + 0) * NWAVE + wave] = t[0];
+      red[(buf * RB + 1) * NWAVE + wave] = t[1];
     }
     // LDS writes visible, then the barrier; the DMAs in flight are NOT waited for
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    block_sum_pair(red + buf * RB * NWAVE, lane, t[0], t[1]);
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const double t = fused_row_total(red + (buf * RB + i) * NWAVE);
-      const double wi = sc[i] * t;
-      twt = fma(wi, t, twt);
+      const double wi = sc[i] * t[i];
+      twt = fma(wi, t[i], twt);
       fused_row_axpy<float4, KQ>(xc[i], wi, g);
     }
     buf ^= 1;

@@ -18,11 +18,7 @@ namespace bbx {
 
 constexpr int T_CHUNK = 2048;  // stored entries of X^T handled by one wave
 
-__device__ inline double wave_sum(double x) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
-  return x;
-}
+__device__ inline double wave_sum(double x) { return wave_allsum(x); }
 
 // Sum of the NPART partials, identical in every block (fixed order).
 __device__ inline double sum_partials(const double* part) {

@@ -495,8 +495,7 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
       if (c_part) {
 #pragma unroll
         for (int k = 0; k < NPART / WAVE; ++k) cs += cp_pre[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cs += __shfl_down(cs, off, WAVE);
+        cs = wave_allsum(cs);
       }
       if (tid == 0) xs[0] = x0_pre - cs;
     }
@@ -521,11 +520,8 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
       // twt_off != 0: also the partial of sum_i rowscale_i t_i^2 = <t, Omega t>,
       // the data part of the CG curvature p.Ap (cg_sampler.hip), written
       // twt_off doubles after the sum's slot.
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        tsum += __shfl_down(tsum, off, WAVE);
-        t2sum += __shfl_down(t2sum, off, WAVE);
-      }
+      tsum = wave_allsum(tsum);
+      t2sum = wave_allsum(t2sum);
       __syncthreads();
       if (lane == 0) {
         xs[wave] = tsum;

@@ -6,11 +6,7 @@
 
 namespace bbx {
 
-__device__ inline double wave_sum_v(double x) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
-  return x;
-}
+__device__ inline double wave_sum_v(double x) { return wave_allsum(x); }
 
 __device__ inline void block_store_partial(double x, double* part) {
   __shared__ double s_w[VEC_BLOCK / WAVE];

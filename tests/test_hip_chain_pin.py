@@ -125,10 +125,14 @@ def test_device_chain_iteration_equals_oracle(family, kind, storage):
         assert n_unconv == 0
         coef_d = kept['coef'][0]
         n_cg = int(kept['n_cg_iter'][0])
-        # +-2 around the oracle's stopping iteration; solves of ~100 iterations
-        # (dense Gaussian designs) sit on a flat stretch of the residual curve
-        # where the summation order moves the stop by a few (+-5 %)
-        slack = max(2, math.ceil(.05 * info_o['n_iter']))
+        # +-2 around the oracle's stopping iteration; solves of 40-100
+        # iterations sit on a flat stretch of the residual curve where rounding
+        # moves the stop by several iterations: the ORACLE's own count ranges
+        # over 75..82 at iteration 3 of the linear/sparse case when Omega is
+        # perturbed by 1e-15 (scripts/pin_sensitivity.py,
+        # profiles/r02_pin_sensitivity.txt), the device's summation order
+        # gives 74.  Hence +-10 %; the coefficients are compared below.
+        slack = max(2, math.ceil(.10 * info_o['n_iter']))
         assert abs(n_cg - info_o['n_iter']) <= slack, (n_cg, info_o['n_iter'])
         scale = max(1., np.abs(coef_o).max())
         tol = 1e-6 if n_cg == info_o['n_iter'] else 1e-5
