@@ -14,14 +14,21 @@ namespace bbx {
 
 constexpr int ROW_GRID = 2048;  // blocks of the n-length sampler kernels
 
-struct ChainScalars {
+// Two 128-byte halves: after the coefficient draw the Omega update and the
+// tau / lambda updates run as two branches on two streams (chain_step), each
+// writing only its own half, so that no cache line is dirty in two L2s.
+struct alignas(128) ChainScalars {
+  // ---- written by the tau / lambda branch
   double gscale;         // tau, raw parametrisation
-  double obs_prec;       // linear model only
-  double loglik;         // of the current coef
-  double logp;           // log posterior (bayesbridge.py:480-511)
+  double logprior;       // log posterior minus the log-likelihood
   double abs_pow_sum;    // sum |beta_j|^alpha over shrunk coordinates
   long long n_gscale_clamped;
   long long n_lscale_fixed;
+  // ---- written by the Omega branch
+  alignas(128) double obs_prec;  // linear model only
+  double loglik;                 // of the current coef
+  // log posterior (bayesbridge.py:480-511)
+  __host__ __device__ double logp() const { return loglik + logprior; }
 };
 
 }  // namespace bbx
@@ -45,6 +52,9 @@ struct bbx_chain {
   bbx::DevMem row_part;                 // ROW_GRID partials x 2
   bbx::DevMem samp_gscale, samp_logp;   // per kept sample (device)
   void* pinned = nullptr;
+  // second stream for the tau / lambda branch of an iteration
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace bbx {
@@ -285,8 +295,9 @@ __global__ __launch_bounds__(256) void chain_gscale_kernel(
   }
   sc->gscale = g;
   sc->abs_pow_sum = pow_sum;
-  // log posterior with the NEW tau (bayesbridge.py:232-234,480-511)
-  double lp = sc->loglik - .5 * slab_sum;
+  // log posterior with the NEW tau (bayesbridge.py:232-234,480-511), without
+  // the log-likelihood, which the Omega branch writes (ChainScalars::logp)
+  double lp = -.5 * slab_sum;
   double prior = 0.;
   if (n_shrunk > 0)
     prior += -(double)n_shrunk * log(g) - pow_sum / pow(g, alpha);
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(256) void chain_gscale_kernel(
   for (int j = 0; j < nu; ++j)
     if (sd_unshrunk[j] < INFINITY) prior -= log(sd_unshrunk[j]);
   prior += (shape0 - 1.) * log(g) - rate0 * g;
-  sc->logp = lp + prior;
+  sc->logprior = lp + prior;
 }
 
 // lambda_j | tau, beta_j (bayesbridge.py:458-478).
@@ -453,7 +464,7 @@ __global__ void chain_store_scalars_kernel(const ChainScalars* __restrict__ sc,
                                            double* __restrict__ lp) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     gs[idx] = sc->gscale;
-    lp[idx] = sc->logp;
+    lp[idx] = sc->logp();
   }
 }
 
@@ -593,6 +604,26 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
                      c->mean.as<double>(), c->square.as<double>());
   c->n_averaged += 1;
 
+  // The two updates that follow read beta and nothing of each other: the
+  // Omega branch (X~ beta: one pass over the matrix, then n Polya-Gamma draws)
+  // stays on the design's stream, the tau / lambda branch (three small
+  // kernels, the last one ~0.1 ms of latency-bound rejection sampling on p
+  // coefficients) runs beside it on a second stream.  Each branch writes its
+  // own half of ChainScalars; Philox streams are keyed by element, so the
+  // draws do not depend on the interleaving.  beta is final here (the CG
+  // solve ended with a stream sync), so the second stream starts at once; only
+  // the lambda kernel has to wait, for the summary kernel above, which still
+  // reads the old lambda.  Worth it when the Omega branch is long enough to
+  // hide the cross-stream hand-offs (~20 us): config 3 +2 %, config 2 -2.5 %.
+  // BBX_CHAIN_FORK=0 / 1 forces one / two streams.
+  static const int fork_env =
+      getenv("BBX_CHAIN_FORK") ? atoi(getenv("BBX_CHAIN_FORK")) : -1;
+  const bool fork = c->stream2 != nullptr &&
+                    (fork_env >= 0 ? fork_env == 1
+                                   : (n >= 400000 && n_shrunk >= 8192));
+  hipStream_t s_b = fork ? c->stream2 : s;
+  if (fork) BBX_HIP(hipEventRecord(c->ev_fork, s));  // summary done with lambda
+
   // --- Omega | beta  (bayesbridge.py:397-410)
   BBX_TRY(chain_linear_predictor(c));
   const int rg = grid_for(n, ROW_GRID);
@@ -612,16 +643,17 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
 
   // --- tau | beta, then lambda | tau, beta, then log posterior
   double* pp = part_slot(h, PS_MISC);
-  hipLaunchKernelGGL(chain_coef_sums_kernel, dim3(NPART), dim3(256), 0, s, P,
+  hipLaunchKernelGGL(chain_coef_sums_kernel, dim3(NPART), dim3(256), 0, s_b, P,
                      nu, c->bridge_exp, c->slab, c->coef.as<double>(),
                      c->sd_unshrunk.as<double>(), pp, pp + NPART,
                      pp + 2 * NPART);
   const double lower_bd = .001 / power_exp_ave_magnitude(c->bridge_exp);
-  hipLaunchKernelGGL(chain_gscale_kernel, dim3(1), dim3(256), 0, s, n_shrunk,
+  hipLaunchKernelGGL(chain_gscale_kernel, dim3(1), dim3(256), 0, s_b, n_shrunk,
                      nu, c->bridge_exp, c->shape0, c->rate0, lower_bd,
                      c->gscale_update, c->seed,
                      iter_stream(STREAM_GSCALE, c->iter), pp, pp + NPART,
                      pp + 2 * NPART, c->sd_unshrunk.as<double>(), sc);
+  if (fork) BBX_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
   if (n_shrunk > 0) {
     // Measured at p = 50k (ms per Gibbs iteration, items per block): 256:
     // 5.69, 128: 5.63, 64: 5.72, 32: 5.83, 16: 6.11 -- the speculative copies
@@ -635,12 +667,16 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
     int64_t nb = (n_shrunk + items - 1) / items;
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(chain_lscale_kernel, dim3((unsigned)nb), dim3(TS_BLOCK),
-                       0, s, n_shrunk, nu, c->bridge_exp, c->seed,
+                       0, s_b, n_shrunk, nu, c->bridge_exp, c->seed,
                        iter_stream(STREAM_LSCALE, c->iter), sc,
                        c->coef.as<double>(), c->lscale.as<double>(), items,
                        ts_cost_threshold());
   }
   BBX_HIP(hipGetLastError());
+  if (fork) {
+    BBX_HIP(hipEventRecord(c->ev_join, c->stream2));
+    BBX_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
+  }
   c->iter += 1;
   return info;
 }
@@ -695,6 +731,9 @@ int bbx_chain_create(bbx_design* design, int model, const double* outcome,
     BBX_TRY(c->scalars.alloc(sizeof(ChainScalars)));
     BBX_TRY(c->row_part.alloc(sizeof(double) * ROW_GRID * 2));
     BBX_HIP(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
+    BBX_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    BBX_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    BBX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     BBX_HIP(hipMemcpy(c->outcome.ptr, outcome, nb, hipMemcpyHostToDevice));
     if (model == BBX_MODEL_LOGIT) {
       if (n_trial) {
@@ -754,6 +793,12 @@ int bbx_chain_destroy(bbx_chain* c) {
     (void)hipSetDevice(c->h->device);
     (void)hipStreamSynchronize(c->h->stream);
   }
+  if (c->stream2) {
+    (void)hipStreamSynchronize(c->stream2);
+    (void)hipStreamDestroy(c->stream2);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->pinned) (void)hipHostFree(c->pinned);
   delete c;
   return BBX_OK;
@@ -934,7 +979,7 @@ int bbx_chain_get_logp(bbx_chain* c, double* loglik, double* logp) {
   ChainScalars sc;
   BBX_HIP(hipMemcpy(&sc, c->scalars.ptr, sizeof(sc), hipMemcpyDeviceToHost));
   if (loglik) *loglik = sc.loglik;
-  if (logp) *logp = sc.logp;
+  if (logp) *logp = sc.logp();
   return BBX_OK;
 }
 
