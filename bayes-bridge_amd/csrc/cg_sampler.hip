@@ -165,23 +165,8 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
 
   BBX_TRY(launch_cg_setup(h, n_unshrunk, d_phi, d_sd, d_x0, s, d, x));
 
-  // b = s (z + X~^T(sqrt(Omega) eta1) + phi eta2)
-  {
-    double* w = h->w_n[1].as<double>();
-    BBX_TRY(launch_sqrt_scale(h, d_omega, d_eta1, w, part_slot(h, PS_SUMW)));
-    TdotEpilogue ep;
-    ep.mode = TD_RHS;
-    ep.s = s;
-    ep.z = d_z;
-    ep.phi = d_phi;
-    ep.eta2 = d_eta2;
-    ep.dot_part = part_slot(h, PS_MISC);
-    BBX_TRY(launch_tdot(h, w, part_slot(h, PS_SUMW), ep, b));
-  }
-
-  // r = b - A x0, or r = b when the warm start is all zeros: SciPy's cg skips
-  // the product then (`r = b - matvec(x) if x.any() else b.copy()`), and so do
-  // we, so that the dot/Tdot counters match the reference's for cold starts.
+  // Is the warm start all zeros?  SciPy's cg skips the product with x0 then
+  // (`r = b - matvec(x) if x.any() else b.copy()`), and so do we.
   CGState* host_st = static_cast<CGState*>(h->host_pinned);
   if (x0_zero < 0) {
     int* d_flag = reinterpret_cast<int*>(st);  // CGState is uploaded below
@@ -195,12 +180,72 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     BBX_HIP(hipStreamSynchronize(h->stream));
     x0_zero = (*h_flag == 0) ? 1 : 0;
   }
-  if (x0_zero) {
-    BBX_TRY(launch_cg_init_resid(h, b, nullptr, r, part_slot(h, PS_RR)));
+
+  // r = b - A x0 with b = s (z + X~^T(sqrt(Omega) eta1) + phi eta2).
+  // BBX_CG_MERGE_RESID=0: the reference's sequence, b by one transposed product
+  // and A x0 by an operator application (two passes over X~^T for a warm start).
+  // Default: X~^T is linear, so both go through ONE transposed product,
+  //   g = X~^T (Omega (X~ (s x0)) - sqrt(Omega) eta1),
+  //   r = s (z + (phi eta2 - g)) - d x0          (TD_RESID epilogue),
+  // and b is never formed (only the absolute stop rule is in use).  One pass
+  // over X~^T, one epilogue and one P-vector launch less per draw; the counters
+  // then show one Tdot less than the reference's for a warm start.
+  static const bool merge_resid =
+      !(getenv("BBX_CG_MERGE_RESID") && atoi(getenv("BBX_CG_MERGE_RESID")) == 0);
+  if (merge_resid) {
+    double* w = h->w_n[1].as<double>();
+    TdotEpilogue ep;
+    ep.mode = TD_RESID;
+    ep.s = s;
+    ep.d = d;
+    ep.x = x0_zero ? nullptr : x;
+    ep.z = d_z;
+    ep.phi = d_phi;
+    ep.eta2 = d_eta2;
+    ep.dot_part = part_slot(h, PS_RR);
+    if (!x0_zero && !h->sparse && dense_fused_applies(h)) {
+      // single-pass dense operator: the normal term rides as a row addend
+      BBX_TRY(launch_prep_v(h, x, s, sp, part_slot(h, PS_C)));
+      BBX_TRY(launch_sqrt_scale(h, d_omega, d_eta1, w, part_slot(h, PS_SUMW),
+                                nullptr, /*negate=*/true));
+      const int st_f =
+          launch_operator_dense_fused(h, sp, d_omega, ep, r, nullptr, w);
+      if (st_f != 0)
+        return st_f < 0 ? st_f
+                        : fail(BBX_ERR_STATE,
+                               "single-pass dense operator refused its design");
+    } else {
+      const double* t0 = nullptr;
+      if (!x0_zero) {
+        double* t = h->w_n[0].as<double>();
+        BBX_TRY(launch_prep_v(h, x, s, sp, part_slot(h, PS_C)));
+        BBX_TRY(launch_dot(h, sp, d_omega, t, nullptr));
+        t0 = t;
+      }
+      BBX_TRY(launch_sqrt_scale(h, d_omega, d_eta1, w, part_slot(h, PS_SUMW),
+                                t0, /*negate=*/t0 == nullptr));
+      BBX_TRY(launch_tdot(h, w, part_slot(h, PS_SUMW), ep, r));
+    }
   } else {
-    BBX_TRY(launch_prep_v(h, x, s, sp, part_slot(h, PS_C)));
-    BBX_TRY(apply_operator(h, d_omega, sp, x, s, d, q));
-    BBX_TRY(launch_cg_init_resid(h, b, q, r, part_slot(h, PS_RR)));
+    {
+      double* w = h->w_n[1].as<double>();
+      BBX_TRY(launch_sqrt_scale(h, d_omega, d_eta1, w, part_slot(h, PS_SUMW)));
+      TdotEpilogue ep;
+      ep.mode = TD_RHS;
+      ep.s = s;
+      ep.z = d_z;
+      ep.phi = d_phi;
+      ep.eta2 = d_eta2;
+      ep.dot_part = part_slot(h, PS_MISC);
+      BBX_TRY(launch_tdot(h, w, part_slot(h, PS_SUMW), ep, b));
+    }
+    if (x0_zero) {
+      BBX_TRY(launch_cg_init_resid(h, b, nullptr, r, part_slot(h, PS_RR)));
+    } else {
+      BBX_TRY(launch_prep_v(h, x, s, sp, part_slot(h, PS_C)));
+      BBX_TRY(apply_operator(h, d_omega, sp, x, s, d, q));
+      BBX_TRY(launch_cg_init_resid(h, b, q, r, part_slot(h, PS_RR)));
+    }
   }
 
   CGState init;

@@ -243,7 +243,14 @@ enum TdotMode {
   //   alpha = rho / p.Ap ; x += alpha p ; r -= alpha q ; partials of r.r
   // with p.Ap = <p, d p> + <t, Omega t> taken from two partial-sum slots (q is
   // not stored).  SciPy's cg: `alpha = rho_cur / dotprod(p, q)`.
-  TD_OPER_UPD = 3
+  TD_OPER_UPD = 3,
+  // The initial residual of a CG draw in ONE transposed product: with
+  //   g = X~^T (Omega (X~ (s x0)) - sqrt(Omega) eta1)   (linearity of X~^T)
+  //   r = b - A x0 = s .* (z + (phi .* eta2 - g)) - d .* x0     (x == nullptr:
+  // cold start, r = b), partials of r.r.  SciPy forms b and A x0 separately
+  // (two products with X~^T); b itself is not needed: the stop rule is the
+  // absolute one (cg_sampler.py:75-80).
+  TD_RESID = 4
 };
 struct TdotEpilogue {
   int mode = TD_PLAIN;
@@ -294,8 +301,10 @@ int launch_prep_v(bbx_design* h, const double* d_x, const double* d_s,
 int launch_sum_n(bbx_design* h, const double* d_w, int64_t len,
                  double* d_part);
 // w[i] = sqrt(omega[i]) * eta[i], plus partials of sum(w).
+// minus != nullptr: w[i] = minus[i] - sqrt(omega[i]) * eta[i] (TD_RESID's input)
 int launch_sqrt_scale(bbx_design* h, const double* d_omega,
-                      const double* d_eta, double* d_w, double* d_part);
+                      const double* d_eta, double* d_w, double* d_part,
+                      const double* d_minus = nullptr, bool negate = false);
 
 int design_alloc_work(bbx_design* h);
 int build_transpose_csr(bbx_design* h);
@@ -316,7 +325,9 @@ int launch_tdot_finalize_dense(bbx_design* h, const TdotEpilogue& ep,
 int launch_operator_dense_fused(bbx_design* h, const double* d_v,
                                 const double* d_rowscale,
                                 const TdotEpilogue& ep, double* d_out,
-                                double* d_twt_part = nullptr);
+                                double* d_twt_part = nullptr,
+                                const double* d_addend = nullptr);
+// (d_addend: n doubles added to rowscale .* (X v) before the transposed product)
 bool dense_fused_applies(const bbx_design* h);
 int build_tiled(bbx_design* h);
 void destroy_tiled(bbx_design* h);

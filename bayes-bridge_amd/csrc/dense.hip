@@ -302,7 +302,8 @@ __global__ __launch_bounds__(1024) void dense_fused_kernel(
     int64_t n, int64_t P, int64_t ld, int64_t rows_per_wg,
     const T* __restrict__ X, const double* __restrict__ v,
     const double* __restrict__ rowscale, double* __restrict__ slab,
-    const int* __restrict__ skip_flag, double* __restrict__ twt_part) {
+    const int* __restrict__ skip_flag, double* __restrict__ twt_part,
+    const double* __restrict__ addend) {
   if (skip_flag && *skip_flag) return;  // the CG solve has already stopped
   __shared__ double red[2][RB][1024 / WAVE];
   double twt = 0.;  // sum_i rowscale_i t_i^2 over this workgroup's rows
@@ -329,12 +330,14 @@ __global__ __launch_bounds__(1024) void dense_fused_kernel(
   using V4 = typename Vec4<T>::type;
   const V4* __restrict__ X4 = reinterpret_cast<const V4*>(X);
   V4 xc[RB][KQ], xn[RB][KQ];
-  double sc[RB], sn[RB];
-  auto load_block = [&](int64_t r, V4 (&x)[RB][KQ], double (&s)[RB]) {
+  double sc[RB], sn[RB], ac[RB], an[RB];
+  auto load_block = [&](int64_t r, V4 (&x)[RB][KQ], double (&s)[RB],
+                        double (&a)[RB]) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const bool ok = r + i < r1;
       s[i] = ok ? (rowscale ? rowscale[r + i] : 1.) : 0.;
+      a[i] = (ok && addend) ? addend[r + i] : 0.;
 #pragma unroll
       for (int k = 0; k < KQ; ++k)
         if (ok && has[k]) {
@@ -344,10 +347,10 @@ __global__ __launch_bounds__(1024) void dense_fused_kernel(
         }
     }
   };
-  load_block(r0, xc, sc);
+  load_block(r0, xc, sc, ac);
   int buf = 0;
   for (int64_t r = r0; r < r1; r += RB) {
-    load_block(r + RB, xn, sn);  // in flight across the reduction below
+    load_block(r + RB, xn, sn, an);  // in flight across the reduction below
     static_assert(RB == 2, "the row sums are exchanged two rows at a time");
     double t[RB];
     wave_sum_pair(fused_row_dot<V4, KQ>(xc[0], vo),
@@ -362,11 +365,12 @@ __global__ __launch_bounds__(1024) void dense_fused_kernel(
     for (int i = 0; i < RB; ++i) {
       const double wi = sc[i] * t[i];
       twt = fma(wi, t[i], twt);
-      fused_row_axpy<V4, KQ>(xc[i], wi, g);
+      fused_row_axpy<V4, KQ>(xc[i], wi + ac[i], g);
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       sc[i] = sn[i];
+      ac[i] = an[i];
 #pragma unroll
       for (int k = 0; k < KQ; ++k) xc[i][k] = xn[i][k];
     }
@@ -413,7 +417,8 @@ __global__ __launch_bounds__(1024) void dense_fused_ring_kernel(
     int64_t n, int64_t P, int64_t ld, int64_t rows_per_wg,
     const float* __restrict__ X, const double* __restrict__ v,
     const double* __restrict__ rowscale, double* __restrict__ slab,
-    const int* __restrict__ skip_flag, double* __restrict__ twt_part) {
+    const int* __restrict__ skip_flag, double* __restrict__ twt_part,
+    const double* __restrict__ addend) {
   if (skip_flag && *skip_flag) return;  // the CG solve has already stopped
   double twt = 0.;  // sum_i rowscale_i t_i^2 over this workgroup's rows
   constexpr int SLOT_Q = KQ * 1024;     // 16-byte units per row slot
@@ -422,6 +427,7 @@ __global__ __launch_bounds__(1024) void dense_fused_ring_kernel(
   float4* ring = reinterpret_cast<float4*>(fused_smem);  // [D * RB][SLOT_Q]
   double* red = reinterpret_cast<double*>(fused_smem + (size_t)D * RB * SLOT_Q * 16);
   double* rs = red + 2 * RB * NWAVE;                     // [rows_per_wg + RB]
+  double* ad = rs + rows_per_wg + 8;                     // [rows_per_wg + RB]
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int64_t ldq = ld / 4;
@@ -456,8 +462,10 @@ __global__ __launch_bounds__(1024) void dense_fused_ring_kernel(
   }
   const int n_rows = (int)(r1 - r0);
   const int n_blk = (n_rows + RB - 1) / RB;
-  for (int j = tid; j < n_blk * RB; j += 1024)
+  for (int j = tid; j < n_blk * RB; j += 1024) {
     rs[j] = j < n_rows ? (rowscale ? rowscale[r0 + j] : 1.) : 0.;
+    ad[j] = (j < n_rows && addend) ? addend[r0 + j] : 0.;
+  }
   // every compiler-visible load is retired before the counted ring starts
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
   __syncthreads();
@@ -492,10 +500,11 @@ __global__ __launch_bounds__(1024) void dense_fused_ring_kernel(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     float4 xc[RB][KQ];
-    double sc[RB];
+    double sc[RB], ac[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       sc[i] = rs[b * RB + i];
+      ac[i] = ad[b * RB + i];
 #pragma unroll
       for (int k = 0; k < KQ; ++k) {
         xc[i][k] = ring[(size_t)(slot * RB + i) * SLOT_Q + k * 1024 + tid];
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(1024) void dense_fused_ring_kernel(
     for (int i = 0; i < RB; ++i) {
       const double wi = sc[i] * t[i];
       twt = fma(wi, t[i], twt);
-      fused_row_axpy<float4, KQ>(xc[i], wi, g);
+      fused_row_axpy<float4, KQ>(xc[i], wi + ac[i], g);
     }
     buf ^= 1;
     slot = (slot + 1 == D) ? 0 : slot + 1;
@@ -533,7 +542,7 @@ __global__ __launch_bounds__(1024) void dense_fused_ring_kernel(
 
 static size_t fused_ring_lds(int KQ, int RB, int D, int64_t rows_per_wg) {
   return (size_t)D * RB * KQ * 1024 * 16 + sizeof(double) * 2 * RB * 16 +
-         sizeof(double) * (size_t)(rows_per_wg + 8);
+         2 * sizeof(double) * (size_t)(rows_per_wg + 8);
 }
 
 // Does the single-pass operator kernel apply to this design?
@@ -548,7 +557,7 @@ bool dense_fused_applies(const bbx_design* h) {
 int launch_operator_dense_fused(bbx_design* h, const double* d_v,
                                 const double* d_rowscale,
                                 const TdotEpilogue& ep, double* d_out,
-                                double* d_twt_part) {
+                                double* d_twt_part, const double* d_addend) {
   static_assert(NPART == 256, "one <t, Omega t> partial per workgroup");
   // BBX_DENSE_FUSED_RING=0 keeps the register-prefetch kernel everywhere;
   // unset: the LDS-DMA ring for f32 storage from 64 rows per workgroup on (its
@@ -572,7 +581,7 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
                      0, h->stream, h->n, h->P, h->dense_ld, rows_per_wg,       \
                      h->dense.as<TT>(), d_v, d_rowscale,                       \
                      h->dense_fused_slab.as<double>(), h->skip_flag,           \
-                     d_twt_part)
+                     d_twt_part, d_addend)
 #define BBX_RING_LAUNCH(KQ, RB, D)                                             \
   do {                                                                         \
     const size_t lb = fused_ring_lds(KQ, RB, D, rows_per_wg);                  \
@@ -587,7 +596,7 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
                        dim3(1024), lb, h->stream, h->n, h->P, h->dense_ld,     \
                        rows_per_wg, h->dense.as<float>(), d_v, d_rowscale,     \
                        h->dense_fused_slab.as<double>(), h->skip_flag,         \
-                       d_twt_part);                                            \
+                       d_twt_part, d_addend);                                          \
   } while (0)
   const bool ring = h->dense_dtype == BBX_F32 && ring_env != 0 &&
                     (ring_env > 0 || rows_per_wg >= 64) &&

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
       e1 = d[jj0];
       e2 = s[jj0];
       if (mode == TD_OPER_UPD) e3 = cg_r[jj0];
-    } else if (mode == TD_RHS) {
+    } else if (mode == TD_RHS || mode == TD_RESID) {
       e0 = z[jj0];
       e1 = phi[jj0];
       e2 = eta2[jj0];
@@ -255,6 +255,12 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
       r = (first ? e3 : s[jj]) *
           ((first ? e0 : z[jj]) +
            (g + (first ? e1 : phi[jj]) * (first ? e2 : eta2[jj])));
+      dacc += r * r;
+    } else if (mode == TD_RESID) {
+      r = (first ? e3 : s[jj]) *
+          ((first ? e0 : z[jj]) +
+           ((first ? e1 : phi[jj]) * (first ? e2 : eta2[jj]) - g));
+      if (x) r -= d[jj] * x[jj];
       dacc += r * r;
     } else {
       r = g;

@@ -93,14 +93,19 @@ __global__ __launch_bounds__(VEC_BLOCK) void sum_n_kernel(
   block_store_partial(acc, part);
 }
 
+// w = sqrt(omega) eta        (plain; cg_sampler.py:66)
+// w = -sqrt(omega) eta       (negate)
+// w = minus - sqrt(omega) eta (minus != nullptr), and the partials of sum(w).
 __global__ __launch_bounds__(VEC_BLOCK) void sqrt_scale_kernel(
     int64_t len, const double* __restrict__ omega,
     const double* __restrict__ eta, double* __restrict__ w,
-    double* __restrict__ part) {
+    double* __restrict__ part, const double* __restrict__ minus, int negate) {
   double acc = 0.;
   for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < len;
        i += (int64_t)gridDim.x * VEC_BLOCK) {
-    const double val = sqrt(omega[i]) * eta[i];
+    double val = sqrt(omega[i]) * eta[i];
+    if (minus) val = minus[i] - val;
+    else if (negate) val = -val;
     w[i] = val;
     acc += val;
   }
@@ -125,9 +130,11 @@ int launch_sum_n(bbx_design* h, const double* d_w, int64_t len,
 }
 
 int launch_sqrt_scale(bbx_design* h, const double* d_omega,
-                      const double* d_eta, double* d_w, double* d_part) {
+                      const double* d_eta, double* d_w, double* d_part,
+                      const double* d_minus, bool negate) {
   hipLaunchKernelGGL(sqrt_scale_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
-                     h->stream, h->n, d_omega, d_eta, d_w, d_part);
+                     h->stream, h->n, d_omega, d_eta, d_w, d_part, d_minus,
+                     negate ? 1 : 0);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }

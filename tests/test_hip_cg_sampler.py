@@ -190,8 +190,9 @@ def test_cg_sample_dense_single_pass_operator(n, p, dtype):
     finally:
         np.random.randn = orig
     _assert_close(c_h, i_h, c_o, i_o)
-    # matvec counters: the single pass counts as one dot and one Tdot
-    assert hip.get_dot_count()[0] == hip.get_dot_count()[1] - 1
+    # matvec counters: the single pass counts as one dot and one Tdot, and the
+    # initial residual of this warm start is one such pass (TD_RESID)
+    assert hip.get_dot_count()[0] == hip.get_dot_count()[1] == i_h['n_iter'] + 1
 
 
 @pytest.mark.parametrize("kind,n,p", [("sparse", 20000, 2000),
