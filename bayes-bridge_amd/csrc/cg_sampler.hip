@@ -23,7 +23,7 @@ namespace bbx {
 
 int launch_cg_setup(bbx_design* h, int n_unshrunk, const double* phi,
                     const double* sd, const double* x0, double* s, double* d,
-                    double* xs);
+                    double* xs, CGState* st, double atol);
 int launch_cg_init_resid(bbx_design* h, const double* b, const double* q,
                          double* r, double* rr_part);
 int launch_cg_direction(bbx_design* h, int k, CGState* st,
@@ -163,13 +163,13 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     d_eta2 = e2;
   }
 
-  BBX_TRY(launch_cg_setup(h, n_unshrunk, d_phi, d_sd, d_x0, s, d, x));
+  BBX_TRY(launch_cg_setup(h, n_unshrunk, d_phi, d_sd, d_x0, s, d, x, st, atol));
 
   // Is the warm start all zeros?  SciPy's cg skips the product with x0 then
   // (`r = b - matvec(x) if x.any() else b.copy()`), and so do we.
   CGState* host_st = static_cast<CGState*>(h->host_pinned);
   if (x0_zero < 0) {
-    int* d_flag = reinterpret_cast<int*>(st);  // CGState is uploaded below
+    int* d_flag = &st->pad;  // scratch word of the state cg_setup just reset
     int* h_flag = reinterpret_cast<int*>(host_st);
     BBX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(any_nonzero_kernel, dim3(NPART), dim3(256), 0,
@@ -248,19 +248,9 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     }
   }
 
-  CGState init;
-  init.rho[0] = init.rho[1] = 0.;
-  init.atol = atol;
-  init.bnorm2 = 0.;
-  init.n_iter = 0;
-  init.done = 0;
-  init.bad = 0;
-  init.pad = 0;
-  *host_st = init;
-  BBX_HIP(hipMemcpyAsync(st, host_st, sizeof(CGState), hipMemcpyHostToDevice,
-                         h->stream));
-  // the pinned buffer is reused for the read-back below
-  BBX_HIP(hipStreamSynchronize(h->stream));
+  // (the loop's CGState was reset by cg_setup_kernel: no upload, and no host
+  // sync between the set-up and the loop -- the GPU used to idle ~30 us here
+  // while the host woke up and refilled the queue)
 
   // Opt-in (BBX_CG_FUSED=1): measured on MI355X at 1M x 50k the single fused
   // vector launch with its two in-launch reductions is ~5 us per CG iteration

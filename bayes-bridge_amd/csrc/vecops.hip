@@ -147,7 +147,18 @@ int launch_sqrt_scale(bbx_design* h, const double* d_omega,
 __global__ __launch_bounds__(VEC_BLOCK) void cg_setup_kernel(
     int64_t P, int n_unshrunk, const double* __restrict__ phi,
     const double* __restrict__ sd, const double* __restrict__ x0,
-    double* __restrict__ s, double* __restrict__ d, double* __restrict__ xs) {
+    double* __restrict__ s, double* __restrict__ d, double* __restrict__ xs,
+    CGState* __restrict__ st, double atol) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // the solve's scalars start here, on the device: nothing to upload
+    st->rho[0] = st->rho[1] = 0.;
+    st->atol = atol;
+    st->bnorm2 = 0.;
+    st->n_iter = 0;
+    st->done = 0;
+    st->bad = 0;
+    st->pad = 0;
+  }
   for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
        jj += (int64_t)gridDim.x * VEC_BLOCK) {
     const double ph = phi[jj];
@@ -494,9 +505,10 @@ int launch_cg_fused(bbx_design* h, const TdotSource& src, int k, int last,
 
 int launch_cg_setup(bbx_design* h, int n_unshrunk, const double* phi,
                     const double* sd, const double* x0, double* s, double* d,
-                    double* xs) {
+                    double* xs, CGState* st, double atol) {
   hipLaunchKernelGGL(cg_setup_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
-                     h->stream, h->P, n_unshrunk, phi, sd, x0, s, d, xs);
+                     h->stream, h->P, n_unshrunk, phi, sd, x0, s, d, xs, st,
+                     atol);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }
