@@ -618,9 +618,14 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
   // BBX_CHAIN_FORK=0 / 1 forces one / two streams.
   static const int fork_env =
       getenv("BBX_CHAIN_FORK") ? atoi(getenv("BBX_CHAIN_FORK")) : -1;
-  const bool fork = c->stream2 != nullptr &&
-                    (fork_env >= 0 ? fork_env == 1
-                                   : (n >= 400000 && n_shrunk >= 8192));
+  const bool fork = fork_env >= 0 ? fork_env == 1
+                                  : (n >= 400000 && n_shrunk >= 8192);
+  if (fork && c->stream2 == nullptr) {
+    // created on first use: chains that never fork keep a single queue
+    BBX_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    BBX_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    BBX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  }
   hipStream_t s_b = fork ? c->stream2 : s;
   if (fork) BBX_HIP(hipEventRecord(c->ev_fork, s));  // summary done with lambda
 
@@ -731,9 +736,6 @@ int bbx_chain_create(bbx_design* design, int model, const double* outcome,
     BBX_TRY(c->scalars.alloc(sizeof(ChainScalars)));
     BBX_TRY(c->row_part.alloc(sizeof(double) * ROW_GRID * 2));
     BBX_HIP(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
-    BBX_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    BBX_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    BBX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     BBX_HIP(hipMemcpy(c->outcome.ptr, outcome, nb, hipMemcpyHostToDevice));
     if (model == BBX_MODEL_LOGIT) {
       if (n_trial) {
