@@ -1,0 +1,44 @@
+"""A short device chain (bbx_chain_run) on a seeded problem, samples saved to
+an .npz -- for comparing variants that are selected once per process
+(BBX_CHAIN_FORK=0|1, BBX_CG_MERGE_RESID=0|1, BBX_CG_MERGE_UPDATE=0|1):
+    python scripts/chain_variant_run.py out.npz [logit|linear] [n] [p] [iters]
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "bayes-bridge_amd"))
+from bayesbridge_amd import HipSparseDesignMatrix, simulate
+from bayesbridge_amd.device_chain import HipGibbsChain
+
+out = sys.argv[1]
+family = sys.argv[2] if len(sys.argv) > 2 else "logit"
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
+p = int(sys.argv[4]) if len(sys.argv) > 4 else 300
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 6
+warnings.simplefilter("ignore")
+X = simulate.simulate_design_csr(n, p, binary_frac=.8, binary_pred_freq=.1, seed=3)
+beta = np.zeros(p)
+beta[:5], beta[5:10] = 1.5, -1.
+y = simulate.simulate_outcome(X, beta, family, seed=4)
+hip = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
+                            storage='tiled')
+P = hip.shape[1]
+if family == "logit":
+    chain = HipGibbsChain(hip, 'logit', y[0], n_trial=y[1], sd_unshrunk=[2.],
+                          bridge_exponent=.5, slab_size=2., gscale_shape=1.5,
+                          gscale_rate=.3, seed=17)
+else:
+    chain = HipGibbsChain(hip, 'linear', y, sd_unshrunk=[np.inf],
+                          bridge_exponent=.5, slab_size=2., seed=17)
+rng = np.random.default_rng(5)
+chain.set_state(np.zeros(P), None, np.exp(rng.normal(0., 1., P - 1)), .07)
+chain.init_obs_prec()
+kept, n_unconv = chain.run(iters, save=('coef', 'local_scale', 'obs_prec'))
+np.savez(out, coef=kept['coef'], local_scale=kept['local_scale'],
+         obs_prec=kept['obs_prec'], global_scale=kept['global_scale'],
+         logp=kept['logp'], n_cg_iter=kept['n_cg_iter'])
+print("n_cg", kept['n_cg_iter'].tolist(), "unconverged", n_unconv)
