@@ -15,7 +15,7 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 template <int D, int MODE>
 __global__ __launch_bounds__(1024) void rd(const v4u* __restrict__ src, int64_t steps,
-                                           unsigned* sink) {
+                                           unsigned* sink, unsigned long long* ends) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t gw = (int64_t)blockIdx.x * 16 + wave, nw = (int64_t)gridDim.x * 16;
   auto chunk = [&](int64_t i) -> int64_t {  // index of the i-th 1 KiB chunk of this wave
@@ -40,12 +40,16 @@ __global__ __launch_bounds__(1024) void rd(const v4u* __restrict__ src, int64_t 
   for (int k = 0; k < D; ++k) acc ^= r[k];
   const unsigned f = acc.x ^ acc.y ^ acc.z ^ acc.w;
   if (f == 0x9E3779B9u) sink[0] = f;
+  // when did this wave's stream end (relative to the other waves of its workgroup)?
+  if (ends && lane == 0) ends[gw] = __builtin_amdgcn_s_memtime();
 }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 template <int D, int MODE>
 static int run(const void* a, const void* b, int64_t steps, void* sink) {
+  static unsigned long long* d_ends = nullptr;
+  if (!d_ends) CK(hipMalloc(&d_ends, 8 * 4096));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -54,21 +58,37 @@ static int run(const void* a, const void* b, int64_t steps, void* sink) {
   for (int it = -4; it < reps; ++it) {
     if (it == 0) CK(hipEventRecord(e0, 0));
     hipLaunchKernelGGL((rd<D, MODE>), dim3(256), dim3(1024), 0, 0,
-                       (const v4u*)((it & 1) ? b : a), steps, (unsigned*)sink);
+                       (const v4u*)((it & 1) ? b : a), steps, (unsigned*)sink, d_ends);
   }
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
   const double bytes = (double)steps * 4096 * 1024;
-  printf("  mode %d  ring %d KiB/wave: %.1f us per launch  %.0f GB/s\n", MODE, D,
-         1e3 * ms / reps, bytes * reps / ms / 1e6);
+  // spread of the 16 waves of a workgroup at the end of the last launch:
+  // what a barrier there would cost (mean over workgroups of max - mean)
+  unsigned long long h_ends[4096];
+  CK(hipMemcpy(h_ends, d_ends, sizeof(h_ends), hipMemcpyDeviceToHost));
+  double wait = 0.;
+  for (int g = 0; g < 256; ++g) {
+    double mx = 0., mean = 0.;
+    unsigned long long base = h_ends[g * 16];
+    for (int w = 0; w < 16; ++w) {
+      const double t = (double)(long long)(h_ends[g * 16 + w] - base);
+      mean += t / 16.;
+      if (w == 0 || t > mx) mx = t;
+    }
+    wait += (mx - mean) / 256.;
+  }
+  printf("  mode %d  ring %d KiB/wave: %.1f us per launch  %.0f GB/s   end-of-stream spread "
+         "inside a workgroup (max - mean): %.0f ticks\n", MODE, D,
+         1e3 * ms / reps, bytes * reps / ms / 1e6, wait);
   return 0;
 }
 
 int main() {
   void* sink;
   CK(hipMalloc(&sink, 64));
-  for (int64_t steps : {(int64_t)52, (int64_t)104, (int64_t)480}) {
+  for (int64_t steps : {(int64_t)13, (int64_t)52, (int64_t)104}) {
     const int64_t bytes = steps * 4096 * 1024;
     void *a, *b;
     CK(hipMalloc(&a, bytes));
