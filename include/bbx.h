@@ -251,7 +251,12 @@ int bbx_cg_sample_dev(bbx_design* h, const double* d_obs_prec,
 
 /* Counters of operator applications since creation / last reset, the
  * equivalent of AbstractDesignMatrix.get_dot_count / reset_matvec_count
- * (abstract_matrix.py:61-72).  Applications inside bbx_cg_sample count too. */
+ * (abstract_matrix.py:61-72).  Applications inside bbx_cg_sample count too:
+ * n_iter products with X~ and with X~^T for the iterations, one product with
+ * X~ for a non-zero warm start, and ONE product with X~^T for the initial
+ * residual -- the reference's two (the right-hand side's and the one inside
+ * A x0) are a single pass over X~^T here, by linearity.  A pass is a pass:
+ * it counts once. */
 int bbx_design_matvec_count(const bbx_design* h, int64_t* n_dot,
                             int64_t* n_tdot);
 int bbx_design_reset_matvec_count(bbx_design* h);
