@@ -241,3 +241,20 @@ def test_update_in_the_tdot_epilogue_equals_the_separate_update(tmp_path, kind,
     scale = max(1., np.abs(a['coef']).max())
     tol = 1e-6 if int(a['n_iter']) == int(b['n_iter']) else 1e-5
     assert np.abs(a['coef'] - b['coef']).max() <= tol * scale
+
+
+def test_cg_sample_wide_design_with_column_groups_in_the_dot():
+    """p = 40 000 > one LDS slice: the tiled X~ v runs with several column
+    groups per row panel (G > 1, partial slabs + tiled_dot_finalize_kernel),
+    a shape whose dot kernel does not deliver <t, Omega t>; the CG loop then
+    keeps cg_update_kernel (the fallback of apply_operator).  Against the
+    oracle like every other case."""
+    from bayesbridge_amd import HipSparseDesignMatrix, simulate
+    X = simulate.simulate_binary_csr_fast(3000, 40000, .003, seed=5)
+    hip = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
+                                storage='tiled')
+    assert hip.tiled_info()['X']['G'] > 1
+    del hip
+    n, P = X.shape[0], X.shape[1] + 1
+    out = _run_both(X, cg_inputs(n, P, seed=2, lam_log_sd=.3), storage='tiled')
+    _assert_close(*out)
