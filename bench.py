@@ -341,12 +341,20 @@ def main():
         else:
             op_bytes = dot_wb + tdot_wb
         op_gbs = op_bytes / op_avg / 1e6 if op_avg > 0 else 0.
-        # whole Gibbs iteration: (n_cg + 1) operator applications (warm start),
-        # the RHS Tdot, the linear predictor of the Omega update, 12 P-vector
-        # passes per CG iteration (direction 6, update 6), ~64 bytes per row
-        # and ~30 P-vector passes for the eta draws and the chain kernels
-        iter_bytes = ((mean_ncg + 1) * op_bytes + dot_wb + tdot_wb
-                      + mean_ncg * 12 * 8 * P + 64 * n + 30 * 8 * P)
+        # whole Gibbs iteration: n_cg operator applications; for the warm
+        # start one more application (dense single-pass kernel) or one product
+        # with X~ plus ONE with X~^T for the initial residual (the reference's
+        # RHS Tdot and the Tdot inside A x0 are a single pass over X~^T,
+        # cg_sampler.hip TD_RESID); the linear predictor of the Omega update;
+        # 10 P-vector passes per CG iteration (direction 6, update in the Tdot
+        # epilogue 4: q is no longer stored), ~64 bytes per row and ~30
+        # P-vector passes for the eta draws and the chain kernels.  Only bytes
+        # that are moved are credited.
+        if dense and fused_b:
+            iter_bytes = (mean_ncg + 1) * op_bytes + dot_wb
+        else:
+            iter_bytes = mean_ncg * op_bytes + 2 * dot_wb + tdot_wb
+        iter_bytes += mean_ncg * 10 * 8 * P + 64 * n + 30 * 8 * P
         iter_gbs = iter_bytes / ms_step / 1e6
         # measured on this box, same size as one launch's algorithmic bytes
         # and at 2 GB: what a plain streaming kernel reaches
