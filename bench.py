@@ -431,6 +431,9 @@ def main():
                 "burnin_ms_per_step": round(burnin_ms, 4) if B > 0 else None,
                 "first_50_n_cg_iter": round(float(ncg_b[:50].mean()), 2)
                 if B >= 50 else None,
+                # the timed region's counts (what the solve's look-ahead for
+                # the stop flag has to predict)
+                "n_cg_iter_timed": [int(v) for v in ncg[:64]],
                 "parallelism": "chains=%d" % world,
                 "devices": min(world, n_dev),
                 "backend": backend,
