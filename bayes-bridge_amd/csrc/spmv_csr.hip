@@ -120,12 +120,16 @@ __device__ inline double block_sum_256(double x) {
 // `gfull` != nullptr means the main product comes as n_slab partial slabs of
 // p entries each (the tiled and dense paths), added here in slab order; then
 // row_chunk_ptr/partial are unused.
+// (the epilogue mode is a template parameter: the kernel runs twice per CG
+// iteration and is pure latency, so the branches and loads of the modes it is
+// not in are worth compiling away)
+template <int mode>
 __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
     int64_t p, int intercept, const int32_t* __restrict__ row_chunk_ptr,
     const double* __restrict__ partial, const double* __restrict__ gfull,
     int n_slab, int64_t slab_stride, const double* __restrict__ offset,
     const double* __restrict__ sumw_part,
-    int mode, const double* __restrict__ s, const double* __restrict__ d,
+    const double* __restrict__ s, const double* __restrict__ d,
     const double* __restrict__ x, const double* __restrict__ z,
     const double* __restrict__ phi, const double* __restrict__ eta2,
     double* __restrict__ out, double* __restrict__ dot_part,
@@ -323,16 +327,29 @@ int launch_dot_csr(bbx_design* h, const double* d_v, const double* d_rowscale,
   return BBX_OK;
 }
 
+#define BBX_FINALIZE_MODES(LAUNCH)                                             \
+  switch (ep.mode) {                                                           \
+    case TD_PLAIN: LAUNCH(TD_PLAIN); break;                                    \
+    case TD_OPER: LAUNCH(TD_OPER); break;                                      \
+    case TD_RHS: LAUNCH(TD_RHS); break;                                        \
+    case TD_OPER_UPD: LAUNCH(TD_OPER_UPD); break;                              \
+    case TD_RESID: LAUNCH(TD_RESID); break;                                    \
+    default: return fail(BBX_ERR_INVALID, "unknown Tdot epilogue mode");       \
+  }
+
 int launch_tdot_finalize(bbx_design* h, const double* d_gfull, int n_slab,
                          const double* d_sumw_part, const TdotEpilogue& ep,
                          double* d_out) {
-  hipLaunchKernelGGL(tdot_finalize_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
-                     h->stream, h->p, h->intercept,
-                     h->t_row_chunk_ptr.as<int32_t>(),
-                     h->t_partial.as<double>(), d_gfull, n_slab, h->p,
-                     h->offset.as<double>(), d_sumw_part, ep.mode, ep.s, ep.d,
-                     ep.x, ep.z, ep.phi, ep.eta2, d_out, ep.dot_part, ep.cg_x,
-                     ep.cg_r, ep.cg_state, ep.cg_k, ep.pdp_part, ep.twt_part);
+#define BBX_FIN(MODE)                                                          \
+  hipLaunchKernelGGL(tdot_finalize_kernel<MODE>, dim3(NPART), dim3(VEC_BLOCK), \
+                     0, h->stream, h->p, h->intercept,                         \
+                     h->t_row_chunk_ptr.as<int32_t>(),                         \
+                     h->t_partial.as<double>(), d_gfull, n_slab, h->p,         \
+                     h->offset.as<double>(), d_sumw_part, ep.s, ep.d, ep.x,    \
+                     ep.z, ep.phi, ep.eta2, d_out, ep.dot_part, ep.cg_x,       \
+                     ep.cg_r, ep.cg_state, ep.cg_k, ep.pdp_part, ep.twt_part)
+  BBX_FINALIZE_MODES(BBX_FIN)
+#undef BBX_FIN
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }
@@ -342,14 +359,17 @@ int launch_tdot_finalize(bbx_design* h, const double* d_gfull, int n_slab,
 int launch_tdot_finalize_dense(bbx_design* h, const TdotEpilogue& ep,
                                double* d_out, const double* d_slab,
                                int n_slab) {
-  hipLaunchKernelGGL(tdot_finalize_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
-                     h->stream, h->P, 0, nullptr, nullptr,
-                     d_slab ? d_slab : h->dense_slab.as<double>(),
-                     d_slab ? n_slab : h->dense_chunks, h->dense_ld,
-                     h->offset.as<double>(), part_slot(h, PS_ZERO), ep.mode,
-                     ep.s, ep.d, ep.x, ep.z, ep.phi, ep.eta2, d_out,
-                     ep.dot_part, ep.cg_x, ep.cg_r, ep.cg_state, ep.cg_k,
-                     ep.pdp_part, ep.twt_part);
+#define BBX_FIN(MODE)                                                          \
+  hipLaunchKernelGGL(tdot_finalize_kernel<MODE>, dim3(NPART), dim3(VEC_BLOCK), \
+                     0, h->stream, h->P, 0, nullptr, nullptr,                  \
+                     d_slab ? d_slab : h->dense_slab.as<double>(),             \
+                     d_slab ? n_slab : h->dense_chunks, h->dense_ld,           \
+                     h->offset.as<double>(), part_slot(h, PS_ZERO), ep.s,      \
+                     ep.d, ep.x, ep.z, ep.phi, ep.eta2, d_out, ep.dot_part,    \
+                     ep.cg_x, ep.cg_r, ep.cg_state, ep.cg_k, ep.pdp_part,      \
+                     ep.twt_part)
+  BBX_FINALIZE_MODES(BBX_FIN)
+#undef BBX_FIN
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }
