@@ -58,6 +58,11 @@ def init_process_group_from_env(backend=None):
                                  torch.cuda.device_count() >= world) else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
+        if torch.cuda.is_available() and torch.cuda.device_count() < world:
+            # ranks share devices (dry runs on a small box): one HIP queue per
+            # process -- the chain's second stream makes co-tenants on one GPU
+            # time-slice badly (measured 3x slower), see chain.hip chain_step
+            os.environ.setdefault("BBX_CHAIN_FORK", "0")
         if backend == "nccl":
             # RCCL binds a communicator to the current device
             torch.cuda.set_device(local_rank % torch.cuda.device_count())

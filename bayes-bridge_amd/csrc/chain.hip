@@ -54,7 +54,7 @@ struct bbx_chain {
   void* pinned = nullptr;
   // second stream for the tau / lambda branch of an iteration
   hipStream_t stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_join = nullptr;
 };
 
 namespace bbx {
@@ -598,11 +598,6 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
       &info, c->mean_zero ? 1 : 0);
   if (st < 0) return st;
   c->mean_zero = false;
-  hipLaunchKernelGGL(chain_summary_kernel, dim3(NPART), dim3(256), 0, s, P, nu,
-                     c->slab, (long long)c->n_averaged, sc,
-                     c->lscale.as<double>(), c->coef.as<double>(),
-                     c->mean.as<double>(), c->square.as<double>());
-  c->n_averaged += 1;
 
   // The two updates that follow read beta and nothing of each other: the
   // Omega branch (X~ beta: one pass over the matrix, then n Polya-Gamma draws)
@@ -611,42 +606,38 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
   // coefficients) runs beside it on a second stream.  Each branch writes its
   // own half of ChainScalars; Philox streams are keyed by element, so the
   // draws do not depend on the interleaving.  beta is final here (the CG
-  // solve ended with a stream sync), so the second stream starts at once; only
-  // the lambda kernel has to wait, for the summary kernel above, which still
-  // reads the old lambda.  Worth it when the Omega branch is long enough to
-  // hide the cross-stream hand-offs (~20 us): config 3 +2 %, config 2 -2.5 %.
-  // BBX_CHAIN_FORK=0 / 1 forces one / two streams.
+  // solve ended with a stream sync), so the second stream needs no event to
+  // start; the summary kernel, which reads the OLD tau and lambda, leads that
+  // branch.  The design's stream waits for the branch at the end.  Measured:
+  // config 3 +1.6 %, config 2 +2.5 %, config 4 +-0; tiny problems keep one
+  // stream, and so should processes that SHARE a GPU (two ranks on one device
+  // ran 3x slower with a second queue each: chains.py sets BBX_CHAIN_FORK=0
+  // then).  BBX_CHAIN_FORK=0 / 1 forces one / two streams.
   static const int fork_env =
       getenv("BBX_CHAIN_FORK") ? atoi(getenv("BBX_CHAIN_FORK")) : -1;
   const bool fork = fork_env >= 0 ? fork_env == 1
-                                  : (n >= 400000 && n_shrunk >= 8192);
+                                  : (n >= 50000 && n_shrunk >= 2048);
   if (fork && c->stream2 == nullptr) {
     // created on first use: chains that never fork keep a single queue
     BBX_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    BBX_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     BBX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   }
   hipStream_t s_b = fork ? c->stream2 : s;
-  if (fork) BBX_HIP(hipEventRecord(c->ev_fork, s));  // summary done with lambda
 
-  // --- Omega | beta  (bayesbridge.py:397-410)
+  // --- Omega | beta  (bayesbridge.py:397-410).  Launch order = what has to
+  // start first: the pass over the matrix, then the whole second branch (it
+  // starts under that pass: the lambda kernel and the Polya-Gamma kernel are
+  // both ALU-bound and slow each other down, the pass is bandwidth-bound),
+  // then the n Polya-Gamma draws.
   BBX_TRY(chain_linear_predictor(c));
-  const int rg = grid_for(n, ROW_GRID);
-  double* rp = c->row_part.as<double>();
-  if (c->model == BBX_MODEL_LOGIT) {
-    hipLaunchKernelGGL(chain_pg_kernel, dim3(rg), dim3(256), 0, s, n, c->seed,
-                       iter_stream(STREAM_PG, c->iter),
-                       c->outcome.as<double>(), c->n_trial.as<double>(),
-                       c->psi.as<double>(), c->obs_prec.as<double>(), rp);
-  } else {
-    hipLaunchKernelGGL(chain_rss_kernel, dim3(rg), dim3(256), 0, s, n,
-                       c->outcome.as<double>(), c->psi.as<double>(), rp);
-  }
-  hipLaunchKernelGGL(chain_obs_finish_kernel, dim3(1), dim3(256), 0, s,
-                     c->model, 0, n, c->seed,
-                     iter_stream(STREAM_OBSVAR, c->iter), rp, rg, sc);
 
-  // --- tau | beta, then lambda | tau, beta, then log posterior
+  // --- running summaries of beta (with the tau and lambda it was drawn
+  // under), then tau | beta, then lambda | tau, beta, then log posterior
+  hipLaunchKernelGGL(chain_summary_kernel, dim3(NPART), dim3(256), 0, s_b, P,
+                     nu, c->slab, (long long)c->n_averaged, sc,
+                     c->lscale.as<double>(), c->coef.as<double>(),
+                     c->mean.as<double>(), c->square.as<double>());
+  c->n_averaged += 1;
   double* pp = part_slot(h, PS_MISC);
   hipLaunchKernelGGL(chain_coef_sums_kernel, dim3(NPART), dim3(256), 0, s_b, P,
                      nu, c->bridge_exp, c->slab, c->coef.as<double>(),
@@ -658,7 +649,6 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
                      c->gscale_update, c->seed,
                      iter_stream(STREAM_GSCALE, c->iter), pp, pp + NPART,
                      pp + 2 * NPART, c->sd_unshrunk.as<double>(), sc);
-  if (fork) BBX_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
   if (n_shrunk > 0) {
     // Measured at p = 50k (ms per Gibbs iteration, items per block): 256:
     // 5.69, 128: 5.63, 64: 5.72, 32: 5.83, 16: 6.11 -- the speculative copies
@@ -677,6 +667,23 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
                        c->coef.as<double>(), c->lscale.as<double>(), items,
                        ts_cost_threshold());
   }
+
+  // --- Omega | beta, continued
+  const int rg = grid_for(n, ROW_GRID);
+  double* rp = c->row_part.as<double>();
+  if (c->model == BBX_MODEL_LOGIT) {
+    hipLaunchKernelGGL(chain_pg_kernel, dim3(rg), dim3(256), 0, s, n, c->seed,
+                       iter_stream(STREAM_PG, c->iter),
+                       c->outcome.as<double>(), c->n_trial.as<double>(),
+                       c->psi.as<double>(), c->obs_prec.as<double>(), rp);
+  } else {
+    hipLaunchKernelGGL(chain_rss_kernel, dim3(rg), dim3(256), 0, s, n,
+                       c->outcome.as<double>(), c->psi.as<double>(), rp);
+  }
+  hipLaunchKernelGGL(chain_obs_finish_kernel, dim3(1), dim3(256), 0, s,
+                     c->model, 0, n, c->seed,
+                     iter_stream(STREAM_OBSVAR, c->iter), rp, rg, sc);
+
   BBX_HIP(hipGetLastError());
   if (fork) {
     BBX_HIP(hipEventRecord(c->ev_join, c->stream2));
@@ -799,7 +806,6 @@ int bbx_chain_destroy(bbx_chain* c) {
     (void)hipStreamSynchronize(c->stream2);
     (void)hipStreamDestroy(c->stream2);
   }
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->pinned) (void)hipHostFree(c->pinned);
   delete c;
