@@ -10,8 +10,7 @@ from ctypes import (POINTER, byref, c_char_p, c_double, c_int, c_int32,
                     c_int64, c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get(
-    "BBX_LIBRARY", os.path.join(os.path.dirname(_HERE), "libbbx.so"))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libbbx.so")
 
 FORMAT_AUTO, FORMAT_CSR, FORMAT_TILED = 0, 1, 2
 F64, F32 = 0, 1

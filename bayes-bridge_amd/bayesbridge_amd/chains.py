@@ -42,15 +42,18 @@ def launch_ranks(n_ranks, script_argv, port=None, extra_env=None,
     return subprocess.call(cmd, env=env, timeout=timeout)
 
 
-def init_process_group_from_env(backend=None):
+def init_process_group_from_env(backend=None, single_rank_group=False):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run)
-    and returns (rank, world_size, local_rank).  World size 1 needs no group."""
+    and returns (rank, world_size, local_rank).  World size 1 needs no group;
+    `single_rank_group` creates one anyway (a launcher started this process:
+    `torch.distributed.run --nproc-per-node 1` then runs every collective of
+    the N-rank path over RCCL on the one device)."""
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         if backend is None:
             # RCCL needs one distinct GPU per rank; with fewer devices than
             # ranks (dry runs on a 1-GPU box) fall back to gloo
@@ -82,8 +85,7 @@ def gather_chain_samples(local, dst=0):
     the point-to-point fabric better than a ring."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) \
-            or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local.unsqueeze(0)
     world = dist.get_world_size()
     rank = dist.get_rank()
@@ -105,8 +107,7 @@ def max_over_ranks(value):
     """MAX all-reduce of a Python float (timing: the slowest rank counts)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) \
-            or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(value)
     dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)

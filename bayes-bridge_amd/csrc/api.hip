@@ -51,6 +51,7 @@ int timer_begin(bbx_design* h, int which) {
     BBX_HIP(hipEventCreate(&pr.a));
     BBX_HIP(hipEventCreate(&pr.b));
   }
+  pr.tag = h->timer.cur_tag;
   BBX_HIP(hipEventRecord(pr.a, h->stream));
   h->timer.pending[which].push_back(pr);
   return BBX_OK;
@@ -70,10 +71,28 @@ int timer_arm(bbx_design* h, int which, hipEvent_t* a, hipEvent_t* b) {
     BBX_HIP(hipEventCreate(&pr.a));
     BBX_HIP(hipEventCreate(&pr.b));
   }
+  pr.tag = h->timer.cur_tag;
   h->timer.pending[which].push_back(pr);
   *a = pr.a;
   *b = pr.b;
   return BBX_OK;
+}
+
+void timer_drop_skipped(bbx_design* h, int n_iter) {
+  if (!h->timer.enabled) return;
+  for (int which = 0; which < KernelTimer::FAMILIES; ++which) {
+    auto& v = h->timer.pending[which];
+    size_t keep = 0;
+    for (size_t i = 0; i < v.size(); ++i) {
+      if (v[i].tag >= 0 && v[i].tag >= n_iter) {
+        h->timer.pool.push_back(v[i]);
+      } else {
+        v[i].tag = -1;  // resolved: a later solve's count does not apply
+        v[keep++] = v[i];
+      }
+    }
+    v.resize(keep);
+  }
 }
 
 int timer_end(bbx_design* h, int which) {
@@ -139,26 +158,6 @@ int launch_tdot(bbx_design* h, const double* d_w, const double* d_sumw_part,
   return launch_tdot_csr(h, d_w, d_sumw_part, ep, d_out);
 }
 
-int launch_tdot_main_csr(bbx_design* h, const double* d_w, TdotSource* src);
-int launch_tdot_main_tiled(bbx_design* h, const double* d_w, TdotSource* src);
-int launch_tdot_main_dense(bbx_design* h, const double* d_w, TdotSource* src);
-
-int launch_tdot_main(bbx_design* h, const double* d_w,
-                     const double* d_sumw_part, TdotSource* src) {
-  h->n_tdot += 1;
-  *src = TdotSource();
-  if (!h->sparse) {
-    BBX_TRY(launch_tdot_main_dense(h, d_w, src));
-  } else if (h->format == BBX_FORMAT_TILED) {
-    BBX_TRY(launch_tdot_main_tiled(h, d_w, src));
-    src->sumw_part = d_sumw_part;
-  } else {
-    BBX_TRY(launch_tdot_main_csr(h, d_w, src));
-    src->sumw_part = d_sumw_part;
-  }
-  return BBX_OK;
-}
-
 int design_alloc_work(bbx_design* h) {
   for (auto& m : h->w_n) BBX_TRY(m.alloc(sizeof(double) * (size_t)h->n));
   // (+2: the CG loop shifts its scaled-direction buffer by one element so that
@@ -167,8 +166,6 @@ int design_alloc_work(bbx_design* h) {
   BBX_TRY(h->part.alloc(sizeof(double) * NPART * PS_COUNT));
   BBX_HIP(hipMemset(h->part.ptr, 0, sizeof(double) * NPART * PS_COUNT));
   BBX_TRY(h->cg_state.alloc(sizeof(CGState)));
-  BBX_TRY(h->cg_gran.alloc(sizeof(uint64_t) * 1024 + 64));
-  BBX_HIP(hipMemset(h->cg_gran.ptr, 0, sizeof(uint64_t) * 1024 + 64));
   BBX_TRY(h->stage_n.alloc(sizeof(double) * (size_t)h->n * 2));
   BBX_TRY(h->stage_P.alloc(sizeof(double) * (size_t)h->P * 6));
   BBX_HIP(hipHostMalloc(&h->host_pinned, 256, hipHostMallocDefault));
@@ -784,21 +781,13 @@ static int bbx_design_get_timing_impl(bbx_design* h, int which, int64_t* n_launc
     return fail(BBX_ERR_INVALID, "which must be 0, 1 or 2");
   BBX_HIP(hipSetDevice(h->device));
   BBX_TRY(timer_collect(h));
-  // real executions only: drop samples below half the median (launches that
-  // found the solve's stop flag set and returned at entry)
-  std::vector<float> v = h->timer.samples[which];
+  // (launches that returned at entry on the stop flag were discarded by the CG
+  // loop, timer_drop_skipped: every sample here is an execution)
   int64_t cnt = 0;
   double tot = 0.;
-  if (!v.empty()) {
-    std::vector<float> sorted = v;
-    std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2,
-                     sorted.end());
-    const float floor_ms = .5f * sorted[sorted.size() / 2];
-    for (float ms : v)
-      if (ms >= floor_ms) {
-        ++cnt;
-        tot += (double)ms;
-      }
+  for (float ms : h->timer.samples[which]) {
+    ++cnt;
+    tot += (double)ms;
   }
   if (n_launch) *n_launch = cnt;
   if (total_ms) *total_ms = tot;
@@ -882,8 +871,7 @@ int bbx_design_timed_bytes(const bbx_design* h, int64_t* dot_bytes,
 int bbx_design_fused_operator_bytes(const bbx_design* h, int64_t* bytes) {
   BBX_TRY(check_handle(h));
   int64_t b = 0;
-  const int64_t ld_max = h->dense_dtype == BBX_F32 ? 8192 : 4096;
-  if (!h->sparse && h->dense_ld <= ld_max && h->n >= 4096) {
+  if (dense_fused_applies(h)) {
     const int64_t el = h->dense_dtype == BBX_F32 ? 4 : 8;
     // ONE pass over the matrix, v and Omega in, 256 per-workgroup slabs out
     b = h->n * h->dense_ld * el + 8 * (h->P + h->n) +

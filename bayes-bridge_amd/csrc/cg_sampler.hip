@@ -24,8 +24,6 @@ namespace bbx {
 int launch_cg_setup(bbx_design* h, int n_unshrunk, const double* phi,
                     const double* sd, const double* x0, double* s, double* d,
                     double* xs, CGState* st, double atol);
-int launch_cg_init_resid(bbx_design* h, const double* b, const double* q,
-                         double* r, double* rr_part);
 int launch_cg_direction(bbx_design* h, int k, CGState* st,
                         const double* rr_part, const double* r, double* pvec,
                         const double* s, double* sp, double* c_part,
@@ -35,9 +33,6 @@ int launch_cg_update(bbx_design* h, int k, CGState* st, const double* pq_part,
                      double* rr_part);
 int launch_cg_finish(bbx_design* h, const double* s, const double* x,
                      double* coef);
-int launch_cg_fused(bbx_design* h, const TdotSource& src, int k, int last,
-                    CGState* st, const double* s, const double* d, double* pvec,
-                    double* x, double* r, double* sp, double* c_part);
 
 __global__ __launch_bounds__(256) void fill_normal_kernel(
     int64_t len, uint64_t seed, uint64_t stream, double* __restrict__ out) {
@@ -151,7 +146,6 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
   // 16-byte aligned, so the buffer starts one element in when there is an
   // intercept entry
   double* sp = h->w_P[6].as<double>() + (h->intercept ? 1 : 0);
-  double* b = h->w_P[7].as<double>();
   CGState* st = h->cg_state.as<CGState>();
 
   if (d_eta1 == nullptr) {
@@ -182,17 +176,16 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
   }
 
   // r = b - A x0 with b = s (z + X~^T(sqrt(Omega) eta1) + phi eta2).
-  // BBX_CG_MERGE_RESID=0: the reference's sequence, b by one transposed product
-  // and A x0 by an operator application (two passes over X~^T for a warm start).
-  // Default: X~^T is linear, so both go through ONE transposed product,
+  // SciPy forms b by one transposed product and A x0 by an operator application
+  // (two passes over X~^T for a warm start).  X~^T is linear, so both go
+  // through ONE transposed product,
   //   g = X~^T (Omega (X~ (s x0)) - sqrt(Omega) eta1),
   //   r = s (z + (phi eta2 - g)) - d x0          (TD_RESID epilogue),
   // and b is never formed (only the absolute stop rule is in use).  One pass
   // over X~^T, one epilogue and one P-vector launch less per draw; the counters
-  // then show one Tdot less than the reference's for a warm start.
-  static const bool merge_resid =
-      !(getenv("BBX_CG_MERGE_RESID") && atoi(getenv("BBX_CG_MERGE_RESID")) == 0);
-  if (merge_resid) {
+  // then show one Tdot less than the reference's for a warm start.  (The
+  // reference's sequence is kept as scripts/experiments/r02_cg_variants.patch.)
+  {
     double* w = h->w_n[1].as<double>();
     TdotEpilogue ep;
     ep.mode = TD_RESID;
@@ -226,40 +219,12 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
                                 t0, /*negate=*/t0 == nullptr));
       BBX_TRY(launch_tdot(h, w, part_slot(h, PS_SUMW), ep, r));
     }
-  } else {
-    {
-      double* w = h->w_n[1].as<double>();
-      BBX_TRY(launch_sqrt_scale(h, d_omega, d_eta1, w, part_slot(h, PS_SUMW)));
-      TdotEpilogue ep;
-      ep.mode = TD_RHS;
-      ep.s = s;
-      ep.z = d_z;
-      ep.phi = d_phi;
-      ep.eta2 = d_eta2;
-      ep.dot_part = part_slot(h, PS_MISC);
-      BBX_TRY(launch_tdot(h, w, part_slot(h, PS_SUMW), ep, b));
-    }
-    if (x0_zero) {
-      BBX_TRY(launch_cg_init_resid(h, b, nullptr, r, part_slot(h, PS_RR)));
-    } else {
-      BBX_TRY(launch_prep_v(h, x, s, sp, part_slot(h, PS_C)));
-      BBX_TRY(apply_operator(h, d_omega, sp, x, s, d, q));
-      BBX_TRY(launch_cg_init_resid(h, b, q, r, part_slot(h, PS_RR)));
-    }
   }
 
   // (the loop's CGState was reset by cg_setup_kernel: no upload, and no host
   // sync between the set-up and the loop -- the GPU used to idle ~30 us here
   // while the host woke up and refilled the queue)
 
-  // Opt-in (BBX_CG_FUSED=1): measured on MI355X at 1M x 50k the single fused
-  // vector launch with its two in-launch reductions is ~5 us per CG iteration
-  // SLOWER than the three small launches it replaces (147 vs 142 us), so the
-  // plain sequence stays the default.
-  static const bool use_fused =
-      getenv("BBX_CG_FUSED") && atoi(getenv("BBX_CG_FUSED")) == 1;
-  const bool fused =
-      use_fused && h->P <= (int64_t)NPART * VEC_BLOCK * 4;  // FUSED_EMAX
   int k = 0;
   bool done = false;
   bool finished_at_poll = false;
@@ -274,65 +239,19 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     bbx_design* h;
     ~SkipScope() { h->skip_flag = nullptr; }
   } skip_scope{h};
-  static const bool no_skip_env =
-      getenv("BBX_CG_NO_SKIP") && atoi(getenv("BBX_CG_NO_SKIP")) == 1;
-  // (every operator kernel of every format reads the flag; BBX_CG_NO_SKIP=1
-  // restores round 1's careful schedule: first look one iteration BEFORE the
-  // previous solve's count, no flag)
-  const bool can_skip = !no_skip_env;
-  h->skip_flag = can_skip ? &st->done : nullptr;
-  int next_poll = h->last_cg_iter > 2
-                      ? h->last_cg_iter + (can_skip ? 2 : -1)
-                      : 1;
-  if (fused) {
-    // direction(0) on its own; afterwards ONE vector launch per iteration does
-    // the Tdot epilogue, the update and the next direction (vecops.hip).
-    if (maxiter > 0)
-      BBX_TRY(launch_cg_direction(h, 0, st, part_slot(h, PS_RR), r, pvec, s, sp,
-                                  part_slot(h, PS_C)));
-    double* t = h->w_n[0].as<double>();
-    while (k < maxiter) {
-      const int stop = (next_poll < maxiter) ? next_poll : maxiter;
-      for (; k < stop; ++k) {
-        BBX_TRY(launch_dot(h, sp, d_omega, t, part_slot(h, PS_SUMW)));
-        TdotSource src;
-        BBX_TRY(launch_tdot_main(h, t, part_slot(h, PS_SUMW), &src));
-        const int st_l = launch_cg_fused(h, src, k, k + 1 == maxiter ? 1 : 0, st,
-                                         s, d, pvec, x, r, sp,
-                                         part_slot(h, PS_C));
-        if (st_l < 0) return st_l;
-      }
-      if (k >= maxiter) break;
-      BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState),
-                             hipMemcpyDeviceToHost, h->stream));
-      BBX_HIP(hipStreamSynchronize(h->stream));
-      if (host_st->done) break;
-      next_poll = k + 2;
-    }
-    {  // a bounded spin that gave up leaves its epoch in the timeout word
-      unsigned tmo = 0;
-      BBX_HIP(hipMemcpyAsync(&tmo, (char*)h->cg_gran.ptr + sizeof(uint64_t) * 1024,
-                             sizeof(unsigned), hipMemcpyDeviceToHost,
-                             h->stream));
-      BBX_HIP(hipStreamSynchronize(h->stream));
-      if (tmo != 0) {
-        BBX_HIP(hipMemsetAsync((char*)h->cg_gran.ptr + sizeof(uint64_t) * 1024,
-                               0, sizeof(unsigned), h->stream));
-        return fail(BBX_ERR_HIP,
-                    "fused CG step: cross-workgroup exchange timed out");
-      }
-    }
-  } else {
-  // BBX_CG_MERGE_UPDATE=0: keep the update as its own launch (A/B)
-  static const bool merge_update =
-      !(getenv("BBX_CG_MERGE_UPDATE") && atoi(getenv("BBX_CG_MERGE_UPDATE")) == 0);
-  double* pdp = merge_update ? part_slot(h, PS_PDP) : nullptr;
+  h->skip_flag = &st->done;
+  int next_poll = h->last_cg_iter > 2 ? h->last_cg_iter + 2 : 1;
+  double* pdp = part_slot(h, PS_PDP);
   bool merged = false;
   // one CG iteration after its direction kernel: q = A p and the update
+  struct TagScope {
+    bbx_design* h;
+    ~TagScope() { h->timer.cur_tag = -1; }
+  } tag_scope{h};
   auto operator_and_update = [&](int kk) -> int {
+    h->timer.cur_tag = kk;  // kernel-timer samples know their iteration
     CGUpdate upd{kk, st, x, r, &merged};
-    BBX_TRY(apply_operator(h, d_omega, sp, pvec, s, d, q,
-                           merge_update ? &upd : nullptr));
+    BBX_TRY(apply_operator(h, d_omega, sp, pvec, s, d, q, &upd));
     if (!merged)
       BBX_TRY(launch_cg_update(h, kk, st, part_slot(h, PS_PQ), pvec, q, x, r,
                                part_slot(h, PS_RR)));
@@ -369,7 +288,6 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     ++k;
     next_poll = k + 2;
   }
-  }
   if (!finished_at_poll) {
     BBX_TRY(launch_cg_finish(h, s, x, d_coef));
     BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,
@@ -377,10 +295,12 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     BBX_HIP(hipStreamSynchronize(h->stream));
   }
   const int n_iter = host_st->n_iter;
+  h->timer.cur_tag = -1;
+  timer_drop_skipped(h, n_iter);
   // Operator applications enqueued past the stopping iteration exited at entry
   // (their kernels see `done`): they are not matvecs and do not count
   // (abstract_matrix.py:61-72 counts products that ran).
-  if (k > n_iter && can_skip) {
+  if (k > n_iter) {
     h->n_dot -= (k - n_iter);
     h->n_tdot -= (k - n_iter);
   }

@@ -524,15 +524,9 @@ __global__ __launch_bounds__(256) void dev_gamma_kernel(
 // methods are exact samplers of the same law, so the switch point is a pure
 // cost choice.  Measured on MI355X, 50 000 draws at one tilt (ts_regimes.py):
 // plain rejection 33 / 45 / 71 us at tilt^a = .1 / 1 / 1.9, double rejection
-// 290-380 us at 2.1-4 and 130 / 110 us at 16 / 100.  BBX_TS_THRESHOLD overrides.
-static double ts_cost_threshold() {
-  static const double v = [] {
-    // (a negative value selects the in-place inner loop of dr_trial: A/B only)
-    const char* e = getenv("BBX_TS_THRESHOLD");
-    return e ? atof(e) : TiltedStable::kCostThreshold;
-  }();
-  return v;
-}
+// 290-380 us at 2.1-4 and 130 / 110 us at 16 / 100.
+// (a negative value selects the in-place inner loop of dr_trial)
+static double ts_cost_threshold() { return TiltedStable::kCostThreshold; }
 
 static inline uint64_t iter_stream(uint64_t stream, int64_t iter) {
   return stream | ((uint64_t)iter << 8);
@@ -653,12 +647,7 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
     // Measured at p = 50k (ms per Gibbs iteration, items per block): 256:
     // 5.69, 128: 5.63, 64: 5.72, 32: 5.83, 16: 6.11 -- the speculative copies
     // of small blocks cost more arithmetic than the extra blocks hide latency.
-    const int items_default = (n_shrunk / TS_BLOCK < 1024) ? 128 : TS_BLOCK;
-    int items = items_default;
-    static const char* items_env = getenv("BBX_TS_ITEMS");
-    if (items_env) items = atoi(items_env);
-    if (items < 1) items = 1;
-    if (items > TS_BLOCK) items = TS_BLOCK;
+    const int items = (n_shrunk / TS_BLOCK < 1024) ? 128 : TS_BLOCK;
     int64_t nb = (n_shrunk + items - 1) / items;
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(chain_lscale_kernel, dim3((unsigned)nb), dim3(TS_BLOCK),
@@ -684,11 +673,13 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
                      c->model, 0, n, c->seed,
                      iter_stream(STREAM_OBSVAR, c->iter), rp, rg, sc);
 
-  BBX_HIP(hipGetLastError());
+  // the second branch is joined on every path, a failed launch included
+  const hipError_t launch_err = hipGetLastError();
   if (fork) {
     BBX_HIP(hipEventRecord(c->ev_join, c->stream2));
     BBX_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
   }
+  BBX_HIP(launch_err);
   c->iter += 1;
   return info;
 }

@@ -137,12 +137,16 @@ struct KernelTimer {
   bool armed[FAMILIES] = {false, false, false};
   struct Pair {
     hipEvent_t a, b;
+    int tag;  // CG iteration the launch belongs to, -1 outside a CG loop
   };
   std::vector<Pair> pending[FAMILIES];
   std::vector<Pair> pool;
-  // every resolved sample; the totals reported leave out launches that exited
-  // at entry because their CG solve had already stopped (see skip_flag): they
-  // take a few microseconds and are not executions of the kernel
+  // Launches enqueued past the stopping iteration exit at entry (skip_flag):
+  // they take a few microseconds and are not executions of the kernel.  The
+  // CG loop tags every sampled launch with its iteration (cur_tag) and, once
+  // the solve's iteration count is known, discards the samples tagged beyond
+  // it (timer_drop_skipped) -- no statistical filter.
+  int cur_tag = -1;
   std::vector<float> samples[FAMILIES];
 };
 
@@ -190,8 +194,6 @@ struct bbx_design {
   bbx::DevMem w_P[10];    // P-length CG vectors
   bbx::DevMem part;       // NPART-length partial-sum slots (several)
   bbx::DevMem cg_state;   // CGState
-  bbx::DevMem cg_gran;    // 2 x 512 exchange granules + timeout word (fused CG)
-  unsigned cg_epoch = 0;  // last epoch used by the fused CG kernel
   bbx::DevMem stage_n, stage_P;  // staging for the host-pointer entry points
   void* host_pinned = nullptr;   // small pinned buffer for flag read-back
 
@@ -238,7 +240,6 @@ int launch_dot(bbx_design* h, const double* d_v, const double* d_rowscale,
 enum TdotMode {
   TD_PLAIN = 0,  // out = g
   TD_OPER = 1,   // out = d .* x + s .* g            (cg_sampler.py:107-108)
-  TD_RHS = 2,    // out = s .* (z + g + phi .* eta2) (cg_sampler.py:66-68)
   // q = d .* p + s .* g as TD_OPER, then the CG update in the same pass:
   //   alpha = rho / p.Ap ; x += alpha p ; r -= alpha q ; partials of r.r
   // with p.Ap = <p, d p> + <t, Omega t> taken from two partial-sum slots (q is
@@ -260,7 +261,7 @@ struct TdotEpilogue {
   const double* z = nullptr;
   const double* phi = nullptr;
   const double* eta2 = nullptr;
-  double* dot_part = nullptr;  // TD_OPER: partials of x.out ; TD_RHS: of out.out
+  double* dot_part = nullptr;  // TD_OPER: partials of x.out
                                // TD_OPER_UPD: partials of the new r.r
   // TD_OPER_UPD only (x above is the search direction p):
   double* cg_x = nullptr;      // iterate, updated in place
@@ -270,23 +271,6 @@ struct TdotEpilogue {
   const double* pdp_part = nullptr;
   const double* twt_part = nullptr;
 };
-// Where the raw main product X_main^T w of the last Tdot launch can be read
-// from (per orientation/format), for epilogues that run in a later kernel.
-struct TdotSource {
-  const double* gfull = nullptr;        // n_slab slabs of `stride` doubles, or
-  int n_slab = 0;
-  int64_t stride = 0;
-  const int32_t* row_chunk_ptr = nullptr;  // CSR layout: chunk partials per row
-  const double* partial = nullptr;
-  const double* offset = nullptr;       // centring (p_eff entries)
-  const double* sumw_part = nullptr;    // NPART partials of sum(w)
-  int64_t p_eff = 0;                    // columns of the main block
-  int intercept = 0;                    // 1: entry 0 of the result is sum(w)
-};
-// Runs only the main kernel of a Tdot (no epilogue) and says where g lives.
-int launch_tdot_main(bbx_design* h, const double* d_w,
-                     const double* d_sumw_part, TdotSource* src);
-
 // out[P] = epilogue([sum w ; X_main^T w - sum(w) offset]).  `sumw_part` holds
 // the NPART partials of sum(w).
 int launch_tdot(bbx_design* h, const double* d_w, const double* d_sumw_part,
@@ -349,8 +333,15 @@ int timer_end(bbx_design* h, int which);
 // rocprofv3 reports) instead of bracketing the dispatch with two record
 // commands (~3 us more per launch).
 int timer_arm(bbx_design* h, int which, hipEvent_t* a, hipEvent_t* b);
+// Discards the pending samples of launches tagged with an iteration >= n_iter
+// (they found the stop flag set and returned at entry).  The stream is idle.
+void timer_drop_skipped(bbx_design* h, int n_iter);
 
 // ---- CG sampler (cg_sampler.hip) -------------------------------------------
+// POSTCONDITION every caller may rely on (chain_step's second stream does: it
+// starts reading d_coef without an event): on return -- success, not converged
+// or error after the first launch -- h->stream is idle (the solve ends with
+// hipStreamSynchronize on every path) and d_coef is final.
 int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
                      const double* d_z, const double* d_x0,
                      const double* d_sd, int n_unshrunk, const double* d_eta1,

@@ -547,11 +547,9 @@ static size_t fused_ring_lds(int KQ, int RB, int D, int64_t rows_per_wg) {
 
 // Does the single-pass operator kernel apply to this design?
 bool dense_fused_applies(const bbx_design* h) {
-  static const bool off =
-      getenv("BBX_DENSE_FUSED") && atoi(getenv("BBX_DENSE_FUSED")) == 0;
   // f64 storage: 8 registers per column group and row, one group per thread
   const int64_t ld_max = h->dense_dtype == BBX_F32 ? 8192 : 4096;
-  return !(off || h->sparse || h->dense_ld > ld_max || h->n < 4096);
+  return !(h->sparse || h->dense_ld > ld_max || h->n < 4096);
 }
 
 int launch_operator_dense_fused(bbx_design* h, const double* d_v,
@@ -585,13 +583,10 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
 #define BBX_RING_LAUNCH(KQ, RB, D)                                             \
   do {                                                                         \
     const size_t lb = fused_ring_lds(KQ, RB, D, rows_per_wg);                  \
-    static bool attr_set = false;                                              \
-    if (!attr_set) {                                                           \
-      BBX_HIP(hipFuncSetAttribute(                                             \
-          reinterpret_cast<const void*>(&dense_fused_ring_kernel<KQ, RB, D>),  \
-          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));            \
-      attr_set = true;                                                         \
-    }                                                                          \
+    /* per device, cheap next to a 1 ms kernel: set on every launch */        \
+    BBX_HIP(hipFuncSetAttribute(                                               \
+        reinterpret_cast<const void*>(&dense_fused_ring_kernel<KQ, RB, D>),    \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
     hipLaunchKernelGGL((dense_fused_ring_kernel<KQ, RB, D>), dim3(wgs),        \
                        dim3(1024), lb, h->stream, h->n, h->P, h->dense_ld,     \
                        rows_per_wg, h->dense.as<float>(), d_v, d_rowscale,     \
@@ -698,18 +693,6 @@ int launch_tdot_dense(bbx_design* h, const double* d_w,
   // The intercept column and the centring live in the matrix itself, so the
   // common epilogue runs with intercept = 0, offset = 0, sum(w) unused.
   return launch_tdot_finalize_dense(h, ep, d_out);
-}
-
-int launch_tdot_main_dense(bbx_design* h, const double* d_w, TdotSource* src) {
-  BBX_TRY(launch_tdot_slabs_dense(h, d_w));
-  src->gfull = h->dense_slab.as<double>();
-  src->n_slab = h->dense_chunks;
-  src->stride = h->dense_ld;
-  src->offset = h->offset.as<double>();   // zeros (length P)
-  src->sumw_part = part_slot(h, PS_ZERO);
-  src->p_eff = h->P;
-  src->intercept = 0;
-  return BBX_OK;
 }
 
 static int create_dense_common(int64_t n, int64_t p, const void* X,

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
       e1 = d[jj0];
       e2 = s[jj0];
       if (mode == TD_OPER_UPD) e3 = cg_r[jj0];
-    } else if (mode == TD_RHS || mode == TD_RESID) {
+    } else if (mode == TD_RESID) {
       e0 = z[jj0];
       e1 = phi[jj0];
       e2 = eta2[jj0];
@@ -255,11 +255,6 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
       cg_r[jj] = r;
       dacc += r * r;
       continue;
-    } else if (mode == TD_RHS) {
-      r = (first ? e3 : s[jj]) *
-          ((first ? e0 : z[jj]) +
-           (g + (first ? e1 : phi[jj]) * (first ? e2 : eta2[jj])));
-      dacc += r * r;
     } else if (mode == TD_RESID) {
       r = (first ? e3 : s[jj]) *
           ((first ? e0 : z[jj]) +
@@ -331,7 +326,6 @@ int launch_dot_csr(bbx_design* h, const double* d_v, const double* d_rowscale,
   switch (ep.mode) {                                                           \
     case TD_PLAIN: LAUNCH(TD_PLAIN); break;                                    \
     case TD_OPER: LAUNCH(TD_OPER); break;                                      \
-    case TD_RHS: LAUNCH(TD_RHS); break;                                        \
     case TD_OPER_UPD: LAUNCH(TD_OPER_UPD); break;                              \
     case TD_RESID: LAUNCH(TD_RESID); break;                                    \
     default: return fail(BBX_ERR_INVALID, "unknown Tdot epilogue mode");       \
@@ -405,16 +399,6 @@ int launch_tdot_csr(bbx_design* h, const double* d_w,
                     double* d_out) {
   BBX_TRY(launch_tdot_chunks_csr(h, d_w));
   return launch_tdot_finalize(h, nullptr, 0, d_sumw_part, ep, d_out);
-}
-
-int launch_tdot_main_csr(bbx_design* h, const double* d_w, TdotSource* src) {
-  BBX_TRY(launch_tdot_chunks_csr(h, d_w));
-  src->row_chunk_ptr = h->t_row_chunk_ptr.as<int32_t>();
-  src->partial = h->t_partial.as<double>();
-  src->offset = h->offset.as<double>();
-  src->p_eff = h->p;
-  src->intercept = h->intercept;
-  return BBX_OK;
 }
 
 // ------------------------------------------------------ transpose at set-up

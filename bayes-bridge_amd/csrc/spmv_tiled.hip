@@ -72,7 +72,6 @@ struct TiledMatrix {
   int64_t R = 0, C = 0, nnz = 0;
   int W = 0, n_block = 0, PR = 0, n_panel = 0, G = 0;
   bool has_vals = false;
-  bool packed = false;  // value-free ids as 14-bit base + 4 x 12-bit deltas
   int64_t n_slice = 0, n_quad = 0, n_tile = 0;
   DevMem ids;        // uint4[n_quad * 64]
   DevMem vals;       // double[n_quad * 64 * 8] when has_vals
@@ -120,27 +119,6 @@ __device__ __forceinline__ void step_accumulate(const double* __restrict__ xs,
     b0 += xs[e.z & 0xFFFFu] + xs[e.w & 0xFFFFu];
     b1 += xs[e.z >> 16] + xs[e.w >> 16];
   }
-}
-
-// Packed value-free step: per row one 64-bit group = 14-bit block-local id of
-// the first entry + four 12-bit forward deltas (5 entries in 8 bytes instead
-// of 4).  A zero delta marks "no further entry" (ids ascend strictly inside a
-// group; the builder starts a new group at a duplicate or at a gap > 4095), and
-// an empty group has base id W, where LDS holds 0.0.
-__device__ __forceinline__ void packed_row(const double* __restrict__ xs,
-                                           unsigned lo, unsigned hi,
-                                           unsigned zero_slot, double& s0,
-                                           double& s1) {
-  const unsigned long long g = (unsigned long long)lo |
-                               ((unsigned long long)hi << 32);
-  const unsigned i0 = lo & 0x3FFFu;
-  const unsigned d1 = (lo >> 14) & 0xFFFu;
-  const unsigned d2 = (unsigned)(g >> 26) & 0xFFFu;
-  const unsigned d3 = (hi >> 6) & 0xFFFu;
-  const unsigned d4 = (hi >> 18) & 0xFFFu;
-  const unsigned i1 = i0 + d1, i2 = i1 + d2, i3 = i2 + d3, i4 = i3 + d4;
-  s0 += xs[i0] + xs[d2 ? i2 : zero_slot] + xs[d4 ? i4 : zero_slot];
-  s1 += xs[d1 ? i1 : zero_slot] + xs[d3 ? i3 : zero_slot];
 }
 
 // The id/value/row-id stream loads are issued through inline asm so that
@@ -191,7 +169,7 @@ __device__ __forceinline__ void asm_load_u32(unsigned& dst, unsigned off,
 
 constexpr int FILL_UNROLL = (TILE_W_MAX + TILE_THREADS - 1) / TILE_THREADS;
 
-template <bool VALS, bool PACK, bool WIDE>
+template <bool VALS, bool WIDE>
 __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_kernel(
     int64_t R, int64_t C, int W, int PR, int G, int blocks_per_group,
     const int32_t* __restrict__ wave_desc, int desc_stride,
@@ -417,10 +395,7 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
               if (u < cntk) {
                 if (ablate & 1)
                   a0 += (double)(e[k][u].x ^ e[k][u].y ^ e[k][u].z ^ e[k][u].w);
-                else if (PACK) {
-                  packed_row(xs, e[k][u].x, e[k][u].y, (unsigned)W, a0, a1);
-                  packed_row(xs, e[k][u].z, e[k][u].w, (unsigned)W, b0, b1);
-                } else
+                else
                   step_accumulate<VALS>(xs, e[k][u], ev[k][u], a0, a1, b0, b1);
               }
             if (inf & BD_LAST) {
@@ -603,7 +578,6 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
   m.n_panel = host.n_panel;
   m.G = host.G;
   m.has_vals = host.has_vals;
-  m.packed = host.packed;
   m.n_slice = host.n_slice;
   m.n_quad = host.n_quad;
   m.n_tile = host.n_tile;
@@ -674,24 +648,20 @@ int build_tiled(bbx_design* h) {
     if (lb > (size_t)TILE_LDS_BYTES)
       return fail(BBX_ERR_INVALID, "tile does not fit in LDS");
   }
-#define BBX_TILED_ATTR(VV, PP, WW)                                             \
+#define BBX_TILED_ATTR(VV, WW)                                                 \
   BBX_HIP(hipFuncSetAttribute(                                                 \
-      reinterpret_cast<const void*>(&tiled_spmv_kernel<VV, PP, WW>),           \
+      reinterpret_cast<const void*>(&tiled_spmv_kernel<VV, WW>),               \
       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-  BBX_TILED_ATTR(false, false, false);
-  BBX_TILED_ATTR(false, false, true);
-  BBX_TILED_ATTR(false, true, false);
-  BBX_TILED_ATTR(false, true, true);
-  BBX_TILED_ATTR(true, false, false);
-  BBX_TILED_ATTR(true, false, true);
+  BBX_TILED_ATTR(false, false);
+  BBX_TILED_ATTR(false, true);
+  BBX_TILED_ATTR(true, false);
+  BBX_TILED_ATTR(true, true);
 #undef BBX_TILED_ATTR
   // The reference-layout arrays are only needed to build; free the big ones.
-  if (!getenv("BBX_KEEP_CSR")) {
-    h->indices.release();
-    h->data.release();
-    h->t_indices.release();
-    h->t_data.release();
-  }
+  h->indices.release();
+  h->data.release();
+  h->t_indices.release();
+  h->t_data.release();
   return BBX_OK;
 }
 
@@ -702,15 +672,21 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                         hipEvent_t ev_end = nullptr, int twt_off = 0) {
   const unsigned grid = (unsigned)(m.n_panel * m.G);
   const size_t lb = lds_bytes(m);
+  // Instrumented builds only (-DBBX_TILED_INSTRUMENT=1; the product library
+  // reads neither variable): BBX_ABLATE=bits removes the gathers / slice loads /
+  // switch barriers (timing only, wrong results), BBX_TILED_DEBUG=N prints the
+  // per-wave phase timing of launches N and N+1.
+#if BBX_TILED_INSTRUMENT
   static const int ablate = getenv("BBX_ABLATE") ? atoi(getenv("BBX_ABLATE")) : 0;
-  // BBX_TILED_DEBUG=N: per-wave phase timing of launches N and N+1 (stderr)
   static const int dbg_at =
       getenv("BBX_TILED_DEBUG") ? atoi(getenv("BBX_TILED_DEBUG")) : -1;
+#else
+  constexpr int ablate = 0;
+  constexpr int dbg_at = -1;
+#endif
   static int dbg_count = 0;
   static unsigned long long* dbg_buf = nullptr;
   unsigned long long* dbg = nullptr;
-  if (dbg_at >= 0 && !BBX_TILED_INSTRUMENT)
-    fprintf(stderr, "[bbx] BBX_TILED_DEBUG needs a -DBBX_TILED_INSTRUMENT=1 build\n");
   if (dbg_at >= 0 && BBX_TILED_INSTRUMENT) {
     if (!dbg_buf)
       BBX_HIP(hipMalloc(&dbg_buf, sizeof(unsigned long long) * 4096 * TILE_WAVES * 4));
@@ -718,8 +694,8 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
       dbg = dbg_buf;
     ++dbg_count;
   }
-#define BBX_TILED_LAUNCH_W(VV, PP, WW, VALPTR)                                 \
-  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, PP, WW>), dim3(grid),           \
+#define BBX_TILED_LAUNCH_W(VV, WW, VALPTR)                                     \
+  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, WW>), dim3(grid),               \
                      dim3(TILE_THREADS), (unsigned)lb, h->stream, ev_begin,    \
                      ev_end, 0u, m.R, m.C, m.W, m.PR,                          \
                      m.G, (m.n_block + m.G - 1) / m.G,                         \
@@ -729,24 +705,20 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                      out, slab, m.PR + m.n_extra,                              \
                      m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),       \
                      out_sum_part, twt_off, ablate, dbg, h->skip_flag)
-#define BBX_TILED_LAUNCH(VV, PP, VALPTR)                                       \
+#define BBX_TILED_LAUNCH(VV, VALPTR)                                           \
   do {                                                                         \
-    if (wide) BBX_TILED_LAUNCH_W(VV, PP, true, VALPTR);                        \
-    else BBX_TILED_LAUNCH_W(VV, PP, false, VALPTR);                            \
+    if (wide) BBX_TILED_LAUNCH_W(VV, true, VALPTR);                            \
+    else BBX_TILED_LAUNCH_W(VV, false, VALPTR);                                \
   } while (0)
   // 16-byte slice loads need every slice start 16-byte aligned: W is a multiple
   // of 64 doubles, so it is the alignment of x itself that decides (inside the
   // CG loop x is an internal buffer placed accordingly; a caller's v + 1 of a
   // design with intercept is not, and takes the 8-byte path)
-  static const bool no_wide =
-      getenv("BBX_TILED_NARROW_FILL") && atoi(getenv("BBX_TILED_NARROW_FILL")) == 1;
-  const bool wide = !no_wide && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+  const bool wide = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
   if (m.has_vals)
-    BBX_TILED_LAUNCH(true, false, m.vals.as<double>());
-  else if (m.packed)
-    BBX_TILED_LAUNCH(false, true, nullptr);
+    BBX_TILED_LAUNCH(true, m.vals.as<double>());
   else
-    BBX_TILED_LAUNCH(false, false, nullptr);
+    BBX_TILED_LAUNCH(false, nullptr);
 #undef BBX_TILED_LAUNCH
 #undef BBX_TILED_LAUNCH_W
   BBX_HIP(hipGetLastError());
@@ -825,23 +797,6 @@ int launch_tdot_tiled(bbx_design* h, const double* d_w,
   // the epilogue kernel adds the G partial slabs in group order
   return launch_tdot_finalize(h, m.slab.as<double>(), m.G, d_sumw_part, ep,
                               d_out);
-}
-
-int launch_tdot_main_tiled(bbx_design* h, const double* d_w,
-                           TdotSource* src) {
-  TiledPair* tp = static_cast<TiledPair*>(h->tiled);
-  const TiledMatrix& m = tp->xt;
-  hipEvent_t ea, eb;
-  BBX_TRY(timer_arm(h, 1, &ea, &eb));
-  BBX_TRY(launch_tiled(h, m, d_w, nullptr, nullptr, nullptr, nullptr,
-                       m.slab.as<double>(), nullptr, ea, eb));
-  src->gfull = m.slab.as<double>();
-  src->n_slab = m.G;
-  src->stride = h->p;
-  src->offset = h->offset.as<double>();
-  src->p_eff = h->p;
-  src->intercept = h->intercept;
-  return BBX_OK;
 }
 
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,

@@ -20,15 +20,9 @@ TiledOptions TiledOptions::from_env(bool transpose) {
     if (!e) e = getenv(name);
     if (e) *dst = atoi(e);
   };
-  if (const char* e = getenv("BBX_TILED_PACK")) o.packed = atoi(e) == 1;
   geti("BBX_TILED_PR", &o.force_PR);
   geti("BBX_TILED_G", &o.force_G);
-  geti("BBX_TILED_BLOCKS", &o.force_blocks);
-  if (const char* e = getenv("BBX_TILED_EXTRA")) o.extra_budget = atoi(e);
-  if (const char* e = getenv("BBX_TILED_TFACTOR")) o.t_factor = atof(e);
-  if (const char* e = getenv("BBX_TILED_BANKS")) o.bank_aware = atoi(e) != 0;
   if (getenv("BBX_TILED_STATS")) o.stats = true;
-  if (const char* e = getenv("BBX_TILED_THREADS")) o.max_threads = atoi(e);
   return o;
 }
 
@@ -180,32 +174,8 @@ struct VRow {
   int32_t begin;  // first entry (index into colidx)
   int32_t len;
   uint16_t slot;  // accumulator slot in LDS (row, or extra slot of a chunk)
-  int32_t g_begin = 0;  // packed layout: first group in the tile's group list
   int32_t steps = 0;    // steps this row needs (sort key)
 };
-
-// Groups of one (chunk of a) row in the packed layout; see packed_row().
-static int pack_groups(const int32_t* colidx, int32_t begin, int32_t len,
-                       int64_t col0, std::vector<uint64_t>& out) {
-  int n = 0;
-  int32_t i = 0;
-  while (i < len) {
-    int64_t prev = colidx[begin + i] - col0;
-    uint64_t g = (uint64_t)prev;
-    int k = 1;
-    while (k < 5 && i + k < len) {
-      const int64_t d = (colidx[begin + i + k] - col0) - prev;
-      if (d <= 0 || d > 4095) break;  // duplicate or long gap: new group
-      g |= (uint64_t)d << (14 + 12 * (k - 1));
-      prev += d;
-      ++k;
-    }
-    out.push_back(g);
-    i += k;
-    ++n;
-  }
-  return n;
-}
 
 // Bank-aware entry order of one 32-lane half of a slice.
 //
@@ -350,7 +320,7 @@ static void bank_aware_order(const HalfRow* rows, int n_rows, int64_t col0,
 static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
                         const int32_t* colidx, const double* vals, int W,
                         int n_block, int PR, int G, int extra_budget,
-                        int panel, bool packed, const TiledOptions& opt,
+                        int panel, const TiledOptions& opt,
                         PanelBuild& pb) {
   const int64_t row0 = (int64_t)panel * PR;
   const int rows_here = (int)std::min<int64_t>(PR, R - row0);
@@ -463,7 +433,6 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
   const int blocks_per_group = (n_block + G - 1) / G;
   std::vector<VRow> vrows, sorted;
   std::vector<int> bucket;
-  std::vector<uint64_t> groups;  // packed layout: groups of the tile's rows
   std::vector<std::vector<int32_t>> slice_perm;  // bank-aware entry order
   BankScratch bank_scratch;
   std::vector<uint8_t> hot;        // per tile: column recurs within 32 rows
@@ -498,7 +467,7 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
         max_len = std::max(max_len, len);
       }
     }
-    if (opt.bank_aware && !packed) {
+    if (opt.bank_aware) {
       // columns present in >= 1/16 of the tile's rows: likely to appear twice
       // among the 32 rows a gather instruction serves
       col_rows.assign((size_t)W + 1, 0);
@@ -511,16 +480,10 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
       const size_t thresh = std::max<size_t>(2, vrows.size() / 256);
       for (int j = 0; j <= W; ++j) hot[(size_t)j] = col_rows[(size_t)j] >= thresh;
     }
-    // sort key: steps the row needs (4 entries per step, or its packed groups)
-    groups.clear();
+    // sort key: steps the row needs (4 entries per step)
     int max_key = 0;
     for (VRow& v : vrows) {
-      if (packed) {
-        v.g_begin = (int32_t)groups.size();
-        v.steps = pack_groups(colidx, v.begin, v.len, col0, groups);
-      } else {
-        v.steps = (v.len + 3) / 4;
-      }
+      v.steps = (v.len + 3) / 4;
       max_key = std::max(max_key, v.steps);
     }
     // by decreasing step count (counting sort, stable)
@@ -546,7 +509,7 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
       if (vals) pb.vals.resize((id0 + (size_t)nq * LANES) * 8, 0.);
       // entry order inside the rows (see bank_aware_order): one problem per
       // (row A | row B) x (lanes 0-31 | lanes 32-63)
-      const bool reorder = opt.bank_aware && !packed;
+      const bool reorder = opt.bank_aware;
       if (reorder) {
         slice_perm.resize(SLICE_ROWS);
         for (int side = 0; side < 2; ++side)
@@ -572,21 +535,7 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
         if (LANES + l < rows_in) vr[1] = &sorted[base + LANES + l];
         pb.rowids.push_back((uint32_t)(vr[0] ? vr[0]->slot : NO_ROW) |
                             ((uint32_t)(vr[1] ? vr[1]->slot : NO_ROW) << 16));
-        for (uint32_t q = 0; q < nq && packed; ++q) {
-          Ids4 pk;
-          uint64_t gg[2];
-          for (int half = 0; half < 2; ++half) {
-            const VRow* v = vr[half];
-            gg[half] = (v && (int)q < v->steps) ? groups[(size_t)v->g_begin + q]
-                                                : (uint64_t)W;  // xs[W] == 0
-          }
-          pk.x = (uint32_t)gg[0];
-          pk.y = (uint32_t)(gg[0] >> 32);
-          pk.z = (uint32_t)gg[1];
-          pk.w = (uint32_t)(gg[1] >> 32);
-          pb.ids[id0 + (size_t)q * LANES + l] = pk;
-        }
-        for (uint32_t q = 0; q < nq && !packed; ++q) {
+        for (uint32_t q = 0; q < nq; ++q) {
           uint16_t e[8];
           for (int half = 0; half < 2; ++half) {
             const VRow* v = vr[half];
@@ -605,12 +554,12 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
               }
             }
           }
-          Ids4 packed;
-          packed.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
-          packed.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
-          packed.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
-          packed.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
-          pb.ids[id0 + (size_t)q * LANES + l] = packed;
+          Ids4 step;
+          step.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+          step.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+          step.z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
+          step.w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
+          pb.ids[id0 + (size_t)q * LANES + l] = step;
         }
       }
     }
@@ -674,11 +623,6 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   m.C = C;
   m.nnz = nnz;
   m.has_vals = vals != nullptr;
-  // Packed ids are opt-in (BBX_TILED_PACK=1).  Measured at 1M x 50k: 18.5 %
-  // fewer id bytes (233 -> 193 MB per product) but only 3-5 % less time: the
-  // per-entry work (LDS gather, index arithmetic) does not shrink with the
-  // bytes, so the achieved HBM rate DROPS.  Kept for footprint-bound uses.
-  m.packed = !m.has_vals && opt.packed;
   m.n_block = (int)((C + TILE_W_MAX - 1) / TILE_W_MAX);
   if (opt.force_blocks > m.n_block) m.n_block = opt.force_blocks;
   if (m.n_block < 1) m.n_block = 1;
@@ -719,7 +663,7 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
       try {
         for (int p = (int)t; p < m.n_panel; p += (int)n_thr)
           build_panel(R, C, rowptr, colidx, vals, m.W, m.n_block, m.PR, m.G,
-                      extra_budget, p, m.packed, opt, pbs[(size_t)p]);
+                      extra_budget, p, opt, pbs[(size_t)p]);
       } catch (...) {
         thread_status[t] = -1;
       }
@@ -880,7 +824,7 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
 namespace {
 
 // The two accumulations of one lane and step, exactly as the kernel writes
-// them (step_accumulate / packed_row in spmv_tiled.hip).
+// them (step_accumulate in spmv_tiled.hip).
 inline void emu_step(const TiledHost& m, const double* xs, const Ids4& e,
                      const double* v, double& a0, double& a1, double& b0,
                      double& b1) {
@@ -889,21 +833,6 @@ inline void emu_step(const TiledHost& m, const double* xs, const Ids4& e,
     a1 += v[1] * xs[e.x >> 16] + v[3] * xs[e.y >> 16];
     b0 += v[4] * xs[e.z & 0xFFFFu] + v[6] * xs[e.w & 0xFFFFu];
     b1 += v[5] * xs[e.z >> 16] + v[7] * xs[e.w >> 16];
-  } else if (m.packed) {
-    auto row = [&](uint32_t lo, uint32_t hi, double& s0, double& s1) {
-      const uint64_t g = (uint64_t)lo | ((uint64_t)hi << 32);
-      const unsigned zero_slot = (unsigned)m.W;
-      const unsigned i0 = lo & 0x3FFFu;
-      const unsigned d1 = (lo >> 14) & 0xFFFu;
-      const unsigned d2 = (unsigned)(g >> 26) & 0xFFFu;
-      const unsigned d3 = (hi >> 6) & 0xFFFu;
-      const unsigned d4 = (hi >> 18) & 0xFFFu;
-      const unsigned i1 = i0 + d1, i2 = i1 + d2, i3 = i2 + d3, i4 = i3 + d4;
-      s0 += xs[i0] + xs[d2 ? i2 : zero_slot] + xs[d4 ? i4 : zero_slot];
-      s1 += xs[d1 ? i1 : zero_slot] + xs[d3 ? i3 : zero_slot];
-    };
-    row(e.x, e.y, a0, a1);
-    row(e.z, e.w, b0, b1);
   } else {
     a0 += xs[e.x & 0xFFFFu] + xs[e.y & 0xFFFFu];
     a1 += xs[e.x >> 16] + xs[e.y >> 16];
@@ -1000,7 +929,7 @@ void emulate_tiled_spmv(const TiledHost& m, const double* x,
 }
 
 double tiled_mean_gather_cycles(const TiledHost& m) {
-  if (m.packed || m.n_quad == 0) return 0.;
+  if (m.n_quad == 0) return 0.;
   double cycles = 0., groups = 0.;
   for (int64_t q = 0; q < m.n_quad; ++q) {
     for (int pos = 0; pos < 8; ++pos)
@@ -1042,12 +971,11 @@ extern "C" {
 // info[0..7] = W, n_block, PR, G, n_quad, n_slice, n_extra, split_T;
 // gather_cycles = mean LDS cycles per ds_read_b64 half-wave group (or NULL).
 int bbx_layout_emulate(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
-                       const int32_t* colidx, const double* vals, int packed,
+                       const int32_t* colidx, const double* vals,
                        int bank_aware, int force_PR, int force_G,
                        int max_threads, const double* x, double* out,
                        int64_t* info, double* gather_cycles) {
   bbx::TiledOptions opt;
-  opt.packed = packed != 0;
   opt.bank_aware = bank_aware != 0;
   opt.force_PR = force_PR;
   opt.force_G = force_G;

@@ -77,16 +77,15 @@ struct FoldDesc {
 
 // Build-time choices that the environment can override (diagnostics, A/B).
 struct TiledOptions {
-  bool packed = false;       // BBX_TILED_PACK=1: 14-bit base + 4 x 12-bit deltas
   int force_PR = 0;          // BBX_TILED_PR
   int force_G = 0;           // BBX_TILED_G
-  int force_blocks = 0;      // BBX_TILED_BLOCKS: number of column blocks
-  int extra_budget = -1;     // BBX_TILED_EXTRA (< 0: what LDS leaves)
-  double t_factor = 0.;      // BBX_TILED_TFACTOR (0: automatic)
-  bool bank_aware = true;    // BBX_TILED_BANKS=0 switches the entry ordering off
+  int force_blocks = 0;      // number of column blocks (0: automatic)
+  int extra_budget = -1;     // extra accumulators per panel (< 0: what LDS leaves)
+  double t_factor = 0.;      // split threshold / mean segment (0: automatic)
+  bool bank_aware = true;    // bank-aware entry order inside the rows
   bool stats = false;        // BBX_TILED_STATS=1
   int max_threads = 64;
-  // transpose: the X^T orientation reads BBX_TILED_PR_T / _G_T / _BLOCKS_T first
+  // transpose: the X^T orientation reads BBX_TILED_PR_T / BBX_TILED_G_T first
   static TiledOptions from_env(bool transpose = false);
 };
 
@@ -95,7 +94,6 @@ struct TiledHost {
   int64_t R = 0, C = 0, nnz = 0;
   int W = 0, n_block = 0, PR = 0, n_panel = 0, G = 0;
   bool has_vals = false;
-  bool packed = false;
   int64_t n_slice = 0, n_quad = 0, n_tile = 0, n_desc = 0;
   int desc_stride = 0;  // > 0: wave k's schedule starts at k * desc_stride
   int n_extra = 0;      // extra accumulators per panel (row splitting)

@@ -1,7 +1,7 @@
 // Self-test of the tiled layout builder + emulator for the sanitizer builds
 // (make sanitize: -fsanitize=address,undefined and -fsanitize=thread; the
 // builder is multi-threaded over panels).  Generates CSR matrices with an LCG,
-// builds both the plain and the packed layout with several worker threads,
+// builds the layout with several worker threads (value-free and valued),
 // emulates the kernel's walk and compares with a plain CSR product.
 #include <cmath>
 #include <cstdio>
@@ -21,7 +21,7 @@ struct Lcg {
   double unit() { return (next() + 0.5) / 2147483648.0; }
 };
 
-int run_case(int64_t R, int64_t C, double density, bool binary, bool packed,
+int run_case(int64_t R, int64_t C, double density, bool binary,
              int force_PR, int force_G, uint64_t seed) {
   Lcg g{seed};
   std::vector<int32_t> rowptr((size_t)R + 1, 0), colidx;
@@ -50,7 +50,6 @@ int run_case(int64_t R, int64_t C, double density, bool binary, bool packed,
     for (int32_t k = rowptr[(size_t)r]; k < rowptr[(size_t)r + 1]; ++k)
       ref[(size_t)r] += vals[(size_t)k] * x[(size_t)colidx[(size_t)k]];
   bbx::TiledOptions opt;
-  opt.packed = packed;
   opt.force_PR = force_PR;
   opt.force_G = force_G;
   opt.max_threads = 4;
@@ -71,10 +70,10 @@ int run_case(int64_t R, int64_t C, double density, bool binary, bool packed,
     worst = std::fmax(worst, std::fabs(a - ref[(size_t)r]));
   }
   const double cyc = bbx::tiled_mean_gather_cycles(m);
-  printf("R=%lld C=%lld nnz=%lld %s%s PR=%d G=%d W=%d blocks=%d extras=%d: "
+  printf("R=%lld C=%lld nnz=%lld %s PR=%d G=%d W=%d blocks=%d extras=%d: "
          "max err %.2e, %.2f LDS cycles per gather\n",
          (long long)R, (long long)C, (long long)nnz, binary ? "binary" : "valued",
-         packed ? " packed" : "", m.PR, m.G, m.W, m.n_block, m.n_extra, worst, cyc);
+         m.PR, m.G, m.W, m.n_block, m.n_extra, worst, cyc);
   return worst <= 1e-10 ? 0 : 1;
 }
 
@@ -82,13 +81,13 @@ int run_case(int64_t R, int64_t C, double density, bool binary, bool packed,
 
 int main() {
   int bad = 0;
-  bad += run_case(3000, 900, .05, true, false, 0, 0, 1);
-  bad += run_case(3000, 900, .05, false, false, 256, 0, 2);
-  bad += run_case(700, 40000, .002, true, false, 128, 2, 3);
-  bad += run_case(700, 40000, .002, true, true, 128, 3, 4);
-  bad += run_case(5000, 17000, .004, false, false, 512, 2, 5);
-  bad += run_case(17, 3, .6, true, false, 0, 0, 6);
-  bad += run_case(1, 70000, .001, true, false, 0, 0, 7);
+  bad += run_case(3000, 900, .05, true, 0, 0, 1);
+  bad += run_case(3000, 900, .05, false, 256, 0, 2);
+  bad += run_case(700, 40000, .002, true, 128, 2, 3);
+  bad += run_case(700, 40000, .002, true, 128, 3, 4);
+  bad += run_case(5000, 17000, .004, false, 512, 2, 5);
+  bad += run_case(17, 3, .6, true, 0, 0, 6);
+  bad += run_case(1, 70000, .001, true, 0, 0, 7);
   if (bad) fprintf(stderr, "%d case(s) FAILED\n", bad);
   return bad ? 1 : 0;
 }

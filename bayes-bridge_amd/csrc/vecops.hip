@@ -170,20 +170,6 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_setup_kernel(
   }
 }
 
-// r = b - q (q == nullptr: r = b), partials of r.r   (SciPy cg: r = b - A x0)
-__global__ __launch_bounds__(VEC_BLOCK) void cg_init_resid_kernel(
-    int64_t P, const double* __restrict__ b, const double* __restrict__ q,
-    double* __restrict__ r, double* __restrict__ rr_part) {
-  double acc = 0.;
-  for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
-       jj += (int64_t)gridDim.x * VEC_BLOCK) {
-    const double val = q ? b[jj] - q[jj] : b[jj];
-    r[jj] = val;
-    acc += val * val;
-  }
-  block_store_partial(acc, rr_part);
-}
-
 // Top of CG iteration k: stop test, rho, search direction, scaled copy for the
 // operator and the partials of <offset, (s.*p)[1:]>.
 //   if ||r|| < atol: done                      (SciPy _isolve cg loop top)
@@ -295,228 +281,12 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_finish_kernel(
     coef[jj] = s[jj] * x[jj];
 }
 
-// ------------------------------------------------------- fused CG vector step
-//
-// The three P-vector kernels between two operator applications -- the Tdot
-// epilogue (q = d p + s g, p.q), the update (alpha, x, r, r.r) and the next
-// direction (stop test, beta, p, s p, <offset, s p>) -- need two global
-// reductions between them, which is why they were three launches of ~5 us
-// plus their boundaries.  Here they are ONE launch of <= 256 workgroups; the
-// two reductions cross workgroups inside the launch through 8-byte
-// {epoch, 32-bit value} granules written with one relaxed agent-scope store
-// each and swept with relaxed agent-scope loads (cdna_hip_programming.md
-// Guideline 16, form R2: the data is the flag, no fence, no plain-stored shared
-// word).  Each workgroup publishes its partial sum (two granules per double)
-// and every workgroup adds all partials in workgroup order, so all of them see
-// bit-identical alpha / rho / beta.  Epochs increase with every launch (a host
-// counter), separate granule arrays serve the two reductions, spins are
-// bounded and report through a timeout word.
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-#define BBX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-constexpr int FUSED_EMAX = 4;          // elements per thread kept in registers
-constexpr unsigned FUSED_SPIN_LIMIT = 1u << 22;
-
-__device__ inline double tdot_source_g(const TdotSource& S, int64_t jj,
-                                       double sumw) {
-  if (S.intercept && jj == 0) return sumw;
-  const int64_t j = jj - S.intercept;
-  double g = 0.;
-  if (S.gfull) {
-    int k = 0;
-    for (; k + 8 <= S.n_slab; k += 8) {
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = S.gfull[(int64_t)(k + u) * S.stride + j];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) g += v[u];
-    }
-    for (; k < S.n_slab; ++k) g += S.gfull[(int64_t)k * S.stride + j];
-  } else {
-    const int32_t cb = S.row_chunk_ptr[j], ce = S.row_chunk_ptr[j + 1];
-    for (int32_t c = cb; c < ce; ++c) g += S.partial[c];
-  }
-  return g - sumw * S.offset[j];
-}
-
-// Block partial -> granules -> sum of all workgroups' partials (same value and
-// same rounding in every workgroup).  Returns false on timeout.
-__device__ inline bool grid_sum(double local, gu64* gran, unsigned epoch,
-                                unsigned* tmo, double* result) {
-  __shared__ double s_w[VEC_BLOCK / WAVE];
-  __shared__ unsigned s_words[2 * NPART];
-  __shared__ double s_total;
-  __shared__ int s_ok;
-  const int lane = threadIdx.x & (WAVE - 1);
-  double x = wave_sum_v(local);
-  if (lane == 0) s_w[threadIdx.x / WAVE] = x;
-  __syncthreads();
-  const int nb = gridDim.x;
-  if (threadIdx.x < WAVE) {
-    if (threadIdx.x == 0) {
-      double tot = 0.;
-#pragma unroll
-      for (int k = 0; k < VEC_BLOCK / WAVE; ++k) tot += s_w[k];
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(tot);
-      __hip_atomic_store(gran + 2 * blockIdx.x,
-                         ((unsigned long long)epoch << 32) | (bits & 0xFFFFFFFFull),
-                         BBX_RLX_AGENT);
-      __hip_atomic_store(gran + 2 * blockIdx.x + 1,
-                         ((unsigned long long)epoch << 32) | (bits >> 32),
-                         BBX_RLX_AGENT);
-    }
-    // one wave sweeps every workgroup's granules until all carry this epoch
-    const int n_gran = 2 * nb;
-    bool all_ok = false;
-    for (unsigned spins = 0; spins < FUSED_SPIN_LIMIT; ++spins) {
-      bool ok = true;
-#pragma unroll
-      for (int u = 0; u < 2 * NPART / WAVE; ++u) {
-        const int idx = lane + u * WAVE;
-        if (idx < n_gran) {
-          const unsigned long long v = __hip_atomic_load(gran + idx, BBX_RLX_AGENT);
-          s_words[idx] = (unsigned)v;
-          ok = ok && ((unsigned)(v >> 32) == epoch);
-        }
-      }
-      if (__all(ok)) {
-        all_ok = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (lane == 0) {
-      s_ok = all_ok ? 1 : 0;
-      if (!all_ok) atomicExch(tmo, epoch);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && s_ok) {
-    double tot = 0.;
-    for (int b = 0; b < nb; ++b) {
-      const unsigned long long bits =
-          (unsigned long long)s_words[2 * b] |
-          ((unsigned long long)s_words[2 * b + 1] << 32);
-      tot += __longlong_as_double((long long)bits);
-    }
-    s_total = tot;
-  }
-  __syncthreads();
-  *result = s_total;
-  const bool ok = s_ok != 0;
-  __syncthreads();
-  return ok;
-}
-
-// Iteration k: q = A p epilogue, update, and (unless `last`) direction k+1.
-__global__ __launch_bounds__(VEC_BLOCK) void cg_fused_kernel(
-    int64_t P, TdotSource S, int k, int last, CGState* __restrict__ st,
-    const double* __restrict__ s, const double* __restrict__ d,
-    double* __restrict__ pvec, double* __restrict__ x, double* __restrict__ r,
-    double* __restrict__ sp, const double* __restrict__ offset, int intercept,
-    double* __restrict__ c_part, gu64* gran_a, gu64* gran_b, unsigned epoch,
-    unsigned* tmo) {
-  if (st->done) return;
-  const double sumw = sum_partials_v(S.sumw_part);
-  const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
-  const int64_t j0 = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x;
-  double pj[FUSED_EMAX], qj[FUSED_EMAX], rj[FUSED_EMAX];
-  // ---- q = d p + s g ; p.q   (cg_sampler.py:107-108)
-  double acc = 0.;
-#pragma unroll
-  for (int m = 0; m < FUSED_EMAX; ++m) {
-    const int64_t jj = j0 + m * stride;
-    pj[m] = qj[m] = rj[m] = 0.;
-    if (jj < P) {
-      const double g = tdot_source_g(S, jj, sumw);
-      pj[m] = pvec[jj];
-      qj[m] = d[jj] * pj[m] + s[jj] * g;
-      acc += pj[m] * qj[m];
-    }
-  }
-  double pq;
-  if (!grid_sum(acc, gran_a, epoch, tmo, &pq)) return;
-  const double rho = st->rho[k & 1];
-  const double alpha = rho / pq;
-  // ---- x += alpha p ; r -= alpha q ; r.r
-  acc = 0.;
-#pragma unroll
-  for (int m = 0; m < FUSED_EMAX; ++m) {
-    const int64_t jj = j0 + m * stride;
-    if (jj < P) {
-      x[jj] += alpha * pj[m];
-      rj[m] = r[jj] - alpha * qj[m];
-      r[jj] = rj[m];
-      acc += rj[m] * rj[m];
-    }
-  }
-  double rho_new;
-  if (!grid_sum(acc, gran_b, epoch, tmo, &rho_new)) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) st->n_iter = k + 1;
-  if (last) return;
-  // ---- top of iteration k+1: stop test, beta, p, s p, <offset, (s p)[1:]>
-  const bool finite = (rho_new == rho_new) && (rho_new - rho_new == 0.);
-  if (!finite || sqrt(rho_new) < st->atol) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      st->done = 1;
-      if (!finite) st->bad = 1;
-    }
-    return;
-  }
-  const double beta = rho_new / rho;
-  acc = 0.;
-#pragma unroll
-  for (int m = 0; m < FUSED_EMAX; ++m) {
-    const int64_t jj = j0 + m * stride;
-    if (jj < P) {
-      const double pn = rj[m] + beta * pj[m];
-      pvec[jj] = pn;
-      const double v = s[jj] * pn;
-      sp[jj] = v;
-      if (jj >= intercept) acc += offset[jj - intercept] * v;
-    }
-  }
-  block_store_partial(acc, c_part);
-  if (blockIdx.x == 0) {
-    // consumers add NPART slots: clear the ones no workgroup owns
-    for (int b = gridDim.x + threadIdx.x; b < NPART; b += VEC_BLOCK) c_part[b] = 0.;
-    if (threadIdx.x == 0) st->rho[(k + 1) & 1] = rho_new;
-  }
-}
-
-// Returns 1 if the fused step was launched, 0 if P is too large for it.
-int launch_cg_fused(bbx_design* h, const TdotSource& src, int k, int last,
-                    CGState* st, const double* s, const double* d, double* pvec,
-                    double* x, double* r, double* sp, double* c_part) {
-  int64_t nb = (h->P + (int64_t)VEC_BLOCK * FUSED_EMAX - 1) /
-               ((int64_t)VEC_BLOCK * FUSED_EMAX);
-  if (nb > NPART) return 0;
-  if (nb < 1) nb = 1;
-  h->cg_epoch += 1;
-  if (h->cg_epoch == 0) h->cg_epoch = 1;
-  gu64* gran = (gu64*)h->cg_gran.ptr;
-  unsigned* tmo = (unsigned*)((char*)h->cg_gran.ptr + sizeof(uint64_t) * 1024);
-  hipLaunchKernelGGL(cg_fused_kernel, dim3((unsigned)nb), dim3(VEC_BLOCK), 0,
-                     h->stream, h->P, src, k, last, st, s, d, pvec, x, r, sp,
-                     h->offset.as<double>(), h->intercept, c_part, gran,
-                     gran + 512, h->cg_epoch, tmo);
-  BBX_HIP(hipGetLastError());
-  return 1;
-}
-
 int launch_cg_setup(bbx_design* h, int n_unshrunk, const double* phi,
                     const double* sd, const double* x0, double* s, double* d,
                     double* xs, CGState* st, double atol) {
   hipLaunchKernelGGL(cg_setup_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
                      h->stream, h->P, n_unshrunk, phi, sd, x0, s, d, xs, st,
                      atol);
-  BBX_HIP(hipGetLastError());
-  return BBX_OK;
-}
-
-int launch_cg_init_resid(bbx_design* h, const double* b, const double* q,
-                         double* r, double* rr_part) {
-  hipLaunchKernelGGL(cg_init_resid_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
-                     h->stream, h->P, b, q, r, rr_part);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }

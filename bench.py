@@ -191,6 +191,7 @@ def committed_traffic(design, which, cfg):
 
 
 def main():
+    t_proc = time.perf_counter()
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
@@ -215,10 +216,15 @@ def main():
     import torch
     from bayesbridge_amd import (HipDenseDesignMatrix, HipGibbsChain,
                                  HipSparseDesignMatrix, _lib, chains)
-    rank, world, local_rank = chains.init_process_group_from_env()
+    # under a launcher a process group exists even for one rank, so that
+    # `torch.distributed.run --nproc-per-node 1 bench.py` takes the N-rank path
+    # (RCCL initialisation, gather, MAX all-reduce, barrier) on a 1-GPU box
+    rank, world, local_rank = chains.init_process_group_from_env(
+        single_rank_group=env_world is not None)
     n_dev = torch.cuda.device_count()
     backend = None
-    if world > 1:
+    grouped = world > 1 or env_world is not None
+    if grouped:
         import torch.distributed as dist
         backend = dist.get_backend()
         if n_dev >= world:
@@ -228,7 +234,7 @@ def main():
     dev_index = local_rank % max(n_dev, 1)   # == local_rank on a full node
     torch.cuda.set_device(dev_index)
     device = "cuda:%d" % dev_index
-    if world > 1 and n_dev >= world:
+    if grouped and n_dev >= world:
         # every rank really sits on its own device
         ids = [None] * world
         import torch.distributed as dist
@@ -274,6 +280,8 @@ def main():
     chain.set_state(coef0, None, np.ones(P - 1) * unit, .01 / unit)
     chain.init_obs_prec()
 
+    torch.cuda.synchronize()
+    startup_s = time.perf_counter() - t_proc   # import, generate, build layout
     K, W, B = args.steps, args.warmup, args.burnin
     if B is None:
         B = 10 if dense else 300
@@ -294,7 +302,7 @@ def main():
     # ~10% of the iteration; DESIGN.md "Measurement")
     design.set_timing(True, every=16)
     design.reset_timing()
-    if world > 1:
+    if grouped:
         # part of the warm-up: the first gather of a process group sets up the
         # point-to-point connections (RCCL does that lazily, 100s of ms)
         chains.gather_chain_samples(d_coef, dst=0)
@@ -434,6 +442,13 @@ def main():
                 # the timed region's counts (what the solve's look-ahead for
                 # the stop flag has to predict)
                 "n_cg_iter_timed": [int(v) for v in ncg[:64]],
+                # set-up cost per rank (an 8-rank launch runs 8 generators and 8
+                # host-side layout builders side by side): seconds from process
+                # start to a ready chain and this rank's peak host RSS
+                "startup_s": round(startup_s, 1),
+                "peak_host_rss_mb": int(
+                    __import__("resource").getrusage(
+                        __import__("resource").RUSAGE_SELF).ru_maxrss / 1024),
                 "parallelism": "chains=%d" % world,
                 "devices": min(world, n_dev),
                 "backend": backend,
@@ -451,7 +466,7 @@ def main():
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
     chain.close()
-    if world > 1:
+    if grouped:
         import torch.distributed as dist
         dist.destroy_process_group()
 

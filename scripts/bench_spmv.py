@@ -5,7 +5,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "bayes-bridge_amd"))
+# (scripts/ab_spmv.sh points this at a private copy holding a build variant)
+sys.path.insert(0, os.environ.get("BBX_PACKAGE_DIR",
+                                  os.path.join(ROOT, "bayes-bridge_amd")))
 
 import numpy as np
 import torch

@@ -53,3 +53,79 @@ def test_gpus_2_launches_two_ranks_by_itself():
     assert line["config"]["parallelism"] == "chains=2"
     assert line["config"]["backend"] in ("gloo", "nccl")
     assert line["cpu_baseline"] is None      # rank 0 at N = 1 only
+
+
+def test_launcher_with_one_rank_runs_the_rccl_path():
+    """`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: under a
+    launcher bench.py creates a process group even for one rank, so on a 1-GPU
+    box RCCL is initialised and the N-rank path's collectives -- the gather of
+    the samples, the MAX all-reduce of the time, the barriers, the
+    one-device-per-rank check -- run over `backend='nccl'` (config 5's path
+    with world size 1)."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+         "--master-port", "29641", os.path.join(ROOT, "bench.py"),
+         "--gpus", "1", "--config", "tiny", "--steps", "4", "--warmup", "1",
+         "--burnin", "2", "--cpu-baseline-iters", "0"],
+        env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1
+    assert line["config"]["backend"] == "nccl"
+    assert line["config"]["rccl_ranks"] == 1
+
+
+def test_rccl_collectives_of_the_chain_gather_with_one_rank():
+    """chains.gather_chain_samples / max_over_ranks / barrier on a world-size-1
+    `nccl` group: device tensors stay on the device, host tensors are moved
+    there (RCCL moves device memory only) and come back on the host."""
+    code = """
+import os, sys
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+from bayesbridge_amd import chains
+rank, world, local = chains.init_process_group_from_env(
+    backend='nccl', single_rank_group=True)
+assert (rank, world) == (0, 1) and dist.get_backend() == 'nccl'
+x = torch.arange(12, dtype=torch.float64, device='cuda').reshape(3, 4)
+got = chains.gather_chain_samples(x, dst=0)
+assert got.is_cuda and got.shape == (1, 3, 4) and torch.equal(got[0], x)
+host = torch.arange(6, dtype=torch.float64).reshape(2, 3)
+got = chains.gather_chain_samples(host, dst=0)
+assert not got.is_cuda and torch.equal(got[0], host)
+assert chains.max_over_ranks(2.5) == 2.5
+chains.barrier()
+ids = [None]
+dist.all_gather_object(ids, torch.cuda.current_device())
+assert ids == [0]
+dist.destroy_process_group()
+print('RCCL_OK')
+""" % os.path.join(ROOT, "bayes-bridge_amd")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29643",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "RCCL_OK" in out.stdout
+
+
+def test_gpus_8_dry_run_over_gloo():
+    """The driver's 8-GPU launch in miniature: `bench.py --gpus 8` starts eight
+    ranks by itself (ports, eight generators and eight host-side layout
+    builders side by side); on a 1-GPU box they share the device (one stream
+    per chain, BBX_CHAIN_FORK=0) and gather over gloo."""
+    line = _bench("--gpus", "8", "--config", "tiny", "--steps", "3",
+                  "--warmup", "1", "--burnin", "2", timeout=1500)
+    assert line["n_gpus"] == 8
+    assert line["config"]["parallelism"] == "chains=8"
+    assert line["value"] > 0
+    assert line["config"]["startup_s"] > 0
+    assert line["config"]["peak_host_rss_mb"] > 0

@@ -232,8 +232,9 @@ def _variant_chain(tmp_path, env, family='logit', iters=6):
 @pytest.mark.parametrize("family", ['logit', 'linear'])
 def test_two_stream_iteration_is_bitwise_the_one_stream_iteration(tmp_path, family):
     """chain_step runs the Omega update and the tau / lambda updates on two
-    streams for large designs (BBX_CHAIN_FORK unset: n >= 400k).  Forced on
-    and off on a small problem: every saved sample is bit-identical (the
+    streams for designs from BASELINE config 2's size on (BBX_CHAIN_FORK unset:
+    n >= 50 000 and >= 2 048 shrunk coefficients).  Forced on and off on a
+    small problem: every saved sample is bit-identical (the
     branches share no data, Philox streams are keyed by element)."""
     a = _variant_chain(tmp_path, {'BBX_CHAIN_FORK': '0'}, family)
     b = _variant_chain(tmp_path, {'BBX_CHAIN_FORK': '1'}, family)
@@ -241,19 +242,3 @@ def test_two_stream_iteration_is_bitwise_the_one_stream_iteration(tmp_path, fami
                 'n_cg_iter'):
         assert np.array_equal(a[key], b[key]), key
     assert np.all(np.isfinite(a['logp'])) and a['coef'].shape[0] == 6
-
-
-def test_one_pass_initial_residual_matches_the_two_pass_sequence(tmp_path):
-    """BBX_CG_MERGE_RESID=0 forms b and A x0 with two products with X~^T as the
-    reference does; the default folds them into one (TD_RESID).  The first
-    iteration (cold start, identical states) agrees to 1e-9 of the coefficient
-    scale; afterwards the two chains are different roundings of the same
-    recurrence and are only required to stay statistically indistinguishable
-    over these few iterations (same stopping iterations +-2)."""
-    a = _variant_chain(tmp_path, {'BBX_CG_MERGE_RESID': '0'})
-    b = _variant_chain(tmp_path, {'BBX_CG_MERGE_RESID': '1'})
-    scale = max(1., np.abs(a['coef'][0]).max())
-    assert np.abs(a['coef'][0] - b['coef'][0]).max() <= 1e-9 * scale
-    assert a['n_cg_iter'][0] == b['n_cg_iter'][0]
-    assert np.abs(a['n_cg_iter'] - b['n_cg_iter']).max() <= \
-        max(2, int(.1 * a['n_cg_iter'].max()))

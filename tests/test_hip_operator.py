@@ -209,45 +209,6 @@ def test_cabi_rejects_malformed_csr():
         np.testing.assert_allclose(hip.Tdot(v), [100., 2., 1.], rtol=1e-14)
 
 
-def test_packed_id_layout_opt_in():
-    """BBX_TILED_PACK=1 stores the value-free ids as 14-bit base + 4 x 12-bit
-    deltas (5 entries per 8 bytes).  The switch is read once per process, so
-    the check runs in a child: skewed binary design with duplicates-free rows,
-    long gaps (sparse rows of X^T) and heavy rows, against SciPy."""
-    import os, subprocess, sys
-    code = """
-import sys, numpy as np
-sys.path.insert(0, %r)
-from bayesbridge_amd import HipSparseDesignMatrix, simulate
-X = simulate.simulate_binary_csr_fast(60000, 20000, .004, seed=31)
-hip = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
-                            storage='tiled')
-info = hip.tiled_info()
-rng = np.random.default_rng(32)
-n, P = hip.shape
-v, w = rng.standard_normal(P), rng.standard_normal(n)
-off = np.asarray(X.mean(axis=0)).ravel()
-ref_v = v[0] + X @ v[1:] - off @ v[1:]
-ref_w = np.concatenate(([w.sum()], X.T @ w - w.sum() * off))
-assert np.abs(hip.dot(v) - ref_v).max() <= 1e-11 * np.abs(ref_v).max()
-assert np.abs(hip.Tdot(w) - ref_w).max() <= 1e-11 * np.abs(ref_w).max()
-print('QUADS', info['X']['n_quad'], info['Xt']['n_quad'])
-""" % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                   'bayes-bridge_amd')
-    quads = {}
-    for pack in ('0', '1'):
-        env = dict(os.environ, BBX_TILED_PACK=pack)
-        res = subprocess.run([sys.executable, '-c', code], env=env,
-                             capture_output=True, text=True, timeout=600)
-        assert res.returncode == 0, res.stdout + res.stderr
-        line = [l for l in res.stdout.splitlines() if l.startswith('QUADS')][0]
-        quads[pack] = [int(t) for t in line.split()[1:]]
-    # (the step counts differ little here: rows cut into chunks of <= 8 entries
-    # for occupancy need 2 steps either way, and long gaps open new groups;
-    # the layout pays off on big panels, DESIGN.md 3.1)
-    assert all(q > 0 for q in quads['0'] + quads['1'])
-
-
 @pytest.mark.parametrize("case", range(24))
 def test_random_shapes_and_patterns(case):
     """Randomised shapes against SciPy: one to several column blocks

@@ -34,8 +34,6 @@ def test_layout_emulation_equals_scipy(layout, case):
     variants = [dict(), dict(bank_aware=False)]
     if case % 4 == 0:
         variants.append(dict(force_PR=128, force_G=2, threads=3))
-    if binary:
-        variants.append(dict(packed=True))
     for kw in variants:
         out_v, info_v = layout.matvec(X, v, **kw)
         out_w, info_w = layout.matvec(Xt, w, **kw)
@@ -60,7 +58,7 @@ def test_integer_vectors_give_exact_sums(layout):
     w = rng.integers(-50, 50, X.shape[0]).astype(np.float64)
     Xt = X.T.tocsr()
     Xt.sort_indices()
-    for kw in (dict(), dict(packed=True), dict(force_PR=256, force_G=2)):
+    for kw in (dict(), dict(force_PR=256, force_G=2)):
         assert np.array_equal(layout.matvec(X, v, **kw)[0], X @ v)
         assert np.array_equal(layout.matvec(Xt, w, **kw)[0], Xt @ w)
 
@@ -87,7 +85,7 @@ def test_bank_aware_order_lowers_lds_conflicts(layout):
 
 def test_builder_under_address_undefined_and_thread_sanitizers():
     """make sanitize: the self-test driver (random matrices, 4 builder threads,
-    plain/packed/valued layouts, emulation vs a plain CSR product) under
+    value-free/valued layouts, emulation vs a plain CSR product) under
     -fsanitize=address,undefined and -fsanitize=thread."""
     res = subprocess.run(
         ['make', '-C', os.path.join(ROOT, 'bayes-bridge_amd', 'csrc'),
