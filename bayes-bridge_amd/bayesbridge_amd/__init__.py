@@ -5,7 +5,7 @@ reference's (bayesbridge/__init__.py:1-4)."""
 from ._lib import BbxError, device_count
 from .bayesbridge import BayesBridge, SamplerOptions
 from .cg_sampler import HipCGSampler
-from .device_chain import HipGibbsChain
+from .device_chain import HipChainBatch, HipGibbsChain
 from .design_matrix import (HipDenseDesignMatrix, HipDesignMatrix,
                             HipSparseDesignMatrix)
 from .model import LinearModel, LogisticModel, RegressionModel
@@ -14,6 +14,6 @@ from .prior import RegressionCoefPrior
 __all__ = [
     "BayesBridge", "RegressionModel", "RegressionCoefPrior", "SamplerOptions",
     "HipDesignMatrix", "HipSparseDesignMatrix", "HipDenseDesignMatrix",
-    "HipCGSampler", "HipGibbsChain", "LinearModel", "LogisticModel", "BbxError",
+    "HipCGSampler", "HipGibbsChain", "HipChainBatch", "LinearModel", "LogisticModel", "BbxError",
     "device_count",
 ]

@@ -114,6 +114,18 @@ def _declare(lib):
         "bbx_chain_run_host": (
             [hp, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
              c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+        "bbx_batch_create": ([hp, c_int, c_void_p, POINTER(hp)], c_int),
+        "bbx_batch_destroy": ([hp], c_int),
+        "bbx_batch_run": (
+            [hp, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
+             c_void_p, c_void_p], c_int),
+        "bbx_batch_run_host": (
+            [hp, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
+             c_void_p, c_void_p], c_int),
+        "bbx_batch_dot": ([hp, c_void_p, c_void_p], c_int),
+        "bbx_batch_tdot": ([hp, c_void_p, c_void_p], c_int),
+        "bbx_batch_bytes": (
+            [hp, POINTER(c_int64), POINTER(c_int64)], c_int),
         "bbx_device_polya_gamma": (
             [c_int, c_uint64, c_int64, c_void_p, c_void_p, c_void_p], c_int),
         "bbx_device_tilted_stable": (

@@ -211,3 +211,101 @@ class HipGibbsChain():
             float(atol), c_void_p(d_coef_ptr) if d_coef_ptr else None, None,
             None, _ptr(gs), _ptr(lp), _ptr(ncg)))
         return gs[:n_sample], lp[:n_sample], ncg[:n_sample], n_unconv
+
+
+class HipChainBatch():
+    """Chains that share every pass over the design (`bbx_batch_*`): the
+    products of the CG solves and the linear predictor of the Omega update run
+    once for all chains of the batch (K-column products over one read of the
+    matrix).  The reference has one chain per process (bayesbridge.py:109);
+    this is how more chains than GPUs are run here.  `chains`: 2 or 4
+    HipGibbsChain objects on the same design; set / get their state through
+    the chains themselves between runs."""
+
+    def __init__(self, chains):
+        import ctypes
+        chains = list(chains)
+        self._lib = _lib.load()
+        self._b = c_void_p()
+        self.chains = chains             # keeps them (and the design) alive
+        self.design = chains[0].design
+        self.P = chains[0].P
+        arr = (c_void_p * len(chains))(*[c.handle.value for c in chains])
+        _lib.check(self._lib.bbx_batch_create(
+            self.design.handle, len(chains), ctypes.cast(arr, c_void_p),
+            byref(self._b)))
+
+    def close(self):
+        b = getattr(self, '_b', None)
+        if b is not None and b.value:
+            try:
+                self._lib.bbx_batch_destroy(b)
+            except Exception:
+                pass
+            self._b = c_void_p()
+
+    __del__ = close
+
+    @property
+    def n_chain(self):
+        return len(self.chains)
+
+    @property
+    def launch_bytes(self):
+        """(dot, Tdot): bytes one batched launch of each product moves."""
+        d, t = c_int64(), c_int64()
+        _lib.check(self._lib.bbx_batch_bytes(self._b, byref(d), byref(t)))
+        return int(d.value), int(t.value)
+
+    def dot(self, v):
+        """[n_chain, P] -> [n_chain, n]: X~ v_c through the batched kernel."""
+        v = _f64(v)
+        out = np.empty((self.n_chain, self.chains[0].n))
+        _lib.check(self._lib.bbx_batch_dot(self._b, _ptr(v), _ptr(out)))
+        return out
+
+    def Tdot(self, w):
+        """[n_chain, n] -> [n_chain, P]: X~^T w_c through the batched kernel."""
+        w = _f64(w)
+        out = np.empty((self.n_chain, self.P))
+        _lib.check(self._lib.bbx_batch_tdot(self._b, _ptr(w), _ptr(out)))
+        return out
+
+    def run(self, n_iter, n_burnin=0, thin=1, maxiter=500, atol=0.,
+            save_coef=True):
+        """n_iter Gibbs iterations of every chain.  Returns (samples,
+        n_unconverged); samples: 'coef' [n_chain, n_sample, P] (if
+        save_coef), 'global_scale', 'logp', 'n_cg_iter' [n_chain, n_sample]."""
+        K = self.n_chain
+        n_sample = (n_iter - n_burnin) // thin
+        rows = max(n_sample, 1)
+        coef = np.zeros((K, rows, self.P)) if save_coef else None
+        gs, lp, ncg = (np.zeros((K, rows)) for _ in range(3))
+        n_unconv = _lib.check(self._lib.bbx_batch_run_host(
+            self._b, int(n_iter), int(n_burnin), int(thin), int(maxiter),
+            float(atol), _ptr(coef), _ptr(gs), _ptr(lp), _ptr(ncg)))
+        out = {'global_scale': gs[:, :n_sample], 'logp': lp[:, :n_sample],
+               'n_cg_iter': ncg[:, :n_sample]}
+        if coef is not None:
+            out['coef'] = coef[:, :n_sample]
+        return out, n_unconv
+
+    def run_device(self, n_iter, d_coef_ptrs=None, n_burnin=0, thin=1,
+                   maxiter=500, atol=0.):
+        """Same, the kept coefficients going to one DEVICE buffer per chain
+        (raw pointers, each sample-major [n_sample, P]).  Returns
+        (global_scale, logp, n_cg_iter, n_unconverged), arrays
+        [n_chain, n_sample]."""
+        import ctypes
+        K = self.n_chain
+        n_sample = (n_iter - n_burnin) // thin
+        rows = max(n_sample, 1)
+        gs, lp, ncg = (np.zeros((K, rows)) for _ in range(3))
+        arr = None
+        if d_coef_ptrs is not None:
+            arr = (c_void_p * K)(*[int(p) for p in d_coef_ptrs])
+        n_unconv = _lib.check(self._lib.bbx_batch_run(
+            self._b, int(n_iter), int(n_burnin), int(thin), int(maxiter),
+            float(atol), None if arr is None else ctypes.cast(arr, c_void_p),
+            _ptr(gs), _ptr(lp), _ptr(ncg)))
+        return gs[:, :n_sample], lp[:, :n_sample], ncg[:, :n_sample], n_unconv

@@ -6,56 +6,9 @@
 #include <new>
 #include <vector>
 
-#include "common.hpp"
+#include "chain.hpp"
 #include "philox.hpp"
 #include "samplers.hpp"
-
-namespace bbx {
-
-constexpr int ROW_GRID = 2048;  // blocks of the n-length sampler kernels
-
-// Two 128-byte halves: after the coefficient draw the Omega update and the
-// tau / lambda updates run as two branches on two streams (chain_step), each
-// writing only its own half, so that no cache line is dirty in two L2s.
-struct alignas(128) ChainScalars {
-  // ---- written by the tau / lambda branch
-  double gscale;         // tau, raw parametrisation
-  double logprior;       // log posterior minus the log-likelihood
-  double abs_pow_sum;    // sum |beta_j|^alpha over shrunk coordinates
-  long long n_gscale_clamped;
-  long long n_lscale_fixed;
-  // ---- written by the Omega branch
-  alignas(128) double obs_prec;  // linear model only
-  double loglik;                 // of the current coef
-  // log posterior (bayesbridge.py:480-511)
-  __host__ __device__ double logp() const { return loglik + logprior; }
-};
-
-}  // namespace bbx
-
-struct bbx_chain {
-  bbx_design* h = nullptr;
-  int model = BBX_MODEL_LOGIT;
-  int n_unshrunk = 0;
-  double bridge_exp = .5, slab = INFINITY, shape0 = 0., rate0 = 0.;
-  uint64_t seed = 0;
-  int64_t iter = 0;        // iterations done (Philox key)
-  int64_t n_averaged = 0;  // summariser count
-  bool mean_zero = true;   // running mean still all zeros => CG warm start 0
-  int gscale_update = BBX_GSCALE_SAMPLE;
-  bbx::DevMem outcome, n_trial, kappa;  // n
-  bbx::DevMem zbase;                    // P: X~^T kappa (logit) or X~^T y
-  bbx::DevMem coef, phi, x0, sd, z, mean, square, sd_unshrunk;  // P-length
-  bbx::DevMem lscale;                   // P - n_unshrunk
-  bbx::DevMem obs_prec, psi;            // n
-  bbx::DevMem scalars;                  // ChainScalars
-  bbx::DevMem row_part;                 // ROW_GRID partials x 2
-  bbx::DevMem samp_gscale, samp_logp;   // per kept sample (device)
-  void* pinned = nullptr;
-  // second stream for the tau / lambda branch of an iteration
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_join = nullptr;
-};
 
 namespace bbx {
 
@@ -558,40 +511,34 @@ static double power_exp_ave_magnitude(double exponent) {
   return std::tgamma(2. / exponent) / std::tgamma(1. / exponent);
 }
 
-// Philox key of the CG draw's normals at 0-based iteration `it`.
-static inline uint64_t cg_draw_seed(const bbx_chain* c, uint64_t it) {
-  return c->seed + 0x9E3779B97F4A7C15ull * (it + 1);
+int chain_pre_draw(bbx_chain* c) {
+  bbx_design* h = c->h;
+  hipStream_t s = h->stream;
+  const int64_t P = h->P, n = h->n;
+  ChainScalars* sc = c->scalars.as<ChainScalars>();
+  // --- beta | Omega, tau, lambda  (bayesbridge.py:372-395)
+  hipLaunchKernelGGL(chain_prior_kernel, dim3(NPART), dim3(256), 0, s, P,
+                     c->n_unshrunk, c->model, c->slab,
+                     (long long)c->n_averaged, sc, c->lscale.as<double>(),
+                     c->sd_unshrunk.as<double>(), c->mean.as<double>(),
+                     c->square.as<double>(), c->zbase.as<double>(),
+                     c->phi.as<double>(), c->x0.as<double>(),
+                     c->sd.as<double>(), c->z.as<double>());
+  if (c->model == BBX_MODEL_LINEAR)
+    hipLaunchKernelGGL(chain_fill_obs_prec_kernel, dim3(grid_for(n, ROW_GRID)),
+                       dim3(256), 0, s, n, sc, c->obs_prec.as<double>());
+  BBX_HIP(hipGetLastError());
+  return BBX_OK;
 }
 
-// One Gibbs iteration (bayesbridge.py:210-240); returns the CG info (>= 0).
-static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
+int chain_post_draw(bbx_chain* c, bool have_psi, hipStream_t branch,
+                    bool join_branch) {
   bbx_design* h = c->h;
   hipStream_t s = h->stream;
   const int64_t P = h->P, n = h->n;
   const int nu = c->n_unshrunk;
   const int64_t n_shrunk = P - nu;
   ChainScalars* sc = c->scalars.as<ChainScalars>();
-  const uint64_t it = (uint64_t)c->iter;
-
-  // --- beta | Omega, tau, lambda  (bayesbridge.py:372-395)
-  hipLaunchKernelGGL(chain_prior_kernel, dim3(NPART), dim3(256), 0, s, P, nu,
-                     c->model, c->slab, (long long)c->n_averaged, sc,
-                     c->lscale.as<double>(), c->sd_unshrunk.as<double>(),
-                     c->mean.as<double>(), c->square.as<double>(),
-                     c->zbase.as<double>(), c->phi.as<double>(),
-                     c->x0.as<double>(), c->sd.as<double>(), c->z.as<double>());
-  if (c->model == BBX_MODEL_LINEAR)
-    hipLaunchKernelGGL(chain_fill_obs_prec_kernel, dim3(grid_for(n, ROW_GRID)),
-                       dim3(256), 0, s, n, sc, c->obs_prec.as<double>());
-  BBX_HIP(hipGetLastError());
-  int info = 0;
-  int st = cg_sample_device(
-      h, c->obs_prec.as<double>(), c->phi.as<double>(), c->z.as<double>(),
-      c->x0.as<double>(), c->sd.as<double>(), nu, nullptr, nullptr,
-      cg_draw_seed(c, it), maxiter, atol, c->coef.as<double>(), n_cg_iter,
-      &info, c->mean_zero ? 1 : 0);
-  if (st < 0) return st;
-  c->mean_zero = false;
 
   // The two updates that follow read beta and nothing of each other: the
   // Omega branch (X~ beta: one pass over the matrix, then n Polya-Gamma draws)
@@ -600,30 +547,32 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
   // coefficients) runs beside it on a second stream.  Each branch writes its
   // own half of ChainScalars; Philox streams are keyed by element, so the
   // draws do not depend on the interleaving.  beta is final here (the CG
-  // solve ended with a stream sync), so the second stream needs no event to
-  // start; the summary kernel, which reads the OLD tau and lambda, leads that
-  // branch.  The design's stream waits for the branch at the end.  Measured:
-  // config 3 +1.6 %, config 2 +2.5 %, config 4 +-0; tiny problems keep one
-  // stream, and so should processes that SHARE a GPU (two ranks on one device
-  // ran 3x slower with a second queue each: chains.py sets BBX_CHAIN_FORK=0
-  // then).  BBX_CHAIN_FORK=0 / 1 forces one / two streams.
+  // solve ended with a stream sync: cg_sample_device's postcondition), so the
+  // second stream needs no event to start; the summary kernel, which reads the
+  // OLD tau and lambda, leads that branch.  The design's stream waits for the
+  // branch at the end.  Measured: config 3 +1.6 %, config 2 +2.5 %, config 4
+  // +-0; tiny problems keep one stream, and so should processes that SHARE a
+  // GPU (two ranks on one device ran 3x slower with a second queue each:
+  // chains.py sets BBX_CHAIN_FORK=0 then).  BBX_CHAIN_FORK=0 / 1 forces one /
+  // two streams.
   static const int fork_env =
       getenv("BBX_CHAIN_FORK") ? atoi(getenv("BBX_CHAIN_FORK")) : -1;
   const bool fork = fork_env >= 0 ? fork_env == 1
                                   : (n >= 50000 && n_shrunk >= 2048);
-  if (fork && c->stream2 == nullptr) {
+  if (fork && branch == nullptr && c->stream2 == nullptr) {
     // created on first use: chains that never fork keep a single queue
     BBX_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    BBX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   }
-  hipStream_t s_b = fork ? c->stream2 : s;
+  if (fork && c->ev_join == nullptr)
+    BBX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  hipStream_t s_b = !fork ? s : (branch ? branch : c->stream2);
 
   // --- Omega | beta  (bayesbridge.py:397-410).  Launch order = what has to
   // start first: the pass over the matrix, then the whole second branch (it
   // starts under that pass: the lambda kernel and the Polya-Gamma kernel are
   // both ALU-bound and slow each other down, the pass is bandwidth-bound),
   // then the n Polya-Gamma draws.
-  BBX_TRY(chain_linear_predictor(c));
+  if (!have_psi) BBX_TRY(chain_linear_predictor(c));
 
   // --- running summaries of beta (with the tau and lambda it was drawn
   // under), then tau | beta, then lambda | tau, beta, then log posterior
@@ -675,13 +624,79 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
 
   // the second branch is joined on every path, a failed launch included
   const hipError_t launch_err = hipGetLastError();
-  if (fork) {
-    BBX_HIP(hipEventRecord(c->ev_join, c->stream2));
+  if (fork && join_branch) {
+    BBX_HIP(hipEventRecord(c->ev_join, s_b));
     BBX_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
   }
   BBX_HIP(launch_err);
   c->iter += 1;
+  return BBX_OK;
+}
+
+// One Gibbs iteration (bayesbridge.py:210-240); returns the CG info (>= 0).
+static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
+  const uint64_t it = (uint64_t)c->iter;
+  BBX_TRY(chain_pre_draw(c));
+  int info = 0;
+  int st = cg_sample_device(
+      c->h, c->obs_prec.as<double>(), c->phi.as<double>(), c->z.as<double>(),
+      c->x0.as<double>(), c->sd.as<double>(), c->n_unshrunk, nullptr, nullptr,
+      cg_draw_seed(c, it), maxiter, atol, c->coef.as<double>(), n_cg_iter,
+      &info, c->mean_zero ? 1 : 0);
+  if (st < 0) return st;
+  c->mean_zero = false;
+  BBX_TRY(chain_post_draw(c, false, nullptr, true));
   return info;
+}
+
+int chain_begin_run(bbx_chain* c, int n_sample) {
+  BBX_TRY(c->samp_gscale.alloc(sizeof(double) * (size_t)(n_sample + 1)));
+  BBX_TRY(c->samp_logp.alloc(sizeof(double) * (size_t)(n_sample + 1)));
+  return BBX_OK;
+}
+
+int chain_save_sample(bbx_chain* c, int idx, double* d_coef, double* d_lscale,
+                      double* d_obs_prec) {
+  bbx_design* h = c->h;
+  const int64_t P = h->P, n = h->n;
+  const int64_t n_shrunk = P - c->n_unshrunk;
+  if (d_coef)
+    BBX_HIP(hipMemcpyAsync(d_coef + (size_t)idx * P, c->coef.ptr,
+                           sizeof(double) * (size_t)P,
+                           hipMemcpyDeviceToDevice, h->stream));
+  if (d_lscale && n_shrunk > 0)
+    BBX_HIP(hipMemcpyAsync(d_lscale + (size_t)idx * n_shrunk, c->lscale.ptr,
+                           sizeof(double) * (size_t)n_shrunk,
+                           hipMemcpyDeviceToDevice, h->stream));
+  if (d_obs_prec) {
+    if (c->model == BBX_MODEL_LOGIT)
+      BBX_HIP(hipMemcpyAsync(d_obs_prec + (size_t)idx * n, c->obs_prec.ptr,
+                             sizeof(double) * (size_t)n,
+                             hipMemcpyDeviceToDevice, h->stream));
+    else
+      BBX_HIP(hipMemcpyAsync(
+          d_obs_prec + idx, &c->scalars.as<ChainScalars>()->obs_prec,
+          sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  }
+  hipLaunchKernelGGL(chain_store_scalars_kernel, dim3(1), dim3(64), 0,
+                     h->stream, c->scalars.as<ChainScalars>(), idx,
+                     c->samp_gscale.as<double>(), c->samp_logp.as<double>());
+  BBX_HIP(hipGetLastError());
+  return BBX_OK;
+}
+
+int chain_end_run(bbx_chain* c, int n_sample, double* gscale, double* logp) {
+  bbx_design* h = c->h;
+  if (gscale && n_sample > 0)
+    BBX_HIP(hipMemcpyAsync(gscale, c->samp_gscale.ptr,
+                           sizeof(double) * (size_t)n_sample,
+                           hipMemcpyDeviceToHost, h->stream));
+  if (logp && n_sample > 0)
+    BBX_HIP(hipMemcpyAsync(logp, c->samp_logp.ptr,
+                           sizeof(double) * (size_t)n_sample,
+                           hipMemcpyDeviceToHost, h->stream));
+  BBX_HIP(hipStreamSynchronize(h->stream));
+  return BBX_OK;
 }
 
 }  // namespace bbx
@@ -1014,13 +1029,11 @@ static int bbx_chain_run_impl(bbx_chain* c, int n_iter, int n_burnin, int thin,
     return fail(BBX_ERR_INVALID, "bad n_iter / n_burnin / thin");
   bbx_design* h = c->h;
   BBX_HIP(hipSetDevice(h->device));
-  const int64_t P = h->P, n = h->n;
+  const int64_t P = h->P;
   if (maxiter <= 0) maxiter = 500;                      // reg_coef_sampler.py:95
   if (!(atol > 0.)) atol = 10e-6 * std::sqrt((double)P);
   const int n_sample = (n_iter - n_burnin) / thin;
-  BBX_TRY(c->samp_gscale.alloc(sizeof(double) * (size_t)(n_sample + 1)));
-  BBX_TRY(c->samp_logp.alloc(sizeof(double) * (size_t)(n_sample + 1)));
-  const int64_t n_shrunk = P - c->n_unshrunk;
+  BBX_TRY(chain_begin_run(c, n_sample));
   int n_unconverged = 0;
   for (int it = 1; it <= n_iter; ++it) {
     int ncg = 0;
@@ -1030,40 +1043,10 @@ static int bbx_chain_run_impl(bbx_chain* c, int n_iter, int n_burnin, int thin,
     if (it <= n_burnin || (it - n_burnin) % thin != 0) continue;
     const int idx = (it - n_burnin) / thin - 1;  // gibbs_util.py:170
     if (idx >= n_sample) continue;
-    if (d_coef)
-      BBX_HIP(hipMemcpyAsync(d_coef + (size_t)idx * P, c->coef.ptr,
-                             sizeof(double) * (size_t)P,
-                             hipMemcpyDeviceToDevice, h->stream));
-    if (d_lscale && n_shrunk > 0)
-      BBX_HIP(hipMemcpyAsync(d_lscale + (size_t)idx * n_shrunk, c->lscale.ptr,
-                             sizeof(double) * (size_t)n_shrunk,
-                             hipMemcpyDeviceToDevice, h->stream));
-    if (d_obs_prec) {
-      if (c->model == BBX_MODEL_LOGIT)
-        BBX_HIP(hipMemcpyAsync(d_obs_prec + (size_t)idx * n, c->obs_prec.ptr,
-                               sizeof(double) * (size_t)n,
-                               hipMemcpyDeviceToDevice, h->stream));
-      else
-        BBX_HIP(hipMemcpyAsync(
-            d_obs_prec + idx,
-            &c->scalars.as<ChainScalars>()->obs_prec, sizeof(double),
-            hipMemcpyDeviceToDevice, h->stream));
-    }
-    hipLaunchKernelGGL(chain_store_scalars_kernel, dim3(1), dim3(64), 0,
-                       h->stream, c->scalars.as<ChainScalars>(), idx,
-                       c->samp_gscale.as<double>(), c->samp_logp.as<double>());
+    BBX_TRY(chain_save_sample(c, idx, d_coef, d_lscale, d_obs_prec));
     if (n_cg_iter) n_cg_iter[idx] = (double)ncg;
   }
-  BBX_HIP(hipGetLastError());
-  if (gscale && n_sample > 0)
-    BBX_HIP(hipMemcpyAsync(gscale, c->samp_gscale.ptr,
-                           sizeof(double) * (size_t)n_sample,
-                           hipMemcpyDeviceToHost, h->stream));
-  if (logp && n_sample > 0)
-    BBX_HIP(hipMemcpyAsync(logp, c->samp_logp.ptr,
-                           sizeof(double) * (size_t)n_sample,
-                           hipMemcpyDeviceToHost, h->stream));
-  BBX_HIP(hipStreamSynchronize(h->stream));
+  BBX_TRY(chain_end_run(c, n_sample, gscale, logp));
   return n_unconverged;
 }
 

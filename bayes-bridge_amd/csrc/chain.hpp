@@ -1,0 +1,81 @@
+// Device-resident Gibbs chain: the handle and the three phases of one
+// iteration (bayesbridge.py:210-240), shared by chain.hip (one chain per pass
+// over the matrix) and batch.hip (K chains per pass).
+#pragma once
+#include <cmath>
+
+#include "common.hpp"
+
+namespace bbx {
+
+constexpr int ROW_GRID = 2048;  // blocks of the n-length sampler kernels
+
+// Two 128-byte halves: after the coefficient draw the Omega update and the
+// tau / lambda updates run as two branches on two streams (chain_step), each
+// writing only its own half, so that no cache line is dirty in two L2s.
+struct alignas(128) ChainScalars {
+  // ---- written by the tau / lambda branch
+  double gscale;         // tau, raw parametrisation
+  double logprior;       // log posterior minus the log-likelihood
+  double abs_pow_sum;    // sum |beta_j|^alpha over shrunk coordinates
+  long long n_gscale_clamped;
+  long long n_lscale_fixed;
+  // ---- written by the Omega branch
+  alignas(128) double obs_prec;  // linear model only
+  double loglik;                 // of the current coef
+  // log posterior (bayesbridge.py:480-511)
+  __host__ __device__ double logp() const { return loglik + logprior; }
+};
+
+}  // namespace bbx
+
+struct bbx_chain {
+  bbx_design* h = nullptr;
+  int model = BBX_MODEL_LOGIT;
+  int n_unshrunk = 0;
+  double bridge_exp = .5, slab = INFINITY, shape0 = 0., rate0 = 0.;
+  uint64_t seed = 0;
+  int64_t iter = 0;        // iterations done (Philox key)
+  int64_t n_averaged = 0;  // summariser count
+  bool mean_zero = true;   // running mean still all zeros => CG warm start 0
+  int gscale_update = BBX_GSCALE_SAMPLE;
+  bbx::DevMem outcome, n_trial, kappa;  // n
+  bbx::DevMem zbase;                    // P: X~^T kappa (logit) or X~^T y
+  bbx::DevMem coef, phi, x0, sd, z, mean, square, sd_unshrunk;  // P-length
+  bbx::DevMem lscale;                   // P - n_unshrunk
+  bbx::DevMem obs_prec, psi;            // n
+  bbx::DevMem scalars;                  // ChainScalars
+  bbx::DevMem row_part;                 // ROW_GRID partials x 2
+  bbx::DevMem samp_gscale, samp_logp;   // per kept sample (device)
+  void* pinned = nullptr;
+  // second stream for the tau / lambda branch of an iteration
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_join = nullptr;
+};
+
+namespace bbx {
+
+// Philox key of the CG draw's normals at 0-based iteration `it`.
+inline uint64_t cg_draw_seed(const bbx_chain* c, uint64_t it) {
+  return c->seed + 0x9E3779B97F4A7C15ull * (it + 1);
+}
+
+// beta | Omega, tau, lambda, part 1 (bayesbridge.py:372-395): phi, the CG warm
+// start, the preconditioner sd and z of this iteration, on the design's stream.
+int chain_pre_draw(bbx_chain* c);
+// Everything after the coefficient draw: Omega | beta (the linear predictor
+// psi = X~ beta unless `have_psi`: a batch computes it for all its chains in
+// one pass), running summaries, tau | beta, lambda | tau, beta, log posterior.
+// `branch` != nullptr overrides the stream of the tau / lambda branch (a batch
+// serialises its chains' branches on one stream: they share the design's
+// scratch partial slots).  Advances c->iter.
+int chain_post_draw(bbx_chain* c, bool have_psi, hipStream_t branch,
+                    bool join_branch);
+// Sample bookkeeping of a run (gibbs_util.py:126-174): per-sample scalars are
+// collected on the device and copied out once at the end.
+int chain_begin_run(bbx_chain* c, int n_sample);
+int chain_save_sample(bbx_chain* c, int idx, double* d_coef, double* d_lscale,
+                      double* d_obs_prec);
+int chain_end_run(bbx_chain* c, int n_sample, double* gscale, double* logp);
+
+}  // namespace bbx

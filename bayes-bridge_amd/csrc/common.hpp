@@ -99,6 +99,16 @@ int no_throw(F&& f) noexcept {
     if (st__ < 0) return st__;                                                 \
   } while (0)
 
+// Chains that may share one pass over a sparse design (batched chains); the
+// per-chain device pointers the batched kernels take by value.
+constexpr int BATCH_MAX = 4;
+struct ChainPtrs {
+  const double* p[BATCH_MAX];
+};
+struct ChainOut {
+  double* p[BATCH_MAX];
+};
+
 // Device allocation owned by a handle; freed in the handle's destructor.
 struct DevMem {
   void* ptr = nullptr;
@@ -186,6 +196,9 @@ struct bbx_design {
 
   // --- LDS-tiled layout (BBX_FORMAT_TILED): see spmv_tiled.hip
   void* tiled = nullptr;           // bbx::TiledPair*
+  // layouts sized for 2 and 4 right-hand sides (batched chains), built on
+  // first use from the CSR arrays above
+  void* tiled_k[2] = {nullptr, nullptr};
 
   bbx::DevMem offset;  // column means (p), zeros when not centred
 
@@ -315,6 +328,27 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
 bool dense_fused_applies(const bbx_design* h);
 int build_tiled(bbx_design* h);
 void destroy_tiled(bbx_design* h);
+int ensure_tiled_k(bbx_design* h, int K);
+// Per-chain arguments of a batched launch of the tiled kernels (K > 1).
+struct TiledBatchArgs {
+  ChainPtrs rowscale{};   // dot epilogue: Omega of each chain (entries may be null)
+  ChainOut out{};         // dot epilogue: out.p[c][row * out_stride]
+  int out_stride = 1;
+  int part_stride = 0;    // doubles between the chains' NPART-blocks
+};
+// t_c = rowscale_c .* (X~ v_c) for the K chains of the interleaved [P][K] input
+// `d_v` (c_part: K NPART-blocks of <offset, v_c[1:]>, part_stride apart).  When
+// d_sum_part != nullptr it receives per chain the NPART partials of sum(t_c)
+// and, twt_off doubles further, of <t_c, Omega_c t_c>.
+int launch_dot_tiled_k(bbx_design* h, int K, const double* d_v,
+                       const double* d_c_part, const TiledBatchArgs& ba,
+                       double* d_sum_part, int twt_off);
+// Main kernel of X~^T w_c for the interleaved [n][K] input: leaves G slabs
+// [G][p][K] (returned through slab / G) for the batched epilogue kernel.
+int launch_tdot_tiled_k(bbx_design* h, int K, const double* d_w,
+                        const double** slab, int* G);
+int tiled_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
+                      int64_t* tdot_bytes);
 // timed_only: count what the timed kernel of each family moves (tiled Tdot:
 // without the epilogue kernel's slab read and P-vector output)
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,

@@ -71,6 +71,7 @@ static_assert(WAVE_CHECK == 1, "tiled layout is built for 64-lane wavefronts");
 struct TiledMatrix {
   int64_t R = 0, C = 0, nnz = 0;
   int W = 0, n_block = 0, PR = 0, n_panel = 0, G = 0;
+  int K = 1;  // right-hand sides the geometry was sized for
   bool has_vals = false;
   int64_t n_slice = 0, n_quad = 0, n_tile = 0;
   DevMem ids;        // uint4[n_quad * 64]
@@ -84,7 +85,7 @@ struct TiledMatrix {
   DevMem panel_fold; // int32[n_panel + 1]
   int n_extra = 0;   // extra accumulators per panel (row splitting)
   int split_T = 0;   // smallest split threshold used by any panel (0 = none)
-  DevMem slab;       // double[G * R] partial sums when G > 1 (or Tdot)
+  DevMem slab;       // double[G * R * K] partial sums when G > 1 (or Tdot)
   int64_t stream_bytes() const {
     return (int64_t)n_quad * 64 * 16 * (has_vals ? 5 : 1) +
            (int64_t)n_slice * 256 + (int64_t)n_desc * (int64_t)sizeof(BatchDesc);
@@ -118,6 +119,35 @@ __device__ __forceinline__ void step_accumulate(const double* __restrict__ xs,
     a1 += xs[e.x >> 16] + xs[e.y >> 16];
     b0 += xs[e.z & 0xFFFFu] + xs[e.w & 0xFFFFu];
     b1 += xs[e.z >> 16] + xs[e.w >> 16];
+  }
+}
+
+// The same step for K = 2 KP right-hand sides (batched chains).  The vector
+// slices sit in LDS as KP planes of interleaved PAIRS, xs2[q][j] = {x_2q[j],
+// x_2q+1[j]}: one ds_read_b128 serves two chains (4 LDS cycles for 64 lanes x
+// 16 bytes, the byte rate of the ds_read_b64 of the single-chain kernel), and
+// planes instead of a 32-byte interleave keep the 16 lanes of a b128 group
+// spread over all sixteen 16-byte slots of the bank row.  Every column sees
+// exactly the additions, in the order, of step_accumulate.
+template <bool VALS, int KP>
+__device__ __forceinline__ void step_accumulate_k(const v2d* __restrict__ xs2,
+                                                  int plane, v4u e,
+                                                  const v2d* v, v2d* A0,
+                                                  v2d* A1, v2d* B0, v2d* B1) {
+#pragma unroll
+  for (int q = 0; q < KP; ++q) {
+    const v2d* xp = xs2 + q * plane;
+    if (VALS) {
+      A0[q] += v[0].x * xp[e.x & 0xFFFFu] + v[1].x * xp[e.y & 0xFFFFu];
+      A1[q] += v[0].y * xp[e.x >> 16] + v[1].y * xp[e.y >> 16];
+      B0[q] += v[2].x * xp[e.z & 0xFFFFu] + v[3].x * xp[e.w & 0xFFFFu];
+      B1[q] += v[2].y * xp[e.z >> 16] + v[3].y * xp[e.w >> 16];
+    } else {
+      A0[q] += xp[e.x & 0xFFFFu] + xp[e.y & 0xFFFFu];
+      A1[q] += xp[e.x >> 16] + xp[e.y >> 16];
+      B0[q] += xp[e.z & 0xFFFFu] + xp[e.w & 0xFFFFu];
+      B1[q] += xp[e.z >> 16] + xp[e.w >> 16];
+    }
   }
 }
 
@@ -168,8 +198,17 @@ __device__ __forceinline__ void asm_load_u32(unsigned& dst, unsigned off,
 }
 
 constexpr int FILL_UNROLL = (TILE_W_MAX + TILE_THREADS - 1) / TILE_THREADS;
+// batched kernels: K slices share the LDS, K * W <= (158 KB / 8) doubles
+constexpr int FILL_K_PAIRS =
+    ((TILE_LDS_BYTES - 2048) / 16 + TILE_THREADS - 1) / TILE_THREADS;
 
-template <bool VALS, bool WIDE>
+// KP == 0: one right-hand side (the single-chain kernel).  KP > 0: K = 2 KP
+// right-hand sides share the pass over the id stream; x is the interleaved
+// [C][K] input, x0_ptr its K intercept entries, c_part / out_sum_part hold one
+// NPART-block per chain `part_stride` doubles apart, rowscale_k / out_k are
+// per-chain pointers (out_k.p[c][row * out_stride]: out_stride = K with
+// p[c] = base + c writes an interleaved [R][K] result), slab is [G][R][K].
+template <bool VALS, bool WIDE, int KP>
 __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_kernel(
     int64_t R, int64_t C, int W, int PR, int G, int blocks_per_group,
     const int32_t* __restrict__ wave_desc, int desc_stride,
@@ -183,13 +222,19 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     double* __restrict__ slab, int n_acc,
     const int32_t* __restrict__ panel_fold, const FoldDesc* __restrict__ folds,
     double* __restrict__ out_sum_part, int twt_off, int ablate,
-    unsigned long long* dbg, const int* __restrict__ skip_flag) {
+    unsigned long long* dbg, const int* __restrict__ skip_flag,
+    ChainPtrs rowscale_k, ChainOut out_k, int out_stride, int part_stride) {
+  constexpr int K = KP > 0 ? 2 * KP : 1;
   // (scalar load, issued first; checked below once the descriptor loads that
   // every launch needs anyway have been issued, so it adds no round trip)
   const int skip = skip_flag ? *skip_flag : 0;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* xs = lds;               // W + 8 doubles; xs[W] == 0 (padding target)
   double* acc = lds + (W + 8);    // n_acc = PR + extra doubles
+  // batched: KP planes of (W + 8) pairs, then KP planes of n_acc pairs
+  v2d* xs2 = reinterpret_cast<v2d*>(lds);
+  v2d* acc2 = xs2 + KP * (W + 8);
+  const int xplane = W + 8;
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
@@ -198,8 +243,14 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   const int64_t row0 = (int64_t)panel * PR;
   const int rows_here = (int)((R - row0 < PR) ? (R - row0) : PR);
 
-  for (int r = tid; r < n_acc; r += TILE_THREADS) acc[r] = 0.;
-  if (tid < 8) xs[W + tid] = 0.;
+  if constexpr (KP > 0) {
+    const v2d zero2 = {0., 0.};
+    for (int r = tid; r < KP * n_acc; r += TILE_THREADS) acc2[r] = zero2;
+    if (tid < 8 * KP) xs2[(tid >> 3) * xplane + W + (tid & 7)] = zero2;
+  } else {
+    for (int r = tid; r < n_acc; r += TILE_THREADS) acc[r] = 0.;
+    if (tid < 8) xs[W + tid] = 0.;
+  }
 
   constexpr int BATCH = VALS ? BATCH_VAL : BATCH_BIN;  // steps per ring slot
   constexpr int RING = VALS ? 2 : BBX_RING_BIN;  // slots: RING-1 batches in flight
@@ -246,6 +297,15 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   unsigned rid[RING];
   unsigned info[RING];
   double a0 = 0., a1 = 0., b0 = 0., b1 = 0.;
+  constexpr int KPA = KP > 0 ? KP : 1;
+  v2d A0[KPA], A1[KPA], B0[KPA], B1[KPA];
+#pragma unroll
+  for (int q = 0; q < KPA; ++q) {
+    A0[q] = v2d{0., 0.};
+    A1[q] = v2d{0., 0.};
+    B0[q] = v2d{0., 0.};
+    B1[q] = v2d{0., 0.};
+  }
   // BBX_TILED_DEBUG: per-wave cycle stamps (start, time in tile switches,
   // end of the stream loop, end of the kernel); dbg is null in production.
   // 32-bit tick counts (durations only: s_memtime bases differ across XCDs)
@@ -339,49 +399,72 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
             // switch, ~1 us): 16-byte lane loads where the source is 16-byte
             // aligned (8-byte accesses reach ~0.6x the rate), pairs of doubles
             // per thread, otherwise one double per lane and load.
-            constexpr int FILL_PAIRS = (FILL_UNROLL + 1) / 2;
-            v2d fp[FILL_PAIRS];
-            // (WIDE is chosen by the launcher: x and W * 8 are 16-byte aligned)
-            constexpr bool wide = WIDE;
-            if (wide) {
+            if constexpr (KP > 0) {
+              // batched: the interleaved input is 16-byte aligned by
+              // construction; element m = j * KP + q of the slice goes to
+              // plane q, slot j
+              v2d fk[FILL_K_PAIRS];
+              const v2d* gx = reinterpret_cast<const v2d*>(x) + col0 * KP;
+              const int m_here = cols_here * KP, m_all = W * KP;
 #pragma unroll
-              for (int u = 0; u < FILL_PAIRS; ++u) {
-                const int j = 2 * (tid + u * TILE_THREADS);
-                if (j + 1 < cols_here && !(ablate & 2)) {
-                  fp[u] = *reinterpret_cast<const v2d*>(x + col0 + j);
-                } else {
-                  fp[u].x = (j < cols_here && !(ablate & 2)) ? x[col0 + j] : 0.;
-                  fp[u].y = 0.;
+              for (int u = 0; u < FILL_K_PAIRS; ++u) {
+                const int m = tid + u * TILE_THREADS;
+                if (m < m_here && !(ablate & 2)) fk[u] = gx[m];
+                else fk[u] = v2d{0., 0.};
+              }
+              if (!(ablate & 4)) __syncthreads();
+              if (dbg) t_skew += (unsigned)__builtin_amdgcn_s_memtime() - t_sw0;
+              __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+#pragma unroll
+              for (int u = 0; u < FILL_K_PAIRS; ++u) {
+                const int m = tid + u * TILE_THREADS;
+                if (m < m_all) xs2[(m % KP) * xplane + m / KP] = fk[u];
+              }
+            } else {
+              constexpr int FILL_PAIRS = (FILL_UNROLL + 1) / 2;
+              v2d fp[FILL_PAIRS];
+              // (WIDE is chosen by the launcher: x and W * 8 are 16-byte aligned)
+              constexpr bool wide = WIDE;
+              if (wide) {
+  #pragma unroll
+                for (int u = 0; u < FILL_PAIRS; ++u) {
+                  const int j = 2 * (tid + u * TILE_THREADS);
+                  if (j + 1 < cols_here && !(ablate & 2)) {
+                    fp[u] = *reinterpret_cast<const v2d*>(x + col0 + j);
+                  } else {
+                    fp[u].x = (j < cols_here && !(ablate & 2)) ? x[col0 + j] : 0.;
+                    fp[u].y = 0.;
+                  }
+                }
+              } else {
+  #pragma unroll
+                for (int u = 0; u < FILL_PAIRS; ++u) {
+                  const int j0 = tid + (2 * u) * TILE_THREADS;
+                  const int j1 = tid + (2 * u + 1) * TILE_THREADS;
+                  fp[u].x = (j0 < cols_here && !(ablate & 2)) ? x[col0 + j0] : 0.;
+                  fp[u].y = (j1 < cols_here && !(ablate & 2)) ? x[col0 + j1] : 0.;
                 }
               }
-            } else {
-#pragma unroll
-              for (int u = 0; u < FILL_PAIRS; ++u) {
-                const int j0 = tid + (2 * u) * TILE_THREADS;
-                const int j1 = tid + (2 * u + 1) * TILE_THREADS;
-                fp[u].x = (j0 < cols_here && !(ablate & 2)) ? x[col0 + j0] : 0.;
-                fp[u].y = (j1 < cols_here && !(ablate & 2)) ? x[col0 + j1] : 0.;
-              }
-            }
-            if (!(ablate & 4))
-              __syncthreads();  // every wave is done with the previous slice
-            if (dbg) t_skew += (unsigned)__builtin_amdgcn_s_memtime() - t_sw0;
-            // one explicit wait for the slice values on every path, so that no
-            // compiler-visible load is left "maybe pending" inside the loop
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
-            if (wide) {
-#pragma unroll
-              for (int u = 0; u < FILL_PAIRS; ++u) {
-                const int j = 2 * (tid + u * TILE_THREADS);
-                if (j < W) *reinterpret_cast<v2d*>(xs + j) = fp[u];  // W even
-              }
-            } else {
-#pragma unroll
-              for (int u = 0; u < FILL_PAIRS; ++u) {
-                const int j0 = tid + (2 * u) * TILE_THREADS;
-                const int j1 = tid + (2 * u + 1) * TILE_THREADS;
-                if (j0 < W) xs[j0] = fp[u].x;
-                if (j1 < W) xs[j1] = fp[u].y;
+              if (!(ablate & 4))
+                __syncthreads();  // every wave is done with the previous slice
+              if (dbg) t_skew += (unsigned)__builtin_amdgcn_s_memtime() - t_sw0;
+              // one explicit wait for the slice values on every path, so that no
+              // compiler-visible load is left "maybe pending" inside the loop
+              __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+              if (wide) {
+  #pragma unroll
+                for (int u = 0; u < FILL_PAIRS; ++u) {
+                  const int j = 2 * (tid + u * TILE_THREADS);
+                  if (j < W) *reinterpret_cast<v2d*>(xs + j) = fp[u];  // W even
+                }
+              } else {
+  #pragma unroll
+                for (int u = 0; u < FILL_PAIRS; ++u) {
+                  const int j0 = tid + (2 * u) * TILE_THREADS;
+                  const int j1 = tid + (2 * u + 1) * TILE_THREADS;
+                  if (j0 < W) xs[j0] = fp[u].x;
+                  if (j1 < W) xs[j1] = fp[u].y;
+                }
               }
             }
             if (!(ablate & 4)) __syncthreads();
@@ -395,15 +478,30 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
               if (u < cntk) {
                 if (ablate & 1)
                   a0 += (double)(e[k][u].x ^ e[k][u].y ^ e[k][u].z ^ e[k][u].w);
+                else if constexpr (KP > 0)
+                  step_accumulate_k<VALS, KP>(xs2, xplane, e[k][u], ev[k][u],
+                                              A0, A1, B0, B1);
                 else
                   step_accumulate<VALS>(xs, e[k][u], ev[k][u], a0, a1, b0, b1);
               }
             if (inf & BD_LAST) {
               const unsigned rr = rid[k];
               const unsigned ra = rr & 0xFFFFu, rb = rr >> 16;
-              if (ra != NO_ROW) acc[ra] += a0 + a1;
-              if (rb != NO_ROW) acc[rb] += b0 + b1;
-              a0 = a1 = b0 = b1 = 0.;
+              if constexpr (KP > 0) {
+#pragma unroll
+                for (int q = 0; q < KP; ++q) {
+                  if (ra != NO_ROW) acc2[q * n_acc + ra] += A0[q] + A1[q];
+                  if (rb != NO_ROW) acc2[q * n_acc + rb] += B0[q] + B1[q];
+                  A0[q] = v2d{0., 0.};
+                  A1[q] = v2d{0., 0.};
+                  B0[q] = v2d{0., 0.};
+                  B1[q] = v2d{0., 0.};
+                }
+              } else {
+                if (ra != NO_ROW) acc[ra] += a0 + a1;
+                if (rb != NO_ROW) acc[rb] += b0 + b1;
+                a0 = a1 = b0 = b1 = 0.;
+              }
             }
           }
           BBX_ISSUE(k);
@@ -433,94 +531,217 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
 #undef BBX_ISSUE
 #undef BBX_WAIT
   if (dbg) t_loop = (unsigned)__builtin_amdgcn_s_memtime() - t_start;
-  // Everything the epilogue reads from memory and that does not depend on the
-  // accumulators is requested NOW, before the wave joins the final barrier:
-  // the round trip (the row scale is an HBM-resident n-vector) overlaps the
-  // wait for the slowest wave instead of following it.
-  constexpr int EPI_UNROLL = TILE_PR_MAX / TILE_THREADS;
-  double rs_pre[EPI_UNROLL];
-  double cp_pre[NPART / WAVE];
-  double x0_pre = 0.;
-  if (out) {
+  if constexpr (KP > 0) {
+    // ---- batched epilogue: the single-chain one below, once per column
+    constexpr int EPI_K = (TILE_PR_MAX / K) / TILE_THREADS;
+    double rs_pre[EPI_K][K];
+    double cp_pre[K][NPART / WAVE];
+    double x0_pre[K];
+    if (out_k.p[0]) {
 #pragma unroll
-    for (int u = 0; u < EPI_UNROLL; ++u) {
-      const int r = tid + u * TILE_THREADS;
-      rs_pre[u] = (rowscale && r < rows_here) ? rowscale[row0 + r] : 1.;
-    }
+      for (int u = 0; u < EPI_K; ++u) {
+        const int r = tid + u * TILE_THREADS;
 #pragma unroll
-    for (int k = 0; k < NPART / WAVE; ++k)
-      cp_pre[k] = c_part ? c_part[lane + k * WAVE] : 0.;
-    if (x0_ptr) x0_pre = *x0_ptr;
-  }
-  __syncthreads();
-  {  // fold the chunk accumulators of split rows, fixed order
-    const int f0 = panel_fold[panel], f1 = panel_fold[panel + 1];
-    for (int f = f0 + tid; f < f1; f += TILE_THREADS) {
-      const FoldDesc fd = folds[f];
-      double v = acc[fd.row];
-      for (int c = 0; c < fd.count; ++c) v += acc[fd.first + c];
-      acc[fd.row] = v;
-    }
-    if (f1 > f0) __syncthreads();
-  }
-  if (out) {
-    // direct epilogue: c = x0 - sum(c_part), summed once in a fixed order
-    if (tid < WAVE) {
-      double cs = 0.;
-      if (c_part) {
-#pragma unroll
-        for (int k = 0; k < NPART / WAVE; ++k) cs += cp_pre[k];
-        cs = wave_allsum(cs);
+        for (int c = 0; c < K; ++c)
+          rs_pre[u][c] = (rowscale_k.p[c] && r < rows_here)
+                             ? rowscale_k.p[c][row0 + r] : 1.;
       }
-      if (tid == 0) xs[0] = x0_pre - cs;
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+#pragma unroll
+        for (int k = 0; k < NPART / WAVE; ++k)
+          cp_pre[c][k] = c_part ? c_part[c * part_stride + lane + k * WAVE] : 0.;
+        x0_pre[c] = x0_ptr ? x0_ptr[c] : 0.;
+      }
     }
     __syncthreads();
-    const double c = xs[0];
-    double tsum = 0., t2sum = 0.;
+    {  // fold the chunk accumulators of split rows, fixed order
+      const int f0 = panel_fold[panel], f1 = panel_fold[panel + 1];
+      for (int f = f0 + tid; f < f1; f += TILE_THREADS) {
+        const FoldDesc fd = folds[f];
 #pragma unroll
-    for (int u = 0; u < EPI_UNROLL; ++u) {
-      const int r = tid + u * TILE_THREADS;
-      if (r < rows_here) {
-        const double t = c + acc[r];
-        double v = t;
-        if (rowscale) v *= rs_pre[u];
-        out[row0 + r] = v;
-        tsum += v;
-        t2sum += v * t;
-      }
-    }
-    if (out_sum_part) {
-      // partial sum of this panel's outputs (feeds the intercept / centring
-      // terms of the following Tdot); fixed order: lanes, then waves.
-      // twt_off != 0: also the partial of sum_i rowscale_i t_i^2 = <t, Omega t>,
-      // the data part of the CG curvature p.Ap (cg_sampler.hip), written
-      // twt_off doubles after the sum's slot.
-      tsum = wave_allsum(tsum);
-      t2sum = wave_allsum(t2sum);
-      __syncthreads();
-      if (lane == 0) {
-        xs[wave] = tsum;
-        xs[TILE_WAVES + wave] = t2sum;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        double tot = 0., tot2 = 0.;
-        for (int wv = 0; wv < TILE_WAVES; ++wv) {
-          tot += xs[wv];
-          tot2 += xs[TILE_WAVES + wv];
+        for (int q = 0; q < KP; ++q) {
+          v2d v = acc2[q * n_acc + fd.row];
+          for (int c = 0; c < fd.count; ++c) v += acc2[q * n_acc + fd.first + c];
+          acc2[q * n_acc + fd.row] = v;
         }
-        out_sum_part[blockIdx.x] = tot;
-        if (twt_off) out_sum_part[twt_off + (int)blockIdx.x] = tot2;
       }
-      // consumers add NPART slots: the first workgroup clears the unused ones
-      if (blockIdx.x == 0 && (int)gridDim.x + tid < NPART) {
-        out_sum_part[gridDim.x + tid] = 0.;
-        if (twt_off) out_sum_part[twt_off + (int)gridDim.x + tid] = 0.;
+      if (f1 > f0) __syncthreads();
+    }
+    double* scratch = lds;  // the slices are dead: 3 K + 2 K TILE_WAVES doubles
+    if (out_k.p[0]) {
+      if (tid < WAVE) {
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+          double cs = 0.;
+          if (c_part) {
+#pragma unroll
+            for (int k = 0; k < NPART / WAVE; ++k) cs += cp_pre[c][k];
+            cs = wave_allsum(cs);
+          }
+          if (tid == 0) scratch[c] = x0_pre[c] - cs;
+        }
+      }
+      __syncthreads();
+      double cc[K], tsum[K], t2sum[K];
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        cc[c] = scratch[c];
+        tsum[c] = 0.;
+        t2sum[c] = 0.;
+      }
+#pragma unroll
+      for (int u = 0; u < EPI_K; ++u) {
+        const int r = tid + u * TILE_THREADS;
+        if (r < rows_here) {
+#pragma unroll
+          for (int q = 0; q < KP; ++q) {
+            const v2d a = acc2[q * n_acc + r];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const int c = 2 * q + hh;
+              const double t = cc[c] + (hh ? a.y : a.x);
+              double v = t;
+              if (rowscale_k.p[c]) v *= rs_pre[u][c];
+              out_k.p[c][(row0 + r) * out_stride] = v;
+              tsum[c] += v;
+              t2sum[c] += v * t;
+            }
+          }
+        }
+      }
+      if (out_sum_part) {
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+          tsum[c] = wave_allsum(tsum[c]);
+          t2sum[c] = wave_allsum(t2sum[c]);
+        }
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+          for (int c = 0; c < K; ++c) {
+            scratch[K + (2 * c) * TILE_WAVES + wave] = tsum[c];
+            scratch[K + (2 * c + 1) * TILE_WAVES + wave] = t2sum[c];
+          }
+        }
+        __syncthreads();
+        if (tid < K) {
+          double tot = 0., tot2 = 0.;
+          for (int wv = 0; wv < TILE_WAVES; ++wv) {
+            tot += scratch[K + (2 * tid) * TILE_WAVES + wv];
+            tot2 += scratch[K + (2 * tid + 1) * TILE_WAVES + wv];
+          }
+          out_sum_part[tid * part_stride + (int)blockIdx.x] = tot;
+          if (twt_off)
+            out_sum_part[tid * part_stride + twt_off + (int)blockIdx.x] = tot2;
+        }
+        // consumers add NPART slots: the first workgroup clears the unused ones
+        if (blockIdx.x == 0 && (int)gridDim.x + tid < NPART) {
+#pragma unroll
+          for (int c = 0; c < K; ++c) {
+            out_sum_part[c * part_stride + gridDim.x + tid] = 0.;
+            if (twt_off)
+              out_sum_part[c * part_stride + twt_off + (int)gridDim.x + tid] = 0.;
+          }
+        }
+      }
+    } else {
+      v2d* dst = reinterpret_cast<v2d*>(slab) + ((int64_t)group * R + row0) * KP;
+      for (int r = tid; r < rows_here; r += TILE_THREADS) {
+#pragma unroll
+        for (int q = 0; q < KP; ++q) dst[(int64_t)r * KP + q] = acc2[q * n_acc + r];
       }
     }
   } else {
-    double* dst = slab + (int64_t)group * R + row0;
-    for (int r = tid; r < rows_here; r += TILE_THREADS) dst[r] = acc[r];
+    // Everything the epilogue reads from memory and that does not depend on the
+    // accumulators is requested NOW, before the wave joins the final barrier:
+    // the round trip (the row scale is an HBM-resident n-vector) overlaps the
+    // wait for the slowest wave instead of following it.
+    constexpr int EPI_UNROLL = TILE_PR_MAX / TILE_THREADS;
+    double rs_pre[EPI_UNROLL];
+    double cp_pre[NPART / WAVE];
+    double x0_pre = 0.;
+    if (out) {
+  #pragma unroll
+      for (int u = 0; u < EPI_UNROLL; ++u) {
+        const int r = tid + u * TILE_THREADS;
+        rs_pre[u] = (rowscale && r < rows_here) ? rowscale[row0 + r] : 1.;
+      }
+  #pragma unroll
+      for (int k = 0; k < NPART / WAVE; ++k)
+        cp_pre[k] = c_part ? c_part[lane + k * WAVE] : 0.;
+      if (x0_ptr) x0_pre = *x0_ptr;
+    }
+    __syncthreads();
+    {  // fold the chunk accumulators of split rows, fixed order
+      const int f0 = panel_fold[panel], f1 = panel_fold[panel + 1];
+      for (int f = f0 + tid; f < f1; f += TILE_THREADS) {
+        const FoldDesc fd = folds[f];
+        double v = acc[fd.row];
+        for (int c = 0; c < fd.count; ++c) v += acc[fd.first + c];
+        acc[fd.row] = v;
+      }
+      if (f1 > f0) __syncthreads();
+    }
+    if (out) {
+      // direct epilogue: c = x0 - sum(c_part), summed once in a fixed order
+      if (tid < WAVE) {
+        double cs = 0.;
+        if (c_part) {
+  #pragma unroll
+          for (int k = 0; k < NPART / WAVE; ++k) cs += cp_pre[k];
+          cs = wave_allsum(cs);
+        }
+        if (tid == 0) xs[0] = x0_pre - cs;
+      }
+      __syncthreads();
+      const double c = xs[0];
+      double tsum = 0., t2sum = 0.;
+  #pragma unroll
+      for (int u = 0; u < EPI_UNROLL; ++u) {
+        const int r = tid + u * TILE_THREADS;
+        if (r < rows_here) {
+          const double t = c + acc[r];
+          double v = t;
+          if (rowscale) v *= rs_pre[u];
+          out[row0 + r] = v;
+          tsum += v;
+          t2sum += v * t;
+        }
+      }
+      if (out_sum_part) {
+        // partial sum of this panel's outputs (feeds the intercept / centring
+        // terms of the following Tdot); fixed order: lanes, then waves.
+        // twt_off != 0: also the partial of sum_i rowscale_i t_i^2 = <t, Omega t>,
+        // the data part of the CG curvature p.Ap (cg_sampler.hip), written
+        // twt_off doubles after the sum's slot.
+        tsum = wave_allsum(tsum);
+        t2sum = wave_allsum(t2sum);
+        __syncthreads();
+        if (lane == 0) {
+          xs[wave] = tsum;
+          xs[TILE_WAVES + wave] = t2sum;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          double tot = 0., tot2 = 0.;
+          for (int wv = 0; wv < TILE_WAVES; ++wv) {
+            tot += xs[wv];
+            tot2 += xs[TILE_WAVES + wv];
+          }
+          out_sum_part[blockIdx.x] = tot;
+          if (twt_off) out_sum_part[twt_off + (int)blockIdx.x] = tot2;
+        }
+        // consumers add NPART slots: the first workgroup clears the unused ones
+        if (blockIdx.x == 0 && (int)gridDim.x + tid < NPART) {
+          out_sum_part[gridDim.x + tid] = 0.;
+          if (twt_off) out_sum_part[twt_off + (int)gridDim.x + tid] = 0.;
+        }
+      }
+    } else {
+      double* dst = slab + (int64_t)group * R + row0;
+      for (int r = tid; r < rows_here; r += TILE_THREADS) dst[r] = acc[r];
+    }
   }
   if (dbg && lane == 0) {
     unsigned long long* o = dbg + ((size_t)blockIdx.x * TILE_WAVES + wave) * 4;
@@ -563,12 +784,15 @@ static int upload(DevMem& dst, const void* src, size_t bytes) {
 // Builds one orientation on the host (tiled_layout.cpp) and moves it to HBM.
 static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
                      const int32_t* rowptr, const int32_t* colidx,
-                     const double* vals, bool transpose) {
+                     const double* vals, bool transpose, int K) {
   TiledHost host;
   std::string err;
-  if (build_tiled_host(R, C, nnz, rowptr, colidx, vals,
-                       TiledOptions::from_env(transpose), &host, &err) != 0)
+  TiledOptions opt = TiledOptions::from_env(transpose);
+  opt.chains = K;
+  if (K > 1) opt.force_PR = opt.force_G = 0;  // overrides tune the K = 1 layout
+  if (build_tiled_host(R, C, nnz, rowptr, colidx, vals, opt, &host, &err) != 0)
     return fail(BBX_ERR_INVALID, err);
+  m.K = host.K;
   m.R = host.R;
   m.C = host.C;
   m.nnz = host.nnz;
@@ -597,22 +821,27 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
                  host.wave_desc.size() * sizeof(int32_t)));
   BBX_TRY(upload(m.rowids, host.rowids.data(),
                  host.rowids.size() * sizeof(uint32_t)));
-  BBX_TRY(m.slab.alloc(sizeof(double) * (size_t)m.G * (size_t)R));
+  BBX_TRY(m.slab.alloc(sizeof(double) * (size_t)m.G * (size_t)R * (size_t)m.K));
   return BBX_OK;
 }
 
 static size_t lds_bytes(const TiledMatrix& m) {
-  return sizeof(double) * ((size_t)m.W + 8 + (size_t)m.PR + (size_t)m.n_extra);
+  return sizeof(double) * (size_t)m.K *
+         ((size_t)m.W + 8 + (size_t)m.PR + (size_t)m.n_extra);
 }
 
 void destroy_tiled(bbx_design* h) {
   delete static_cast<TiledPair*>(h->tiled);
   h->tiled = nullptr;
+  for (void*& t : h->tiled_k) {
+    delete static_cast<TiledPair*>(t);
+    t = nullptr;
+  }
 }
 
-// Builds both orientations from the device CSR arrays already in the handle
-// (CSR of X and CSR of X^T) through a host pass.
-int build_tiled(bbx_design* h) {
+// Builds both orientations from the device CSR arrays in the handle (CSR of X
+// and CSR of X^T) through a host pass, sized for K right-hand sides.
+static int build_tiled_pair(bbx_design* h, int K, void** slot) {
   const int64_t n = h->n, p = h->p, nnz = h->nnz;
   std::vector<int32_t> rowptr((size_t)n + 1), colidx((size_t)std::max<int64_t>(nnz, 1));
   std::vector<double> vals;
@@ -628,9 +857,9 @@ int build_tiled(bbx_design* h) {
   }
   TiledPair* tp = new (std::nothrow) TiledPair();
   if (!tp) return fail(BBX_ERR_INVALID, "out of host memory");
-  h->tiled = tp;
+  *slot = tp;  // owned by the handle from here on (destroy_tiled)
   BBX_TRY(build_one(tp->x, n, p, nnz, rowptr.data(), colidx.data(),
-                    h->binary ? nullptr : vals.data(), false));
+                    h->binary ? nullptr : vals.data(), false, K));
   // transpose orientation from the CSR of X^T built on the device
   rowptr.assign((size_t)p + 1, 0);
   BBX_HIP(hipMemcpy(rowptr.data(), h->t_indptr.ptr, sizeof(int32_t) * (size_t)(p + 1),
@@ -642,34 +871,62 @@ int build_tiled(bbx_design* h) {
     BBX_HIP(hipMemcpy(vals.data(), h->t_data.ptr, sizeof(double) * (size_t)nnz,
                       hipMemcpyDeviceToHost));
   BBX_TRY(build_one(tp->xt, p, n, nnz, rowptr.data(), colidx.data(),
-                    h->binary ? nullptr : vals.data(), true));
+                    h->binary ? nullptr : vals.data(), true, K));
   for (const TiledMatrix* m : {&tp->x, &tp->xt}) {
     const size_t lb = lds_bytes(*m);
     if (lb > (size_t)TILE_LDS_BYTES)
       return fail(BBX_ERR_INVALID, "tile does not fit in LDS");
   }
-#define BBX_TILED_ATTR(VV, WW)                                                 \
-  BBX_HIP(hipFuncSetAttribute(                                                 \
-      reinterpret_cast<const void*>(&tiled_spmv_kernel<VV, WW>),               \
-      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-  BBX_TILED_ATTR(false, false);
-  BBX_TILED_ATTR(false, true);
-  BBX_TILED_ATTR(true, false);
-  BBX_TILED_ATTR(true, true);
-#undef BBX_TILED_ATTR
-  // The reference-layout arrays are only needed to build; free the big ones.
-  h->indices.release();
-  h->data.release();
-  h->t_indices.release();
-  h->t_data.release();
   return BBX_OK;
+}
+
+int build_tiled(bbx_design* h) {
+  BBX_TRY(build_tiled_pair(h, 1, &h->tiled));
+#define BBX_TILED_ATTR(VV, WW, KK)                                             \
+  BBX_HIP(hipFuncSetAttribute(                                                 \
+      reinterpret_cast<const void*>(&tiled_spmv_kernel<VV, WW, KK>),           \
+      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+  BBX_TILED_ATTR(false, false, 0);
+  BBX_TILED_ATTR(false, true, 0);
+  BBX_TILED_ATTR(true, false, 0);
+  BBX_TILED_ATTR(true, true, 0);
+  BBX_TILED_ATTR(false, true, 1);
+  BBX_TILED_ATTR(false, true, 2);
+  BBX_TILED_ATTR(true, true, 1);
+#undef BBX_TILED_ATTR
+  // The reference-layout index arrays stay in HBM (0.8 GB at 1M x 50k, next to
+  // 288 GB): a layout sized for K batched chains is built from them on first
+  // use (ensure_tiled_k), and storage = 'csr' cross-checks need them anyway.
+  return BBX_OK;
+}
+
+// The layout sized for K right-hand sides (K = 2, 4), built on first use.
+int ensure_tiled_k(bbx_design* h, int K) {
+  if (!h->sparse || h->format != BBX_FORMAT_TILED || !h->tiled)
+    return fail(BBX_ERR_STATE, "batched chains need the tiled format");
+  if (K == 1) return BBX_OK;
+  if (K != 2 && K != 4) return fail(BBX_ERR_INVALID, "K must be 1, 2 or 4");
+  void** slot = &h->tiled_k[K == 2 ? 0 : 1];
+  if (*slot) return BBX_OK;
+  const int st = build_tiled_pair(h, K, slot);
+  if (st < 0) {
+    delete static_cast<TiledPair*>(*slot);
+    *slot = nullptr;
+  }
+  return st;
+}
+
+static const TiledPair* tiled_pair_for(const bbx_design* h, int K) {
+  return static_cast<const TiledPair*>(
+      K == 1 ? h->tiled : h->tiled_k[K == 2 ? 0 : 1]);
 }
 
 static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                         const double* c_part, const double* x0_ptr,
                         const double* rowscale, double* out, double* slab,
                         double* out_sum_part, hipEvent_t ev_begin = nullptr,
-                        hipEvent_t ev_end = nullptr, int twt_off = 0) {
+                        hipEvent_t ev_end = nullptr, int twt_off = 0,
+                        const TiledBatchArgs* ba = nullptr) {
   const unsigned grid = (unsigned)(m.n_panel * m.G);
   const size_t lb = lds_bytes(m);
   // Instrumented builds only (-DBBX_TILED_INSTRUMENT=1; the product library
@@ -694,8 +951,10 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
       dbg = dbg_buf;
     ++dbg_count;
   }
-#define BBX_TILED_LAUNCH_W(VV, WW, VALPTR)                                     \
-  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, WW>), dim3(grid),               \
+  static const TiledBatchArgs no_batch{};
+  const TiledBatchArgs& bb = ba ? *ba : no_batch;
+#define BBX_TILED_LAUNCH_W(VV, WW, KK, VALPTR)                                 \
+  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, WW, KK>), dim3(grid),           \
                      dim3(TILE_THREADS), (unsigned)lb, h->stream, ev_begin,    \
                      ev_end, 0u, m.R, m.C, m.W, m.PR,                          \
                      m.G, (m.n_block + m.G - 1) / m.G,                         \
@@ -704,18 +963,28 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                      m.ids.as<uint4>(), VALPTR, x, c_part, x0_ptr, rowscale,   \
                      out, slab, m.PR + m.n_extra,                              \
                      m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),       \
-                     out_sum_part, twt_off, ablate, dbg, h->skip_flag)
+                     out_sum_part, twt_off, ablate, dbg, h->skip_flag,         \
+                     bb.rowscale, bb.out, bb.out_stride, bb.part_stride)
 #define BBX_TILED_LAUNCH(VV, VALPTR)                                           \
   do {                                                                         \
-    if (wide) BBX_TILED_LAUNCH_W(VV, true, VALPTR);                            \
-    else BBX_TILED_LAUNCH_W(VV, false, VALPTR);                                \
+    if (m.K == 2) BBX_TILED_LAUNCH_W(VV, true, 1, VALPTR);                \
+    else if (wide) BBX_TILED_LAUNCH_W(VV, true, 0, VALPTR);                    \
+    else BBX_TILED_LAUNCH_W(VV, false, 0, VALPTR);                             \
   } while (0)
   // 16-byte slice loads need every slice start 16-byte aligned: W is a multiple
   // of 64 doubles, so it is the alignment of x itself that decides (inside the
   // CG loop x is an internal buffer placed accordingly; a caller's v + 1 of a
   // design with intercept is not, and takes the 8-byte path)
   const bool wide = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
-  if (m.has_vals)
+  if (m.K > 1 && !wide)
+    return fail(BBX_ERR_INVALID, "batched input must be 16-byte aligned");
+  // (four valued right-hand sides do not fit the 128-VGPR budget of a
+  // 1024-thread workgroup without scratch: valued designs batch two chains)
+  if (m.K == 4 && m.has_vals)
+    return fail(BBX_ERR_INVALID, "valued designs batch at most 2 chains");
+  if (m.K == 4)
+    BBX_TILED_LAUNCH_W(false, true, 2, nullptr);
+  else if (m.has_vals)
     BBX_TILED_LAUNCH(true, m.vals.as<double>());
   else
     BBX_TILED_LAUNCH(false, nullptr);
@@ -799,6 +1068,130 @@ int launch_tdot_tiled(bbx_design* h, const double* d_w,
                               d_out);
 }
 
+// ---- batched products (K right-hand sides, one pass over the id stream)
+
+// t_c[r] = rowscale_c[r] * (c_c + sum_g slab[g][r][c])   (dot with G > 1), plus
+// the per-chain partials of sum(t_c) and <t_c, Omega_c t_c>.  Grid = NPART.
+template <int K>
+__global__ __launch_bounds__(256) void tiled_dot_finalize_k_kernel(
+    int64_t R, int G, const double* __restrict__ slab,
+    const double* __restrict__ c_part, const double* x0_ptr,
+    ChainPtrs rowscale, ChainOut out, int out_stride, int part_stride,
+    double* __restrict__ sum_part, int twt_off) {
+  __shared__ double s_c[K];
+  __shared__ double s_w[2 * K][256 / WAVE];
+  if (threadIdx.x < K) {
+    double c = x0_ptr ? x0_ptr[threadIdx.x] : 0.;
+    if (c_part) {
+      double cs = 0.;
+      for (int k = 0; k < NPART; ++k) cs += c_part[threadIdx.x * part_stride + k];
+      c -= cs;
+    }
+    s_c[threadIdx.x] = c;
+  }
+  __syncthreads();
+  double tsum[K], t2sum[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) tsum[c] = t2sum[c] = 0.;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < R;
+       r += (int64_t)gridDim.x * 256) {
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      double a = 0.;
+      for (int g = 0; g < G; ++g) a += slab[((int64_t)g * R + r) * K + c];
+      const double t = s_c[c] + a;
+      double v = t;
+      if (rowscale.p[c]) v *= rowscale.p[c][r];
+      out.p[c][r * out_stride] = v;
+      tsum[c] += v;
+      t2sum[c] += v * t;
+    }
+  }
+  if (!sum_part) return;
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    const double a = wave_allsum(tsum[c]), b = wave_allsum(t2sum[c]);
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+      s_w[2 * c][threadIdx.x / WAVE] = a;
+      s_w[2 * c + 1][threadIdx.x / WAVE] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double a = 0., b = 0.;
+    for (int k = 0; k < 256 / WAVE; ++k) {
+      a += s_w[2 * threadIdx.x][k];
+      b += s_w[2 * threadIdx.x + 1][k];
+    }
+    sum_part[threadIdx.x * part_stride + blockIdx.x] = a;
+    if (twt_off) sum_part[threadIdx.x * part_stride + twt_off + blockIdx.x] = b;
+  }
+}
+
+int launch_dot_tiled_k(bbx_design* h, int K, const double* d_v,
+                       const double* d_c_part, const TiledBatchArgs& ba,
+                       double* d_sum_part, int twt_off) {
+  const TiledPair* tp = tiled_pair_for(h, K);
+  if (!tp || K < 2) return fail(BBX_ERR_STATE, "batched layout not built");
+  const TiledMatrix& m = tp->x;
+  const double* x = d_v + (size_t)h->intercept * K;
+  const double* x0 = h->intercept ? d_v : nullptr;
+  h->n_dot += 1;
+  if (m.G == 1 && m.n_panel <= NPART) {
+    hipEvent_t ea, eb;
+    BBX_TRY(timer_arm(h, 0, &ea, &eb));
+    return launch_tiled(h, m, x, d_c_part, x0, nullptr, nullptr, nullptr,
+                        d_sum_part, ea, eb, twt_off, &ba);
+  }
+  // several column groups (or more panels than partial slots): slabs, then
+  // the finalize kernel
+  BBX_TRY(timer_begin(h, 0));
+  TiledBatchArgs slab_only = ba;
+  slab_only.out = ChainOut{};
+  BBX_TRY(launch_tiled(h, m, x, nullptr, nullptr, nullptr, nullptr,
+                       m.slab.as<double>(), nullptr, nullptr, nullptr, 0,
+                       &slab_only));
+#define BBX_DOT_FIN(KK)                                                        \
+  hipLaunchKernelGGL(tiled_dot_finalize_k_kernel<KK>, dim3(NPART), dim3(256),  \
+                     0, h->stream, m.R, m.G, m.slab.as<double>(), d_c_part,    \
+                     x0, ba.rowscale, ba.out, ba.out_stride, ba.part_stride,   \
+                     d_sum_part, twt_off)
+  if (K == 2) BBX_DOT_FIN(2); else BBX_DOT_FIN(4);
+#undef BBX_DOT_FIN
+  BBX_HIP(hipGetLastError());
+  return timer_end(h, 0);
+}
+
+int launch_tdot_tiled_k(bbx_design* h, int K, const double* d_w,
+                        const double** slab, int* G) {
+  const TiledPair* tp = tiled_pair_for(h, K);
+  if (!tp || K < 2) return fail(BBX_ERR_STATE, "batched layout not built");
+  const TiledMatrix& m = tp->xt;
+  h->n_tdot += 1;
+  hipEvent_t ea, eb;
+  BBX_TRY(timer_arm(h, 1, &ea, &eb));
+  TiledBatchArgs none;
+  BBX_TRY(launch_tiled(h, m, d_w, nullptr, nullptr, nullptr, nullptr,
+                       m.slab.as<double>(), nullptr, ea, eb, 0, &none));
+  *slab = m.slab.as<double>();
+  *G = m.G;
+  return BBX_OK;
+}
+
+// What ONE batched launch of each product moves (the timed kernels): the id
+// stream of the K-layout + K vectors in + K vectors (dot) or G slabs of K
+// columns (Tdot) out.
+int tiled_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
+                      int64_t* tdot_bytes) {
+  const TiledPair* tp = tiled_pair_for(h, K);
+  if (!tp) return fail(BBX_ERR_STATE, "batched layout not built");
+  *dot_bytes = tp->x.stream_bytes() + 8 * (int64_t)K * (h->P + h->n) +
+               (tp->x.G > 1 ? 16 * (int64_t)K * tp->x.G * h->n : 0);
+  *tdot_bytes = tp->xt.stream_bytes() + 8 * (int64_t)K * h->n +
+                8 * (int64_t)K * tp->xt.G * h->p;
+  return BBX_OK;
+}
+
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
                        int64_t* tdot_bytes, bool timed_only) {
   const TiledPair* tp = static_cast<const TiledPair*>(h->tiled);
@@ -830,7 +1223,11 @@ int tiled_describe(const bbx_design* h, int which, int* W, int* n_block,
                    int* PR, int* G, int64_t* n_quad, int64_t* n_slice) {
   const TiledPair* tp = static_cast<const TiledPair*>(h->tiled);
   if (!tp) return fail(BBX_ERR_STATE, "tiled format not built");
-  const TiledMatrix& m = which == 0 ? tp->x : tp->xt;
+  if (which >= 2) {  // 2, 3: the K = 2 layout; 4, 5: the K = 4 layout
+    tp = tiled_pair_for(h, which < 4 ? 2 : 4);
+    if (!tp) return fail(BBX_ERR_STATE, "batched layout not built");
+  }
+  const TiledMatrix& m = (which & 1) == 0 ? tp->x : tp->xt;
   if (W) *W = m.W;
   if (n_block) *n_block = m.n_block;
   if (PR) *PR = m.PR;

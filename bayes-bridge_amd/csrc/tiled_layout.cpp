@@ -570,35 +570,48 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
   build_schedules(pb, G, vals ? BATCH_VAL : BATCH_BIN);
 }
 
+// LDS doubles one right-hand side may use: slice + 8 + accumulators + extras
+// (2 KB of the CU's LDS stay free for static use).
+static int lds_budget_per_chain(int K) {
+  return (int)((TILE_LDS_BYTES - 2048) / 8) / K;
+}
+
 // Picks (PR, G): row panels x groups of column blocks.  One workgroup runs per
 // CU (it owns the CU's LDS), so the launch should be a single round of <= 256
 // workgroups of equal work.  Cost model fitted on MI355X (profiles/,
 // DESIGN.md): a tile costs ~4.3 us of fixed time (slice refill from L2, two
 // barriers, pipeline ramp) plus ~24 ps per stored entry streamed.
+static double shape_cost(int64_t R, int64_t nnz, int n_block, int pr, int g,
+                         int K) {
+  const int64_t n_panel = (R + pr - 1) / pr;
+  const int bpg = (n_block + g - 1) / g;
+  const double n_wg = (double)n_panel * g;
+  const double rounds = std::ceil(n_wg / (double)TILE_WG_PER_ROUND);
+  const double rows = (double)std::min<int64_t>(pr, R);
+  const double tile_nnz = (double)nnz * rows / (double)R / n_block;
+  const double per_tile = 4.3 + tile_nnz * 24e-6;            // us
+  double cost = rounds * bpg * per_tile + 6.;
+  if (g > 1) cost += (double)R * g * K * 16. / 4e6;          // slab pass
+  return cost;
+}
+
 static void choose_shape(int64_t R, int64_t C, int64_t nnz, int n_block, int W,
-                         int* PR_out, int* G_out) {
+                         int K, int* PR_out, int* G_out, double* cost_out) {
   double best = 1e300;
-  int best_pr = 256, best_g = 1;
-  const int lds_rows = (int)((TILE_LDS_BYTES - 2048) / 8) - (W + 8);
+  int best_pr = 128, best_g = 1;
+  const int lds_rows = lds_budget_per_chain(K) - (W + 8);
   // (panels beyond 4096 rows only through BBX_TILED_PR[_T]: at 1M x 50k the
   // X^T geometries PR = 6272 x 96 blocks x G = 32 and PR = 5056 x 75 x 25 ran
   // the main kernel in 46.9 / 49.7 us against 48.5 us, with twice the slab
   // traffic for the epilogue kernel -- profiles/r02_ab_geometry.txt)
-  int pr_cap = TILE_PR_MAX < 4096 ? TILE_PR_MAX : 4096;
+  int pr_cap = TILE_PR_MAX / K < 4096 ? TILE_PR_MAX / K : 4096;
   if (lds_rows - 256 < pr_cap) pr_cap = lds_rows - 256;  // room for extras
   if (pr_cap < 128) pr_cap = 128;
   for (int pr = 128; pr <= pr_cap; pr += 128) {
-    const int64_t n_panel = (R + pr - 1) / pr;
     for (int g = 1; g <= n_block; ++g) {
       const int bpg = (n_block + g - 1) / g;
       if ((n_block + bpg - 1) / bpg != g) continue;  // not a distinct split
-      const double n_wg = (double)n_panel * g;
-      const double rounds = std::ceil(n_wg / (double)TILE_WG_PER_ROUND);
-      const double rows = (double)std::min<int64_t>(pr, R);
-      const double tile_nnz = (double)nnz * rows / (double)R / n_block;
-      const double per_tile = 4.3 + tile_nnz * 24e-6;            // us
-      double cost = rounds * bpg * per_tile + 6.;
-      if (g > 1) cost += (double)R * g * 16. / 4e6;              // slab pass
+      const double cost = shape_cost(R, nnz, n_block, pr, g, K);
       if (cost < best) {
         best = cost;
         best_pr = pr;
@@ -608,6 +621,7 @@ static void choose_shape(int64_t R, int64_t C, int64_t nnz, int n_block, int W,
   }
   *PR_out = best_pr;
   *G_out = best_g;
+  if (cost_out) *cost_out = best;
 }
 
 int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
@@ -623,17 +637,51 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   m.C = C;
   m.nnz = nnz;
   m.has_vals = vals != nullptr;
-  m.n_block = (int)((C + TILE_W_MAX - 1) / TILE_W_MAX);
-  if (opt.force_blocks > m.n_block) m.n_block = opt.force_blocks;
-  if (m.n_block < 1) m.n_block = 1;
-  int64_t w = (C + m.n_block - 1) / m.n_block;
-  w = (w + 63) / 64 * 64;
-  m.W = (int)w;
-  choose_shape(R, C, nnz, m.n_block, m.W, &m.PR, &m.G);
+  const int K = opt.chains;
+  if (K != 1 && K != 2 && K != 4) return fail("chains must be 1, 2 or 4");
+  m.K = K;
+  auto width_for = [&](int n_block) {
+    int64_t w = (C + n_block - 1) / n_block;
+    return (int)((w + 63) / 64 * 64);
+  };
+  if (K == 1) {
+    m.n_block = (int)((C + TILE_W_MAX - 1) / TILE_W_MAX);
+    if (opt.force_blocks > m.n_block) m.n_block = opt.force_blocks;
+    if (m.n_block < 1) m.n_block = 1;
+    m.W = width_for(m.n_block);
+    choose_shape(R, C, nnz, m.n_block, m.W, K, &m.PR, &m.G, nullptr);
+  } else {
+    // K slices and K accumulator sets share the LDS: the slice width is part
+    // of the search (a wide slice means few tile switches but short panels,
+    // i.e. more workgroups than CUs).  Candidates: every block count from the
+    // widest slice that leaves room for 128 rows + 256 extras down to slices
+    // a quarter as wide.
+    const int w_cap = (lds_budget_per_chain(K) - 8 - 128 - 256) / 64 * 64;
+    int nb_min = (int)((C + w_cap - 1) / w_cap);
+    if (nb_min < 1) nb_min = 1;
+    if (opt.force_blocks > nb_min) nb_min = opt.force_blocks;
+    const int nb_max = opt.force_blocks > 0 ? nb_min : 4 * nb_min + 4;
+    double best = 1e300;
+    for (int nb = nb_min; nb <= nb_max; ++nb) {
+      const int w = width_for(nb);
+      if (nb > nb_min && w == width_for(nb - 1)) continue;
+      int pr, g;
+      double cost;
+      choose_shape(R, C, nnz, nb, w, K, &pr, &g, &cost);
+      if (cost < best) {
+        best = cost;
+        m.n_block = nb;
+        m.W = w;
+        m.PR = pr;
+        m.G = g;
+      }
+      if (w <= 64) break;
+    }
+  }
   if (opt.force_PR > 0) m.PR = opt.force_PR;
   if (opt.force_G > 0) m.G = opt.force_G;
   if (m.PR < 64) m.PR = 64;
-  if (m.PR > TILE_PR_MAX) m.PR = TILE_PR_MAX;
+  if (m.PR > TILE_PR_MAX / K) m.PR = TILE_PR_MAX / K;
   if (m.G < 1) m.G = 1;
   if (m.G > m.n_block) m.G = m.n_block;
   {  // normalise G so that every group is non-empty
@@ -643,8 +691,7 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   m.n_panel = (int)((R + m.PR - 1) / m.PR);
   // LDS left after the vector slice and the row accumulators pays for the
   // extra accumulators of split rows (2 KB stay free for static LDS).
-  int extra_budget =
-      (int)((TILE_LDS_BYTES - 2048) / 8) - (m.W + 8) - m.PR;
+  int extra_budget = lds_budget_per_chain(K) - (m.W + 8) - m.PR;
   if (extra_budget > 8192) extra_budget = 8192;
   if (extra_budget < 0) extra_budget = 0;
   if (opt.extra_budget >= 0) extra_budget = opt.extra_budget;
@@ -692,12 +739,12 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
     }
     char line[1024];
     snprintf(line, sizeof(line),
-            "[bbx tiled %lldx%lld] W=%d blocks=%d PR=%d G=%d split T=%d "
+            "[bbx tiled %lldx%lld K=%d] W=%d blocks=%d PR=%d G=%d split T=%d "
             "extras=%d workgroups=%lld: "
             "quads=%lld (+%lld re-loaded to fill batches, %.1f%%); batches per "
             "wave: ideal %.1f, mean critical path %.1f, worst workgroup %lld "
             "(%.1f%% over ideal)\n",
-            (long long)R, (long long)C, m.W, m.n_block, m.PR, m.G, stat_T,
+            (long long)R, (long long)C, K, m.W, m.n_block, m.PR, m.G, stat_T,
             stat_extra, (long long)n_wg, (long long)quads, (long long)dup,
             100. * (double)dup / (double)std::max<int64_t>(quads, 1),
             (double)total / (double)(n_wg * TILE_WAVES),
@@ -973,12 +1020,13 @@ extern "C" {
 int bbx_layout_emulate(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
                        const int32_t* colidx, const double* vals,
                        int bank_aware, int force_PR, int force_G,
-                       int max_threads, const double* x, double* out,
+                       int max_threads, int chains, const double* x, double* out,
                        int64_t* info, double* gather_cycles) {
   bbx::TiledOptions opt;
   opt.bank_aware = bank_aware != 0;
   opt.force_PR = force_PR;
   opt.force_G = force_G;
+  opt.chains = chains > 0 ? chains : 1;
   if (max_threads > 0) opt.max_threads = max_threads;
   bbx::TiledHost m;
   std::string err;

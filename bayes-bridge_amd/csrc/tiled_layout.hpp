@@ -77,6 +77,10 @@ struct FoldDesc {
 
 // Build-time choices that the environment can override (diagnostics, A/B).
 struct TiledOptions {
+  // Right-hand sides that share one pass over the matrix (batched chains):
+  // the LDS holds K interleaved vector slices and K accumulators per row, so W
+  // and PR shrink to what K of each fit next to each other.  1, 2 or 4.
+  int chains = 1;
   int force_PR = 0;          // BBX_TILED_PR
   int force_G = 0;           // BBX_TILED_G
   int force_blocks = 0;      // number of column blocks (0: automatic)
@@ -93,6 +97,7 @@ struct TiledOptions {
 struct TiledHost {
   int64_t R = 0, C = 0, nnz = 0;
   int W = 0, n_block = 0, PR = 0, n_panel = 0, G = 0;
+  int K = 1;  // right-hand sides the geometry was sized for (TiledOptions::chains)
   bool has_vals = false;
   int64_t n_slice = 0, n_quad = 0, n_tile = 0, n_desc = 0;
   int desc_stride = 0;  // > 0: wave k's schedule starts at k * desc_stride
@@ -106,7 +111,9 @@ struct TiledHost {
   std::vector<FoldDesc> folds;
   std::vector<int32_t> panel_fold;  // [n_panel + 1]
   std::string stats;                // filled when TiledOptions::stats
-  int64_t lds_doubles() const { return (int64_t)W + 8 + PR + n_extra; }
+  int64_t lds_doubles() const {
+    return (int64_t)K * ((int64_t)W + 8 + PR + n_extra);
+  }
 };
 
 // Builds the tiled form of an R x C CSR matrix (`vals` == nullptr: every
@@ -121,7 +128,9 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
 // accumulators at the end of each slice, split rows folded in descriptor
 // order.  slab[g * R + r] = partial sum of row r over the column blocks of
 // group g -- the same additions in the same order as the kernel, so a GPU
-// launch can be compared with it bit for bit.
+// launch can be compared with it bit for bit.  (A layout sized for K > 1
+// right-hand sides is walked one right-hand side at a time: the batched kernel
+// does the same additions in the same order for each of its K columns.)
 void emulate_tiled_spmv(const TiledHost& m, const double* x,
                         std::vector<double>* slab);
 

@@ -61,6 +61,12 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-baseline-iters", type=int, default=5,
                     help="Gibbs iterations of each CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=111)
+    ap.add_argument("--multi-chain", default=None,
+                    help="comma-separated batch widths for the `multi_chain` "
+                         "object (k chains on ONE GPU sharing every pass over "
+                         "X; rank 0 at N = 1 only; '0' = skip).  Default: 2,4 "
+                         "for the sparse configs, 4,8 for config4")
+    ap.add_argument("--multi-chain-steps", type=int, default=20)
     return ap.parse_args(argv)
 
 
@@ -163,6 +169,64 @@ def cpu_baselines(prob, state, n_iters, seed):
     return port, omp
 
 
+def multi_chain_block(design, make_chain, state, widths, steps, warmup,
+                      single_value, dense):
+    """k chains on one GPU through ONE pass over X per product (csrc/batch.hip)
+    -- the reference's answer to "more chains" is more processes, each with
+    its own passes (bayesbridge.py:109).  Every batch starts all its chains
+    from the single chain's post-warm-up state (own seeds), runs `warmup`
+    untimed and `steps` timed iterations and reports aggregate
+    chain-iterations/s, the batched launches' bytes and their rate."""
+    import numpy as np
+    import torch
+    from bayesbridge_amd import HipChainBatch
+    coef, obs, ls, g, mean, square, navg = state
+    out = {"what": "k chains per GPU sharing every pass over X (K-column "
+                   "products); chain-iterations/s of the whole batch, same "
+                   "start state and stationarity as the single-chain line",
+           "k=1": {"chain_iters_per_sec": round(single_value, 2)}}
+    for k in widths:
+        chains = []
+        for i in range(k):
+            ch = make_chain(7000 + 13 * i)
+            ch.set_state(coef, obs, ls, g)
+            ch.set_summary(mean, square, navg)
+            chains.append(ch)
+        t0 = time.perf_counter()
+        batch = HipChainBatch(chains)
+        build_s = time.perf_counter() - t0
+        batch.run_device(warmup)
+        design.set_timing(True, every=8)
+        design.reset_timing()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gs, lp, ncg, _ = batch.run_device(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timing = design.get_timing()
+        design.set_timing(False)
+        assert np.all(np.isfinite(lp)) and np.all(gs > 0)
+        dot_b, tdot_b = batch.launch_bytes
+        entry = {"chain_iters_per_sec": round(k * steps / dt, 2),
+                 "vs_k1": round(k * steps / dt / single_value, 3),
+                 "ms_per_batch_step": round(1e3 * dt / steps, 4),
+                 "mean_n_cg_iter": [round(float(v), 1) for v in ncg.mean(1)],
+                 "layout_build_s": round(build_s, 2)}
+        for name, nbytes in (("dot", dot_b), ("tdot", tdot_b)):
+            cnt, ms = timing[name]
+            if cnt > 0 and ms > 0:
+                avg = ms / cnt
+                entry[name] = {"avg_ms": round(avg, 5), "bytes": int(nbytes),
+                               "gbs": round(nbytes / avg / 1e6, 1),
+                               "frac": round(nbytes / avg / 1e6 / HBM_PEAK_GBS,
+                                             4), "launches": cnt}
+        out["k=%d" % k] = entry
+        batch.close()
+        for ch in chains:
+            ch.close()
+    return out
+
+
 def committed_traffic(design, which, cfg):
     """HBM bytes per launch of the dominant kernel from the committed PMC
     passes (profiles/r0N_spmv_profile.json; FETCH_SIZE doubled per the gfx950
@@ -254,9 +318,11 @@ def main():
             storage_dtype='float32')
         del prob["X"]
         outcome = prob["y"].cpu().numpy()
-        chain = HipGibbsChain(design, 'linear', outcome,
-                              bridge_exponent=ALPHA, slab_size=SLAB,
-                              seed=seed_k)
+        def make_chain(seed):
+            return HipGibbsChain(design, 'linear', outcome,
+                                 bridge_exponent=ALPHA, slab_size=SLAB,
+                                 seed=seed)
+        chain = make_chain(seed_k)
         intercept0 = outcome.mean()
     else:
         prob = build_problem(torch, args.config, args.seed, device)
@@ -268,9 +334,11 @@ def main():
             device=dev_index, storage=args.storage)
         # chain: prior and init of the reference demo (demo.ipynb cells 7, 9)
         n_success = prob["n_success"].cpu().numpy()
-        chain = HipGibbsChain(design, 'logit', n_success,
-                              bridge_exponent=ALPHA, slab_size=SLAB,
-                              seed=seed_k)
+        def make_chain(seed):
+            return HipGibbsChain(design, 'logit', n_success,
+                                 bridge_exponent=ALPHA, slab_size=SLAB,
+                                 seed=seed)
+        chain = make_chain(seed_k)
         ph = n_success.mean()
         intercept0 = math.log(ph / (1 - ph))             # intercept MLE
     P = p + 1
@@ -292,7 +360,12 @@ def main():
     ncg_w = chain.run_device(W)[2] if W > 0 else np.zeros(0)
     # state after warm-up (for the CPU baselines)
     state = None
-    if rank == 0 and world == 1 and args.cpu_baseline_iters > 0 and not dense:
+    widths = args.multi_chain
+    if widths is None:
+        widths = "0" if dense else "2,4"
+    widths = [int(v) for v in widths.split(",") if int(v) > 1]
+    solo = rank == 0 and world == 1 and env_world is None
+    if solo and ((args.cpu_baseline_iters > 0 and not dense) or widths):
         coef, obs, ls, g = chain.get_state()
         mean, square, navg = chain.get_summary()
         state = (coef, obs, ls, g, mean, square, navg)
@@ -456,7 +529,11 @@ def main():
             },
             "roofline": roofline,
         }
-        if state is not None:
+        if state is not None and widths:
+            line["multi_chain"] = multi_chain_block(
+                design, make_chain, state, widths, args.multi_chain_steps, 5,
+                line["value"], dense)
+        if state is not None and args.cpu_baseline_iters > 0 and not dense:
             port, omp = cpu_baselines(prob, state, args.cpu_baseline_iters,
                                       args.seed)
             line["cpu_baseline"] = port

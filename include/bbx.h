@@ -68,6 +68,7 @@ extern "C" {
 
 typedef struct bbx_design bbx_design; /* opaque: one design operator on one GPU */
 typedef struct bbx_chain bbx_chain;   /* opaque: one device-resident Gibbs chain */
+typedef struct bbx_batch bbx_batch;   /* opaque: chains that share the passes over X */
 
 /* ---------------------------------------------------------------- library */
 
@@ -382,6 +383,52 @@ int bbx_chain_run_host(bbx_chain* c, int n_iter, int n_burnin, int thin,
                        int maxiter, double atol, double* coef, double* lscale,
                        double* obs_prec, double* gscale, double* logp,
                        double* n_cg_iter);
+
+/* ------------------------------------------------------------ batched chains
+ * The reference runs ONE chain per process (bayesbridge.py:109) and its hot
+ * loop is the operator of cg_sampler.py:105-108: two passes over the design per
+ * CG iteration.  The matrix stream does not depend on the chain, so several
+ * chains on one GPU can share every pass: a batch steps its chains in lock step
+ * and runs the products of the CG solves (and the linear predictor of the
+ * Omega update) as K-column products over one read of the matrix.  Everything
+ * else of an iteration is the chain's own code with the chain's own Philox
+ * keys; a chain's samples do not depend on which chains it is batched with
+ * (bit for bit), and differ from `bbx_chain_run` only by the rounding of the
+ * differently blocked sums.
+ *
+ * `chains`: n_chain (2 or 4; dense designs: 2 ... 8) chains created with
+ * bbx_chain_create on `design` (sparse: tiled format).  The batch borrows them:
+ * set/get their state through the bbx_chain_* calls between runs, destroy the
+ * batch before its chains.  The first batch of a width builds the matching
+ * layout of the design (host pass, ~1 s at 1M x 50k). */
+int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,
+                     bbx_batch** out);
+int bbx_batch_destroy(bbx_batch* b);
+/*
+ * n_iter Gibbs iterations of every chain (arguments as bbx_chain_run).
+ *   d_coef[n_chain]          host array of DEVICE buffers [n_sample * P], one per
+ *                            chain (entries or the array itself may be NULL)
+ *   gscale, logp, n_cg_iter  HOST buffers [n_chain * n_sample], chain-major, or NULL
+ * Returns the number of (chain, iteration) CG solves that hit maxiter, or < 0.
+ */
+int bbx_batch_run(bbx_batch* b, int n_iter, int n_burnin, int thin,
+                  int maxiter, double atol, double* const* d_coef,
+                  double* gscale, double* logp, double* n_cg_iter);
+/* Same with a HOST coefficient buffer [n_chain * n_sample * P] (chain-major,
+ * sample s of chain c at (c * n_sample + s) * P), copied at the end, or NULL. */
+int bbx_batch_run_host(bbx_batch* b, int n_iter, int n_burnin, int thin,
+                       int maxiter, double atol, double* coef, double* gscale,
+                       double* logp, double* n_cg_iter);
+/* The batched products on their own, host pointers, chain-major: v [n_chain][P]
+ * -> out [n_chain][n] (X~ v_c) and w [n_chain][n] -> out [n_chain][P] (X~^T w_c)
+ * through the kernels the batch's CG loop launches (abstract_matrix.py:61-72's
+ * dot / Tdot, K at a time).  For the parity tests. */
+int bbx_batch_dot(bbx_batch* b, const double* v, double* out);
+int bbx_batch_tdot(bbx_batch* b, const double* w, double* out);
+/* Bytes ONE batched launch of each product kernel moves (all chains together):
+ * the figure the kernel timers of the design are divided into for a batch. */
+int bbx_batch_bytes(const bbx_batch* b, int64_t* dot_bytes,
+                    int64_t* tdot_bytes);
 
 /* The device-side scalar samplers on n_draw inputs (host pointers), exposed
  * so that their distributions can be tested against the host samplers:

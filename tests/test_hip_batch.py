@@ -1,0 +1,182 @@
+"""GPU parity of batched chains (`bbx_batch_*`, csrc/batch.hip): K chains on
+one GPU share every pass over the design.  The reference has one chain per
+process (bayesbridge.py:109) and no counterpart of a batch, so the parity
+statement is: a chain's samples are, BIT FOR BIT, what the same chain produces
+with any other companions in any other slot of a batch; and they agree with the
+single-chain path (`bbx_chain_run`, itself pinned to the oracle in
+test_hip_chain_pin.py) to the rounding of the differently blocked sums.  The
+batched product kernels are compared with the CPU emulator of the tiled
+kernel's walk over the K-sized layout, column by column, bit for bit."""
+import numpy as np
+import pytest
+
+from helpers import TiledLayoutCpu, mixed_design
+
+pytestmark = pytest.mark.gpu
+
+
+def _chains(hip, y, family, seeds, prior=None):
+    from bayesbridge_amd import HipGibbsChain
+    P = hip.shape[1]
+    out = []
+    for sd in seeds:
+        if family == 'logit':
+            ch = HipGibbsChain(hip, 'logit', y[0], n_trial=y[1],
+                               sd_unshrunk=[2.], bridge_exponent=.5,
+                               slab_size=2., gscale_shape=1.5, gscale_rate=.3,
+                               seed=sd)
+        else:
+            ch = HipGibbsChain(hip, 'linear', y, sd_unshrunk=[np.inf],
+                               bridge_exponent=.5, slab_size=2., seed=sd)
+        rng = np.random.default_rng(1000 + sd)     # the chain's own start
+        ch.set_state(np.zeros(P), None, np.exp(rng.normal(0., 1., P - 1)), .07)
+        ch.init_obs_prec()
+        out.append(ch)
+    return out
+
+
+def _problem(n, p, family, binary_frac=1., seed=3):
+    from bayesbridge_amd import HipSparseDesignMatrix, simulate
+    if binary_frac >= 1.:
+        X = simulate.simulate_binary_csr_fast(n, p, .05, seed=seed)
+    else:
+        X = mixed_design(n, p, binary_frac=binary_frac, seed=seed)
+    beta = np.zeros(p)
+    beta[:5], beta[5:10] = 1.5, -1.
+    y = simulate.simulate_outcome(X, beta, family, seed=4)
+    hip = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
+                                storage='tiled')
+    return X, y, hip
+
+
+@pytest.mark.parametrize("K", [2, 4])
+@pytest.mark.parametrize("shape", [(9000, 20000, .004), (700, 40000, .003),
+                                   (20000, 1000, .02)])
+def test_batched_products_equal_the_cpu_emulator_bitwise(K, shape):
+    """K-column tiled products against the CPU emulator of the kernel's walk on
+    the layout sized for K right-hand sides (tests/test_tiled_layout_cpu.py
+    checks that layout against SciPy without a GPU): every column is bit for
+    bit the emulator's sum, whatever the other columns hold."""
+    from bayesbridge_amd import HipChainBatch, HipSparseDesignMatrix, simulate
+    n, p, f = shape
+    layout = TiledLayoutCpu()
+    X = simulate.simulate_binary_csr_fast(n, p, f, seed=11)
+    Xt = X.T.tocsr()
+    Xt.sort_indices()
+    hip = HipSparseDesignMatrix(X.copy(), center_predictor=False,
+                                add_intercept=False, storage='tiled')
+    y = simulate.simulate_outcome(X, np.zeros(p), 'linear', seed=1)
+    batch = HipChainBatch(_chains(hip, y, 'linear', list(range(K))))
+    rng = np.random.default_rng(5)
+    v, w = rng.standard_normal((K, p)), rng.standard_normal((K, n))
+    got_v, got_w = batch.dot(v), batch.Tdot(w)
+    for c in range(K):
+        emu_v, _ = layout.matvec(X, v[c], chains=K)
+        emu_w, _ = layout.matvec(Xt, w[c], chains=K)
+        assert np.array_equal(got_v[c], emu_v), c
+        assert np.array_equal(got_w[c], emu_w), c
+    # a column does not see its neighbours: permuted inputs, permuted outputs
+    perm = np.roll(np.arange(K), 1)
+    assert np.array_equal(batch.dot(v[perm]), got_v[perm])
+    assert np.array_equal(batch.Tdot(w[perm]), got_w[perm])
+
+
+@pytest.mark.parametrize("K", [2, 4])
+def test_batched_products_with_centring_and_intercept(K):
+    """Intercept column and implicit centring per column, against SciPy; valued
+    entries for K = 2 (four valued right-hand sides exceed the register budget
+    and are refused)."""
+    from bayesbridge_amd import BbxError, HipChainBatch
+    for binary_frac in (1., .7):
+        X, y, hip = _problem(6000, 3000, 'linear', binary_frac)
+        chains = _chains(hip, y, 'linear', list(range(K)))
+        if binary_frac < 1. and K == 4:
+            with pytest.raises(BbxError):
+                HipChainBatch(chains)
+            continue
+        batch = HipChainBatch(chains)
+        n, P = hip.shape
+        rng = np.random.default_rng(6)
+        v, w = rng.standard_normal((K, P)), rng.standard_normal((K, n))
+        off = np.asarray(X.mean(axis=0)).ravel()
+        got_v, got_w = batch.dot(v), batch.Tdot(w)
+        for c in range(K):
+            ref_v = v[c, 0] + X @ v[c, 1:] - off @ v[c, 1:]
+            ref_w = np.concatenate(([w[c].sum()],
+                                    X.T @ w[c] - w[c].sum() * off))
+            assert np.abs(got_v[c] - ref_v).max() <= 1e-11 * np.abs(ref_v).max()
+            assert np.abs(got_w[c] - ref_w).max() <= 1e-11 * np.abs(ref_w).max()
+            # and the single-chain operator of the same handle
+            assert np.abs(got_v[c] - hip.dot(v[c])).max() \
+                <= 1e-11 * np.abs(ref_v).max()
+
+
+@pytest.mark.parametrize("family", ['logit', 'linear'])
+@pytest.mark.parametrize("K", [2, 4])
+def test_a_chain_does_not_depend_on_its_batch(family, K):
+    """Chain A batched with different companions, in a different slot: every
+    saved sample of A is bit-identical (fixed per-column summation order, own
+    Philox keys, own stop rule).  Against A run alone through bbx_chain_run the
+    first draws agree to rounding -- the batch's products block their sums
+    differently -- and the stopping iterations within 2."""
+    from bayesbridge_amd import HipChainBatch
+    X, y, hip = _problem(5000, 600, family)
+    iters = 6
+    seeds_1 = [17, 23, 31, 47][:K]
+    seeds_2 = [61, 17, 5, 9][:K]           # A = seed 17 moves to slot 1
+    b1 = HipChainBatch(_chains(hip, y, family, seeds_1))
+    s1, unconv1 = b1.run(iters)
+    b1.close()
+    b2 = HipChainBatch(_chains(hip, y, family, seeds_2))
+    s2, unconv2 = b2.run(iters)
+    b2.close()
+    assert unconv1 == 0 and unconv2 == 0
+    for key in ('coef', 'global_scale', 'logp', 'n_cg_iter'):
+        assert np.array_equal(s1[key][0], s2[key][1]), key
+        assert not np.array_equal(s1[key][1], s2[key][0]) or key == 'n_cg_iter'
+    assert np.all(np.isfinite(s1['logp']))
+    # the same chain alone, through the single-chain path
+    alone = _chains(hip, y, family, [17])[0]
+    kept, _ = alone.run(iters, save=('coef',))
+    scale = max(1., np.abs(kept['coef'][0]).max())
+    same_count = kept['n_cg_iter'][0] == s1['n_cg_iter'][0][0]
+    # (the bounds of test_hip_cg_sampler.py against the oracle)
+    tol = 1e-6 if same_count else 1e-5
+    assert np.abs(kept['coef'][0] - s1['coef'][0][0]).max() <= tol * scale
+    assert abs(kept['n_cg_iter'][0] - s1['n_cg_iter'][0][0]) <= 2
+    assert abs(kept['logp'][0] - s1['logp'][0][0]) <= 1e-6 * abs(kept['logp'][0])
+    # reruns are bitwise reproducible
+    b3 = HipChainBatch(_chains(hip, y, family, seeds_1))
+    s3, _ = b3.run(iters)
+    for key in ('coef', 'global_scale', 'logp', 'n_cg_iter'):
+        assert np.array_equal(s1[key], s3[key]), key
+
+
+def test_batched_chain_on_a_mixed_design_and_resume():
+    """Valued (mixed binary / Gaussian) columns, K = 2; a batch run in two
+    halves equals the straight run bit for bit (the chains carry all state)."""
+    from bayesbridge_amd import HipChainBatch
+    X, y, hip = _problem(4000, 300, 'logit', binary_frac=.8)
+    straight = HipChainBatch(_chains(hip, y, 'logit', [3, 4]))
+    s, _ = straight.run(8)
+    halves = HipChainBatch(_chains(hip, y, 'logit', [3, 4]))
+    a, _ = halves.run(5)
+    b, _ = halves.run(3)
+    for key in ('coef', 'global_scale', 'logp', 'n_cg_iter'):
+        joined = np.concatenate([a[key], b[key]], axis=1)
+        assert np.array_equal(joined, s[key]), key
+
+
+def test_batch_argument_checks():
+    from bayesbridge_amd import BbxError, HipChainBatch
+    X, y, hip = _problem(2000, 100, 'linear')
+    X2, y2, hip2 = _problem(2000, 100, 'linear', seed=8)
+    a, b, c = _chains(hip, y, 'linear', [1, 2, 3])
+    other = _chains(hip2, y2, 'linear', [4])[0]
+    with pytest.raises(BbxError):
+        HipChainBatch([a, b, c])             # 2 or 4 chains
+    with pytest.raises(BbxError):
+        HipChainBatch([a, a])                # a chain twice
+    with pytest.raises(BbxError):
+        HipChainBatch([a, other])            # another design
+    HipChainBatch([a, b]).run(1)

@@ -34,6 +34,9 @@ def test_layout_emulation_equals_scipy(layout, case):
     variants = [dict(), dict(bank_aware=False)]
     if case % 4 == 0:
         variants.append(dict(force_PR=128, force_G=2, threads=3))
+    # geometries sized for 2 and 4 right-hand sides sharing the pass (batched
+    # chains): narrower slices, shorter panels, same sums per right-hand side
+    variants += [dict(chains=2), dict(chains=4)]
     for kw in variants:
         out_v, info_v = layout.matvec(X, v, **kw)
         out_w, info_w = layout.matvec(Xt, w, **kw)
@@ -41,7 +44,8 @@ def test_layout_emulation_equals_scipy(layout, case):
         assert np.abs(out_w - ref_w).max() <= tol_w, (kw, info_w)
         # every layout fits the CU's LDS next to 2 KB of static use
         for info in (info_v, info_w):
-            lds = 8 * (info['W'] + 8 + info['PR'] + info['n_extra'])
+            lds = 8 * kw.get('chains', 1) * (info['W'] + 8 + info['PR']
+                                             + info['n_extra'])
             assert lds <= 160 * 1024 - 2048 + 8 * 8, info
     # binary designs: the emulator adds whole numbers exactly
     if binary and np.all(v == np.round(v)):
@@ -58,7 +62,8 @@ def test_integer_vectors_give_exact_sums(layout):
     w = rng.integers(-50, 50, X.shape[0]).astype(np.float64)
     Xt = X.T.tocsr()
     Xt.sort_indices()
-    for kw in (dict(), dict(force_PR=256, force_G=2)):
+    for kw in (dict(), dict(force_PR=256, force_G=2), dict(chains=2),
+               dict(chains=4)):
         assert np.array_equal(layout.matvec(X, v, **kw)[0], X @ v)
         assert np.array_equal(layout.matvec(Xt, w, **kw)[0], Xt @ w)
 
