@@ -201,9 +201,14 @@ struct BankScratch {
   std::vector<int32_t> top;     // [row * 32 + bank]: one past the bucket's last
   std::vector<int32_t> bot;     // [row * 32 + bank]: bucket's first
 };
+// `nb` = number of bank slots the lanes of one LDS group compete for: 32
+// eight-byte slots for the ds_read_b64 of the single-chain kernel (groups of 32
+// lanes), 16 sixteen-byte slots for the ds_read_b128 of the batched kernels
+// (groups of 16 lanes, MI355X_MICROARCH.md "LDS").
 static void bank_aware_order(const HalfRow* rows, int n_rows, int64_t col0,
                              int pad_bank, const uint8_t* hot, BankScratch& sc,
-                             std::vector<int32_t>* perm) {
+                             std::vector<int32_t>* const* perm, int nb) {
+  const int bmask = nb - 1;
   int max_len = 0;
   size_t total = 0;
   for (int i = 0; i < n_rows; ++i) {
@@ -211,7 +216,7 @@ static void bank_aware_order(const HalfRow* rows, int n_rows, int64_t col0,
     total += (size_t)rows[i].len;
   }
   sc.ent.resize(total);
-  sc.top.assign((size_t)n_rows * 32, 0);
+  sc.top.assign((size_t)n_rows * 32, 0);  // (stride 32 for either nb)
   sc.bot.assign((size_t)n_rows * 32, 0);
   int left[32], n_banks[32];
   uint32_t avail[32];  // banks in which the row still holds entries
@@ -221,24 +226,24 @@ static void bank_aware_order(const HalfRow* rows, int n_rows, int64_t col0,
     for (int i = 0; i < n_rows; ++i) {
       int32_t cnt[33] = {0};
       const int32_t len = rows[i].len;
-      for (int32_t k = 0; k < len; ++k) cnt[((rows[i].col[k] - col0) & 31) + 1] += 1;
-      int nb = 0;
+      for (int32_t k = 0; k < len; ++k) cnt[((rows[i].col[k] - col0) & bmask) + 1] += 1;
+      int nbk = 0;
       for (int b = 0; b < 32; ++b) {
-        nb += cnt[b + 1] > 0;
+        nbk += cnt[b + 1] > 0;
         cnt[b + 1] += cnt[b];
         sc.bot[(size_t)i * 32 + (size_t)b] = (int32_t)off + cnt[b];
         sc.top[(size_t)i * 32 + (size_t)b] = (int32_t)off + cnt[b];
       }
       for (int32_t k = len - 1; k >= 0; --k) {
-        const int b = (int)((rows[i].col[k] - col0) & 31);
+        const int b = (int)((rows[i].col[k] - col0) & bmask);
         sc.ent[(size_t)sc.top[(size_t)i * 32 + (size_t)b]++] = k;
       }
       left[i] = len;
-      n_banks[i] = nb;
+      n_banks[i] = nbk;
       avail[i] = 0;
       for (int b = 0; b < 32; ++b)
         if (cnt[b + 1] > cnt[b]) avail[i] |= 1u << b;
-      perm[i].resize((size_t)len);
+      perm[i]->resize((size_t)len);
       off += (size_t)len;
     }
   }
@@ -283,7 +288,7 @@ static void bank_aware_order(const HalfRow* rows, int n_rows, int64_t col0,
         const int32_t e = sc.ent[(size_t)pick_slot];
         sc.ent[(size_t)pick_slot] = sc.ent[(size_t)(top[pick_bank] - 1)];
         top[pick_bank] -= 1;
-        perm[i][(size_t)k] = e;
+        (*perm[i])[(size_t)k] = e;
       } else {
         // (2) a free bank, the one this row holds the most entries in;
         // (3) none free: its fullest bucket (a conflict either way)
@@ -300,7 +305,7 @@ static void bank_aware_order(const HalfRow* rows, int n_rows, int64_t col0,
         }
         const int32_t e = sc.ent[(size_t)(top[pick_bank] - 1)];
         top[pick_bank] -= 1;
-        perm[i][(size_t)k] = e;
+        (*perm[i])[(size_t)k] = e;
         if (!(used & (1u << pick_bank))) {
           used |= 1u << pick_bank;
           const int64_t id = rows[i].col[e] - col0;
@@ -512,20 +517,33 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
       const bool reorder = opt.bank_aware;
       if (reorder) {
         slice_perm.resize(SLICE_ROWS);
+        // lanes whose gathers are served in the same LDS cycle(s): the two
+        // 32-lane halves for ds_read_b64, four 16-lane groups for ds_read_b128
+        static const int kGroups128[4][16] = {
+            {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+            {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+            {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+            {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+        const bool wide_reads = opt.chains > 1;
+        const int n_groups = wide_reads ? 4 : 2, group_lanes = wide_reads ? 16 : 32;
+        const int nb = wide_reads ? 16 : 32;
         for (int side = 0; side < 2; ++side)
-          for (int half = 0; half < 2; ++half) {
+          for (int grp = 0; grp < n_groups; ++grp) {
             HalfRow hr[32];
+            std::vector<int32_t>* pp[32];
             int n_hr = 0;
-            const int first = base + side * LANES + half * 32;
-            for (int i = 0; i < 32 && first + i < base + rows_in &&
-                            first + i < n_rows; ++i) {
-              hr[n_hr].col = colidx + sorted[first + i].begin;
-              hr[n_hr].len = sorted[first + i].len;
+            for (int i = 0; i < group_lanes; ++i) {
+              const int lane = wide_reads ? kGroups128[grp][i] : grp * 32 + i;
+              const int idx = base + side * LANES + lane;
+              if (idx >= base + rows_in || idx >= n_rows) continue;
+              hr[n_hr].col = colidx + sorted[idx].begin;
+              hr[n_hr].len = sorted[idx].len;
+              pp[n_hr] = &slice_perm[(size_t)(side * LANES + lane)];
               ++n_hr;
             }
             if (n_hr > 0)
-              bank_aware_order(hr, n_hr, col0, W & 31, hot.data(), bank_scratch,
-                               &slice_perm[(size_t)(side * LANES + half * 32)]);
+              bank_aware_order(hr, n_hr, col0, W & (nb - 1), hot.data(),
+                               bank_scratch, pp, nb);
           }
       }
       for (int l = 0; l < LANES; ++l) {
@@ -977,21 +995,31 @@ void emulate_tiled_spmv(const TiledHost& m, const double* x,
 
 double tiled_mean_gather_cycles(const TiledHost& m) {
   if (m.n_quad == 0) return 0.;
+  // K == 1: ds_read_b64, two groups of 32 lanes, 32 eight-byte slots;
+  // K > 1 : ds_read_b128 (one per plane of pairs), four groups of 16 lanes,
+  //         16 sixteen-byte slots.  Equal addresses broadcast.
+  static const int kGroups128[4][16] = {
+      {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+      {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+      {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+  const bool wide = m.K > 1;
+  const int n_groups = wide ? 4 : 2, group_lanes = wide ? 16 : 32;
+  const int bmask = wide ? 15 : 31;
   double cycles = 0., groups = 0.;
   for (int64_t q = 0; q < m.n_quad; ++q) {
     for (int pos = 0; pos < 8; ++pos)
-      for (int half = 0; half < 2; ++half) {
-        // ds_read_b64: the 32 lanes of a half conflict when DISTINCT 8-byte
-        // slots share (slot mod 32); equal addresses broadcast
+      for (int grp = 0; grp < n_groups; ++grp) {
         uint16_t seen[32][32];
         int n_seen[32] = {0};
         int worst = 1;
-        for (int l = 32 * half; l < 32 * half + 32; ++l) {
+        for (int i = 0; i < group_lanes; ++i) {
+          const int l = wide ? kGroups128[grp][i] : grp * 32 + i;
           const Ids4& e = m.ids[(size_t)q * LANES + (size_t)l];
           const uint32_t word = pos < 2 ? e.x : pos < 4 ? e.y : pos < 6 ? e.z : e.w;
           // positions: x.lo x.hi y.lo y.hi z.lo z.hi w.lo w.hi
           const uint16_t id = (pos & 1) ? (uint16_t)(word >> 16) : (uint16_t)word;
-          const int bank = id & 31;
+          const int bank = id & bmask;
           bool dup = false;
           for (int k = 0; k < n_seen[bank]; ++k) dup = dup || seen[bank][k] == id;
           if (!dup) {
