@@ -33,8 +33,9 @@ namespace bbx {
 
 struct BatchState {
   CGState st[BATCH_MAX];
-  int all_done;  // every chain's stop rule has fired: operator kernels exit
-  int pad[3];
+  int n_done;    // chains whose stop rule has fired
+  int all_done;  // n_done == K: the operator kernels exit at entry
+  int pad[2];
 };
 
 }  // namespace bbx
@@ -42,7 +43,7 @@ struct BatchState {
 struct bbx_batch {
   bbx_design* h = nullptr;
   int K = 0;
-  bbx_chain* chain[bbx::BATCH_MAX] = {nullptr, nullptr, nullptr, nullptr};
+  bbx_chain* chain[bbx::BATCH_MAX] = {};
   bbx::DevMem s, d, x, r, p, sp;  // (P + 2) * K doubles, interleaved [j][c]
   bbx::DevMem t, w;               // n * K doubles
   bbx::DevMem eta1[bbx::BATCH_MAX], eta2[bbx::BATCH_MAX];  // n, P per chain
@@ -60,6 +61,10 @@ static inline double* bpart(const bbx_batch* b, int slot) {
 }
 
 // ------------------------------------------------------------------ kernels
+//
+// The vector kernels of a batch handle KC = min(K, 4) chains per thread (their
+// elements of the interleaved vectors are adjacent) and K / KC groups of
+// chains in blockIdx.y; `c0` is the group's first chain.
 
 // the sum of one NPART-block, same adds in the same order in every thread
 // (vecops.hip part_issue / part_finish, without the LDS round)
@@ -80,34 +85,35 @@ __device__ inline double part_finish_k(const PartLoadK& p) {
   return wave_allsum(a);  // every wave computes the same value
 }
 
-// per-chain block partial: part[c * NPART + blockIdx.x]
-template <int K>
-__device__ inline void block_store_partials_k(const double (&x)[K],
-                                              double* part) {
-  __shared__ double s_w[K][VEC_BLOCK / WAVE];
+// per-chain block partial: part[(c0 + c) * NPART + blockIdx.x]
+template <int KC>
+__device__ inline void block_store_partials_k(const double (&x)[KC],
+                                              double* part, int c0) {
+  __shared__ double s_w[KC][VEC_BLOCK / WAVE];
 #pragma unroll
-  for (int c = 0; c < K; ++c) {
+  for (int c = 0; c < KC; ++c) {
     const double v = wave_allsum(x[c]);
     if ((threadIdx.x & (WAVE - 1)) == 0) s_w[c][threadIdx.x / WAVE] = v;
   }
   __syncthreads();
-  if (threadIdx.x < K) {
+  if (threadIdx.x < KC) {
     double r = 0.;
 #pragma unroll
     for (int k = 0; k < VEC_BLOCK / WAVE; ++k) r += s_w[threadIdx.x][k];
-    part[threadIdx.x * NPART + blockIdx.x] = r;
+    part[(c0 + (int)threadIdx.x) * NPART + blockIdx.x] = r;
   }
   __syncthreads();
 }
 
 // s, d and the scaled warm start of every chain (cg_sampler.py:104,128-138,76)
-template <int K>
+template <int KC>
 __global__ __launch_bounds__(VEC_BLOCK) void b_setup_kernel(
-    int64_t P, int n_unshrunk, ChainPtrs phi, ChainPtrs sd, ChainPtrs x0,
+    int64_t P, int K, int n_unshrunk, ChainPtrs phi, ChainPtrs sd, ChainPtrs x0,
     double* __restrict__ s, double* __restrict__ d, double* __restrict__ xs,
     BatchState* __restrict__ bs, double atol) {
-  if (blockIdx.x == 0 && threadIdx.x < K) {
-    CGState* st = &bs->st[threadIdx.x];
+  const int c0 = blockIdx.y * KC;
+  if (blockIdx.x == 0 && threadIdx.x < KC) {
+    CGState* st = &bs->st[c0 + threadIdx.x];
     st->rho[0] = st->rho[1] = 0.;
     st->atol = atol;
     st->bnorm2 = 0.;
@@ -115,89 +121,97 @@ __global__ __launch_bounds__(VEC_BLOCK) void b_setup_kernel(
     st->done = 0;
     st->bad = 0;
     st->pad = 0;
-    if (threadIdx.x == 0) bs->all_done = 0;
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
+      bs->n_done = 0;
+      bs->all_done = 0;
+    }
   }
   for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
        jj += (int64_t)gridDim.x * VEC_BLOCK) {
 #pragma unroll
-    for (int c = 0; c < K; ++c) {
-      const double ph = phi.p[c][jj];
-      const double sj = (jj < n_unshrunk) ? 2. * sd.p[c][jj] : 1. / ph;
+    for (int c = 0; c < KC; ++c) {
+      const double ph = phi.p[c0 + c][jj];
+      const double sj = (jj < n_unshrunk) ? 2. * sd.p[c0 + c][jj] : 1. / ph;
       const double sp = sj * ph;
-      s[jj * K + c] = sj;
-      d[jj * K + c] = sp * sp;
-      xs[jj * K + c] = x0.p[c][jj] / sj;
+      s[jj * K + c0 + c] = sj;
+      d[jj * K + c0 + c] = sp * sp;
+      xs[jj * K + c0 + c] = x0.p[c0 + c][jj] / sj;
     }
   }
 }
 
 // v_c = s_c .* x_c (or x_c) into the interleaved buffer, and the partials of
 // <offset, v_c[1:]>.  x comes interleaved (x_il) or from per-chain arrays.
-template <int K>
+template <int KC>
 __global__ __launch_bounds__(VEC_BLOCK) void b_prep_kernel(
-    int64_t P, int intercept, const double* __restrict__ x_il, ChainPtrs x_sep,
-    const double* __restrict__ s_il, const double* __restrict__ offset,
-    double* __restrict__ v, double* __restrict__ c_part) {
-  double acc[K];
+    int64_t P, int K, int intercept, const double* __restrict__ x_il,
+    ChainPtrs x_sep, const double* __restrict__ s_il,
+    const double* __restrict__ offset, double* __restrict__ v,
+    double* __restrict__ c_part) {
+  const int c0 = blockIdx.y * KC;
+  double acc[KC];
 #pragma unroll
-  for (int c = 0; c < K; ++c) acc[c] = 0.;
+  for (int c = 0; c < KC; ++c) acc[c] = 0.;
   for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
        jj += (int64_t)gridDim.x * VEC_BLOCK) {
     const double off = jj >= intercept ? offset[jj - intercept] : 0.;
 #pragma unroll
-    for (int c = 0; c < K; ++c) {
-      double val = x_il ? x_il[jj * K + c] : x_sep.p[c][jj];
-      if (s_il) val *= s_il[jj * K + c];
-      v[jj * K + c] = val;
+    for (int c = 0; c < KC; ++c) {
+      double val = x_il ? x_il[jj * K + c0 + c] : x_sep.p[c0 + c][jj];
+      if (s_il) val *= s_il[jj * K + c0 + c];
+      v[jj * K + c0 + c] = val;
       if (jj >= intercept) acc[c] += off * val;
     }
   }
-  block_store_partials_k<K>(acc, c_part);
+  block_store_partials_k<KC>(acc, c_part, c0);
 }
 
 // w_c = minus_c - sqrt(Omega_c) eta1_c (minus == nullptr: -sqrt(Omega_c) eta1_c)
 // interleaved, and the partials of sum(w_c).
-template <int K>
+template <int KC>
 __global__ __launch_bounds__(VEC_BLOCK) void b_sqrt_scale_kernel(
-    int64_t n, ChainPtrs omega, ChainPtrs eta, const double* __restrict__ minus,
-    double* __restrict__ w, double* __restrict__ part) {
-  double acc[K];
+    int64_t n, int K, ChainPtrs omega, ChainPtrs eta,
+    const double* __restrict__ minus, double* __restrict__ w,
+    double* __restrict__ part) {
+  const int c0 = blockIdx.y * KC;
+  double acc[KC];
 #pragma unroll
-  for (int c = 0; c < K; ++c) acc[c] = 0.;
+  for (int c = 0; c < KC; ++c) acc[c] = 0.;
   for (int64_t i = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * VEC_BLOCK) {
 #pragma unroll
-    for (int c = 0; c < K; ++c) {
-      double val = sqrt(omega.p[c][i]) * eta.p[c][i];
-      if (minus) val = minus[i * K + c] - val;
+    for (int c = 0; c < KC; ++c) {
+      double val = sqrt(omega.p[c0 + c][i]) * eta.p[c0 + c][i];
+      if (minus) val = minus[i * K + c0 + c] - val;
       else val = -val;
-      w[i * K + c] = val;
+      w[i * K + c0 + c] = val;
       acc[c] += val;
     }
   }
-  block_store_partials_k<K>(acc, part);
+  block_store_partials_k<KC>(acc, part, c0);
 }
 
 // Top of CG iteration k for every chain that is still running (vecops.hip
 // cg_direction_kernel per column): stop test, rho, beta, p, s .* p, partials of
 // <offset, (s p)[1:]> and <p, d p>.
-template <int K>
+template <int KC>
 __global__ __launch_bounds__(VEC_BLOCK) void b_direction_kernel(
-    int64_t P, int intercept, int k, BatchState* __restrict__ bs,
+    int64_t P, int K, int intercept, int k, BatchState* __restrict__ bs,
     const double* __restrict__ rr_part, const double* __restrict__ r,
     double* __restrict__ pvec, const double* __restrict__ s,
     const double* __restrict__ offset, double* __restrict__ sp,
     double* __restrict__ c_part, const double* __restrict__ d,
     double* __restrict__ pdp_part) {
-  PartLoadK pl[K];
+  const int c0 = blockIdx.y * KC;
+  PartLoadK pl[KC];
 #pragma unroll
-  for (int c = 0; c < K; ++c) pl[c] = part_issue_k(rr_part + c * NPART);
-  bool run[K];
-  double beta[K], rho[K];
+  for (int c = 0; c < KC; ++c) pl[c] = part_issue_k(rr_part + (c0 + c) * NPART);
+  bool run[KC];
+  double beta[KC], rho[KC];
   bool any = false;
 #pragma unroll
-  for (int c = 0; c < K; ++c) {
-    const CGState* st = &bs->st[c];
+  for (int c = 0; c < KC; ++c) {
+    const CGState* st = &bs->st[c0 + c];
     const int was_done = st->done;
     const double atol = st->atol;
     const double rho_prev = (k > 0) ? st->rho[(k - 1) & 1] : 1.;
@@ -209,108 +223,110 @@ __global__ __launch_bounds__(VEC_BLOCK) void b_direction_kernel(
     any = any || run[c];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       if (stop) {
-        bs->st[c].done = 1;
-        if (!finite) bs->st[c].bad = 1;
+        bs->st[c0 + c].done = 1;
+        if (!finite) bs->st[c0 + c].bad = 1;
+        // the last chain to stop raises the flag the operator kernels read
+        if (atomicAdd(&bs->n_done, 1) + 1 == K) bs->all_done = 1;
       } else if (run[c]) {
-        bs->st[c].rho[k & 1] = rho[c];
+        bs->st[c0 + c].rho[k & 1] = rho[c];
       }
     }
   }
-  if (!any) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) bs->all_done = 1;
-    return;
-  }
-  double acc[K], acc_d[K];
+  if (!any) return;
+  double acc[KC], acc_d[KC];
 #pragma unroll
-  for (int c = 0; c < K; ++c) acc[c] = acc_d[c] = 0.;
+  for (int c = 0; c < KC; ++c) acc[c] = acc_d[c] = 0.;
   for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
        jj += (int64_t)gridDim.x * VEC_BLOCK) {
     const double off = jj >= intercept ? offset[jj - intercept] : 0.;
 #pragma unroll
-    for (int c = 0; c < K; ++c) {
+    for (int c = 0; c < KC; ++c) {
       if (!run[c]) continue;
-      double pj = r[jj * K + c];
-      if (k > 0) pj += beta[c] * pvec[jj * K + c];
-      pvec[jj * K + c] = pj;
-      const double v = s[jj * K + c] * pj;
-      sp[jj * K + c] = v;
+      const int64_t at = jj * K + c0 + c;
+      double pj = r[at];
+      if (k > 0) pj += beta[c] * pvec[at];
+      pvec[at] = pj;
+      const double v = s[at] * pj;
+      sp[at] = v;
       if (jj >= intercept) acc[c] += off * v;
-      acc_d[c] += d[jj * K + c] * pj * pj;
+      acc_d[c] += d[at] * pj * pj;
     }
   }
-  block_store_partials_k<K>(acc, c_part);
-  block_store_partials_k<K>(acc_d, pdp_part);
+  block_store_partials_k<KC>(acc, c_part, c0);
+  block_store_partials_k<KC>(acc_d, pdp_part, c0);
 }
 
-// The Tdot epilogue of a batch: adds the G slabs [G][p][K] in group order,
-// applies the intercept / centring correction and, per chain,
+// The Tdot epilogue of a batch: adds the G slabs [G][slab_rows][K] in group
+// order, applies the intercept / centring correction and, per chain,
 //   TD_OPER_UPD: q = d p + s g ; alpha = rho / (<p, d p> + <t, Omega t>) ;
 //                x += alpha p ; r -= alpha q ; partials of r.r ; n_iter = k + 1
 //   TD_RESID   : r = s (z + (phi eta2 - g)) - d x0 (warm) ; partials of r.r
+//   TD_PLAIN   : r = g
 // (spmv_csr.hip tdot_finalize_kernel per column).
-template <int K, int mode>
+template <int KC, int mode>
 __global__ __launch_bounds__(VEC_BLOCK) void b_finalize_kernel(
-    int64_t p, int intercept, const double* __restrict__ slab, int G,
-    const double* __restrict__ offset, const double* __restrict__ sumw_part,
-    const double* __restrict__ s, const double* __restrict__ d,
-    const double* __restrict__ pvec, double* __restrict__ x,
-    double* __restrict__ r, ChainPtrs z, ChainPtrs phi, ChainPtrs eta2,
-    int warm, double* __restrict__ rr_part, BatchState* __restrict__ bs,
-    int cg_k, const double* __restrict__ pdp_part,
+    int64_t p, int K, int intercept, const double* __restrict__ slab, int G,
+    int64_t slab_rows, const double* __restrict__ offset,
+    const double* __restrict__ sumw_part, const double* __restrict__ s,
+    const double* __restrict__ d, const double* __restrict__ pvec,
+    double* __restrict__ x, double* __restrict__ r, ChainPtrs z, ChainPtrs phi,
+    ChainPtrs eta2, int warm, double* __restrict__ rr_part,
+    BatchState* __restrict__ bs, int cg_k, const double* __restrict__ pdp_part,
     const double* __restrict__ twt_part) {
+  const int c0 = blockIdx.y * KC;
   const int64_t P = p + intercept;
-  PartLoadK pw[K], pa[K], pb[K];
+  PartLoadK pw[KC], pa[KC], pb[KC];
 #pragma unroll
-  for (int c = 0; c < K; ++c) {
-    pw[c] = part_issue_k(sumw_part + c * NPART);
+  for (int c = 0; c < KC; ++c) {
+    pw[c] = part_issue_k(sumw_part + (c0 + c) * NPART);
     if (mode == TD_OPER_UPD) {
-      pa[c] = part_issue_k(pdp_part + c * NPART);
-      pb[c] = part_issue_k(twt_part + c * NPART);
+      pa[c] = part_issue_k(pdp_part + (c0 + c) * NPART);
+      pb[c] = part_issue_k(twt_part + (c0 + c) * NPART);
     }
   }
-  double sumw[K], alpha[K];
-  bool run[K];
+  double sumw[KC], alpha[KC];
+  bool run[KC];
   bool any = false;
 #pragma unroll
-  for (int c = 0; c < K; ++c) {
+  for (int c = 0; c < KC; ++c) {
     sumw[c] = part_finish_k(pw[c]);
     run[c] = true;
     alpha[c] = 0.;
     if (mode == TD_OPER_UPD) {
-      run[c] = !bs->st[c].done;
-      const double rho = bs->st[c].rho[cg_k & 1];
+      run[c] = !bs->st[c0 + c].done;
+      const double rho = bs->st[c0 + c].rho[cg_k & 1];
       const double pap = part_finish_k(pa[c]) + part_finish_k(pb[c]);
       alpha[c] = rho / pap;
     }
     any = any || run[c];
   }
   if (!any) return;
-  double dacc[K];
+  double dacc[KC];
 #pragma unroll
-  for (int c = 0; c < K; ++c) dacc[c] = 0.;
+  for (int c = 0; c < KC; ++c) dacc[c] = 0.;
   for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
        jj += (int64_t)gridDim.x * VEC_BLOCK) {
-    double g[K];
+    double g[KC];
     if (intercept && jj == 0) {
 #pragma unroll
-      for (int c = 0; c < K; ++c) g[c] = sumw[c];
+      for (int c = 0; c < KC; ++c) g[c] = sumw[c];
     } else {
       const int64_t j = jj - intercept;
 #pragma unroll
-      for (int c = 0; c < K; ++c) g[c] = 0.;
+      for (int c = 0; c < KC; ++c) g[c] = 0.;
       for (int gi = 0; gi < G; ++gi) {
-        const double* row = slab + ((int64_t)gi * p + j) * K;
+        const double* row = slab + ((int64_t)gi * slab_rows + j) * K + c0;
 #pragma unroll
-        for (int c = 0; c < K; ++c) g[c] += row[c];
+        for (int c = 0; c < KC; ++c) g[c] += row[c];
       }
       const double off = offset[j];
 #pragma unroll
-      for (int c = 0; c < K; ++c) g[c] -= sumw[c] * off;
+      for (int c = 0; c < KC; ++c) g[c] -= sumw[c] * off;
     }
 #pragma unroll
-    for (int c = 0; c < K; ++c) {
+    for (int c = 0; c < KC; ++c) {
       if (!run[c]) continue;
-      const int64_t at = jj * K + c;
+      const int64_t at = jj * K + c0 + c;
       double rj;
       if (mode == TD_OPER_UPD) {
         const double pj = pvec[at];
@@ -318,7 +334,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void b_finalize_kernel(
         x[at] += alpha[c] * pj;
         rj = r[at] - alpha[c] * q;
       } else if (mode == TD_RESID) {
-        rj = s[at] * (z.p[c][jj] + (phi.p[c][jj] * eta2.p[c][jj] - g[c]));
+        rj = s[at] * (z.p[c0 + c][jj] +
+                      (phi.p[c0 + c][jj] * eta2.p[c0 + c][jj] - g[c]));
         if (warm) rj -= d[at] * x[at];
       } else {
         rj = g[c];  // TD_PLAIN: the product itself
@@ -327,28 +344,44 @@ __global__ __launch_bounds__(VEC_BLOCK) void b_finalize_kernel(
       dacc[c] += rj * rj;
     }
   }
-  if (rr_part) block_store_partials_k<K>(dacc, rr_part);
-  if (mode == TD_OPER_UPD && blockIdx.x == 0 && threadIdx.x < K &&
+  if (rr_part) block_store_partials_k<KC>(dacc, rr_part, c0);
+  if (mode == TD_OPER_UPD && blockIdx.x == 0 && threadIdx.x < KC &&
       run[threadIdx.x])
-    bs->st[threadIdx.x].n_iter = cg_k + 1;
+    bs->st[c0 + threadIdx.x].n_iter = cg_k + 1;
 }
 
 // coef_c = s_c .* x_c   (cg_sampler.py:89)
-template <int K>
+template <int KC>
 __global__ __launch_bounds__(VEC_BLOCK) void b_finish_kernel(
-    int64_t P, const double* __restrict__ s, const double* __restrict__ x,
-    ChainOut coef) {
+    int64_t P, int K, const double* __restrict__ s,
+    const double* __restrict__ x, ChainOut coef) {
+  const int c0 = blockIdx.y * KC;
   for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
        jj += (int64_t)gridDim.x * VEC_BLOCK) {
 #pragma unroll
-    for (int c = 0; c < K; ++c) coef.p[c][jj] = s[jj * K + c] * x[jj * K + c];
+    for (int c = 0; c < KC; ++c)
+      coef.p[c0 + c][jj] = s[jj * K + c0 + c] * x[jj * K + c0 + c];
   }
 }
 
-#define BBX_K_DISPATCH(K, CALL)                                                \
+// grid of a batched vector kernel: NPART blocks x K / KC chain groups
+#define BBX_KC_LAUNCH(K, KERNEL, STREAM, ...)                                  \
   do {                                                                         \
-    if ((K) == 2) { constexpr int KK = 2; CALL; }                              \
-    else { constexpr int KK = 4; CALL; }                                       \
+    if ((K) == 2)                                                              \
+      hipLaunchKernelGGL((KERNEL<2>), dim3(NPART, 1), dim3(VEC_BLOCK), 0,      \
+                         STREAM, __VA_ARGS__);                                 \
+    else                                                                       \
+      hipLaunchKernelGGL((KERNEL<4>), dim3(NPART, (K) / 4), dim3(VEC_BLOCK),   \
+                         0, STREAM, __VA_ARGS__);                              \
+  } while (0)
+#define BBX_KC_LAUNCH_MODE(K, KERNEL, MODE, STREAM, ...)                       \
+  do {                                                                         \
+    if ((K) == 2)                                                              \
+      hipLaunchKernelGGL((KERNEL<2, MODE>), dim3(NPART, 1), dim3(VEC_BLOCK),   \
+                         0, STREAM, __VA_ARGS__);                              \
+    else                                                                       \
+      hipLaunchKernelGGL((KERNEL<4, MODE>), dim3(NPART, (K) / 4),              \
+                         dim3(VEC_BLOCK), 0, STREAM, __VA_ARGS__);             \
   } while (0)
 
 // ------------------------------------------------------------------- driver
@@ -359,23 +392,69 @@ static ChainPtrs gather_ptrs(const bbx_batch* b, DevMem bbx_chain::*field) {
   return out;
 }
 
+// Geometry of the operator as the batched vector kernels see it.  Sparse: the
+// intercept entry and the implicit centring are corrections around the main
+// block (sparse_matrix.py:68-129).  Dense: they are part of the stored matrix.
+struct BatchShape {
+  int icpt;            // 1: entry 0 of a P-vector is the intercept
+  int64_t p_main;      // columns of the main block
+  const double* offset;
+};
+static BatchShape batch_shape(const bbx_design* h) {
+  BatchShape g;
+  g.icpt = h->sparse ? h->intercept : 0;
+  g.p_main = h->sparse ? h->p : h->P;
+  g.offset = h->offset.as<double>();  // dense: P zeros
+  return g;
+}
+
+// t_c = rowscale_c .* (X~ v_c) for the interleaved input, one pass over X.
+static int batch_dot(bbx_batch* b, const double* v_il, const TiledBatchArgs& ba,
+                     bool want_sums) {
+  bbx_design* h = b->h;
+  const int K = b->K;
+  if (h->sparse)
+    return launch_dot_tiled_k(h, K, v_il, bpart(b, PS_C), ba,
+                              want_sums ? bpart(b, PS_SUMW) : nullptr,
+                              want_sums ? (PS_TWT - PS_SUMW) * K * NPART : 0);
+  return launch_dot_dense_k(h, K, v_il, ba,
+                            want_sums ? bpart(b, PS_TWT) : nullptr);
+}
+
+// slabs of X~^T w_c for the interleaved input, one pass over X
+static int batch_tdot(bbx_batch* b, const double* w_il, const double** slab,
+                      int* G, int64_t* slab_rows) {
+  bbx_design* h = b->h;
+  if (h->sparse) {
+    *slab_rows = h->p;
+    return launch_tdot_tiled_k(h, b->K, w_il, slab, G);
+  }
+  *slab_rows = h->dense_ld;
+  return launch_tdot_dense_k(h, b->K, w_il, slab, G);
+}
+
+// sum(w_c) partials of the Tdot epilogue: dense designs have no implicit
+// centring, their epilogue reads zeros
+static const double* batch_sumw(const bbx_batch* b) {
+  return bpart(b, b->h->sparse ? PS_SUMW : PS_ZERO);
+}
+
 // psi_c = X~ coef_c for every chain in one pass (the linear predictor of the
 // Omega update and of the log-likelihood, bayesbridge.py:401,407).
 static int batch_linear_predictor(bbx_batch* b) {
   bbx_design* h = b->h;
   const int K = b->K;
+  const BatchShape g = batch_shape(h);
   const ChainPtrs coef = gather_ptrs(b, &bbx_chain::coef);
   double* sp = b->sp.as<double>();
-  BBX_K_DISPATCH(K, hipLaunchKernelGGL(
-      b_prep_kernel<KK>, dim3(NPART), dim3(VEC_BLOCK), 0, h->stream, h->P,
-      h->intercept, nullptr, coef, nullptr, h->offset.as<double>(), sp,
-      bpart(b, PS_C)));
+  BBX_KC_LAUNCH(K, b_prep_kernel, h->stream, h->P, K, g.icpt, nullptr, coef,
+                nullptr, g.offset, sp, bpart(b, PS_C));
   BBX_HIP(hipGetLastError());
   TiledBatchArgs ba;
   for (int c = 0; c < K; ++c) ba.out.p[c] = b->chain[c]->psi.as<double>();
   ba.out_stride = 1;
   ba.part_stride = NPART;
-  return launch_dot_tiled_k(h, K, sp, bpart(b, PS_C), ba, nullptr, 0);
+  return batch_dot(b, sp, ba, false);
 }
 
 // K draws of the prior-preconditioned CG sampler in lock step: cg_sampler.hip
@@ -385,6 +464,7 @@ static int cg_sample_batch(bbx_batch* b, int maxiter, double atol,
   bbx_design* h = b->h;
   const int K = b->K;
   const int64_t P = h->P, n = h->n;
+  const BatchShape g = batch_shape(h);
   hipStream_t st_ = h->stream;
   double* s = b->s.as<double>();
   double* d = b->d.as<double>();
@@ -403,7 +483,7 @@ static int cg_sample_batch(bbx_batch* b, int maxiter, double atol,
   const ChainPtrs omega = gather_ptrs(b, &bbx_chain::obs_prec);
   ChainPtrs e1{}, e2{};
   ChainOut coef{};
-  int n_unshrunk = b->chain[0]->n_unshrunk;
+  const int n_unshrunk = b->chain[0]->n_unshrunk;
   for (int c = 0; c < K; ++c) {
     bbx_chain* ch = b->chain[c];
     const uint64_t seed = cg_draw_seed(ch, (uint64_t)ch->iter);
@@ -413,8 +493,6 @@ static int cg_sample_batch(bbx_batch* b, int maxiter, double atol,
     e2.p[c] = b->eta2[c].as<double>();
     coef.p[c] = ch->coef.as<double>();
   }
-  const double* offset = h->offset.as<double>();
-  const int twt_off = (PS_TWT - PS_SUMW) * K * NPART;
   TiledBatchArgs dot_args;
   for (int c = 0; c < K; ++c) {
     dot_args.rowscale.p[c] = omega.p[c];
@@ -423,30 +501,28 @@ static int cg_sample_batch(bbx_batch* b, int maxiter, double atol,
   dot_args.out_stride = K;
   dot_args.part_stride = NPART;
 
-  BBX_K_DISPATCH(K, hipLaunchKernelGGL(
-      b_setup_kernel<KK>, dim3(NPART), dim3(VEC_BLOCK), 0, st_, P, n_unshrunk,
-      phi, sd, x0, s, d, x, bs, atol));
+  BBX_KC_LAUNCH(K, b_setup_kernel, st_, P, K, n_unshrunk, phi, sd, x0, s, d, x,
+                bs, atol);
   // r = b - A x0 through ONE transposed product (cg_sampler.hip, TD_RESID)
   const double* t0 = nullptr;
   if (!cold) {
-    BBX_K_DISPATCH(K, hipLaunchKernelGGL(
-        b_prep_kernel<KK>, dim3(NPART), dim3(VEC_BLOCK), 0, st_, P,
-        h->intercept, x, ChainPtrs{}, s, offset, sp, bpart(b, PS_C)));
+    BBX_KC_LAUNCH(K, b_prep_kernel, st_, P, K, g.icpt, x, ChainPtrs{}, s,
+                  g.offset, sp, bpart(b, PS_C));
     BBX_HIP(hipGetLastError());
-    BBX_TRY(launch_dot_tiled_k(h, K, sp, bpart(b, PS_C), dot_args, nullptr, 0));
+    BBX_TRY(batch_dot(b, sp, dot_args, false));
     t0 = t;
   }
-  BBX_K_DISPATCH(K, hipLaunchKernelGGL(
-      b_sqrt_scale_kernel<KK>, dim3(NPART), dim3(VEC_BLOCK), 0, st_, n, omega,
-      e1, t0, w, bpart(b, PS_SUMW)));
+  BBX_KC_LAUNCH(K, b_sqrt_scale_kernel, st_, n, K, omega, e1, t0, w,
+                bpart(b, PS_SUMW));
   BBX_HIP(hipGetLastError());
   const double* slab = nullptr;
   int G = 0;
-  BBX_TRY(launch_tdot_tiled_k(h, K, w, &slab, &G));
-  BBX_K_DISPATCH(K, hipLaunchKernelGGL(
-      (b_finalize_kernel<KK, TD_RESID>), dim3(NPART), dim3(VEC_BLOCK), 0, st_,
-      h->p, h->intercept, slab, G, offset, bpart(b, PS_SUMW), s, d, pvec, x, r,
-      z, phi, e2, cold ? 0 : 1, bpart(b, PS_RR), bs, 0, nullptr, nullptr));
+  int64_t slab_rows = 0;
+  BBX_TRY(batch_tdot(b, w, &slab, &G, &slab_rows));
+  BBX_KC_LAUNCH_MODE(K, b_finalize_kernel, TD_RESID, st_, g.p_main, K, g.icpt,
+                     slab, G, slab_rows, g.offset, batch_sumw(b), s, d, pvec, x,
+                     r, z, phi, e2, cold ? 0 : 1, bpart(b, PS_RR), bs, 0,
+                     nullptr, nullptr);
   BBX_HIP(hipGetLastError());
 
   struct SkipScope {
@@ -458,31 +534,27 @@ static int cg_sample_batch(bbx_batch* b, int maxiter, double atol,
   } skip_scope{h};
   h->skip_flag = &bs->all_done;
   auto direction = [&](int kk) -> int {
-    BBX_K_DISPATCH(K, hipLaunchKernelGGL(
-        b_direction_kernel<KK>, dim3(NPART), dim3(VEC_BLOCK), 0, st_, P,
-        h->intercept, kk, bs, bpart(b, PS_RR), r, pvec, s, offset, sp,
-        bpart(b, PS_C), d, bpart(b, PS_PDP)));
+    BBX_KC_LAUNCH(K, b_direction_kernel, st_, P, K, g.icpt, kk, bs,
+                  bpart(b, PS_RR), r, pvec, s, g.offset, sp, bpart(b, PS_C), d,
+                  bpart(b, PS_PDP));
     BBX_HIP(hipGetLastError());
     return BBX_OK;
   };
   auto operator_and_update = [&](int kk) -> int {
     h->timer.cur_tag = kk;
     BBX_TRY(timer_begin(h, 2));
-    BBX_TRY(launch_dot_tiled_k(h, K, sp, bpart(b, PS_C), dot_args,
-                               bpart(b, PS_SUMW), twt_off));
-    BBX_TRY(launch_tdot_tiled_k(h, K, t, &slab, &G));
-    BBX_K_DISPATCH(K, hipLaunchKernelGGL(
-        (b_finalize_kernel<KK, TD_OPER_UPD>), dim3(NPART), dim3(VEC_BLOCK), 0,
-        st_, h->p, h->intercept, slab, G, offset, bpart(b, PS_SUMW), s, d,
-        pvec, x, r, ChainPtrs{}, ChainPtrs{}, ChainPtrs{}, 0, bpart(b, PS_RR),
-        bs, kk, bpart(b, PS_PDP), bpart(b, PS_TWT)));
+    BBX_TRY(batch_dot(b, sp, dot_args, true));
+    BBX_TRY(batch_tdot(b, t, &slab, &G, &slab_rows));
+    BBX_KC_LAUNCH_MODE(K, b_finalize_kernel, TD_OPER_UPD, st_, g.p_main, K,
+                       g.icpt, slab, G, slab_rows, g.offset, batch_sumw(b), s, d,
+                       pvec, x, r, ChainPtrs{}, ChainPtrs{}, ChainPtrs{}, 0,
+                       bpart(b, PS_RR), bs, kk, bpart(b, PS_PDP),
+                       bpart(b, PS_TWT));
     BBX_HIP(hipGetLastError());
     return timer_end(h, 2);
   };
   auto finish = [&]() -> int {
-    BBX_K_DISPATCH(K, hipLaunchKernelGGL(
-        b_finish_kernel<KK>, dim3(NPART), dim3(VEC_BLOCK), 0, st_, P, s, x,
-        coef));
+    BBX_KC_LAUNCH(K, b_finish_kernel, st_, P, K, s, x, coef);
     BBX_HIP(hipGetLastError());
     BBX_HIP(hipMemcpyAsync(host_bs, bs, sizeof(BatchState),
                            hipMemcpyDeviceToHost, st_));
@@ -562,8 +634,10 @@ int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,
   if (!out) return fail(BBX_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (!design || !chains) return fail(BBX_ERR_INVALID, "NULL argument");
-  if (n_chain != 2 && n_chain != 4)
-    return fail(BBX_ERR_INVALID, "a batch holds 2 or 4 chains");
+  if (n_chain != 2 && n_chain != 4 && n_chain != 8 && n_chain != 16)
+    return fail(BBX_ERR_INVALID, "a batch holds 2, 4, 8 or 16 chains");
+  if (design->sparse && n_chain > 4)
+    return fail(BBX_ERR_INVALID, "sparse designs batch 2 or 4 chains");
   for (int c = 0; c < n_chain; ++c) {
     if (!chains[c] || chains[c]->h != design)
       return fail(BBX_ERR_INVALID,
@@ -576,10 +650,13 @@ int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,
                   "the chains of a batch must agree on n_unshrunk");
   }
   bbx_design* h = design;
-  if (!h->sparse || h->format != BBX_FORMAT_TILED)
+  if (h->sparse && h->format != BBX_FORMAT_TILED)
     return fail(BBX_ERR_STATE,
-                "batched chains need a sparse design in the tiled format");
-  if (!h->binary && n_chain > 2)
+                "batched chains need the tiled format of a sparse design");
+  if (!h->sparse && !dense_batch_applies(h))
+    return fail(BBX_ERR_STATE,
+                "batched chains need f32 storage of a dense design");
+  if (h->sparse && !h->binary && n_chain > 2)
     return fail(BBX_ERR_INVALID,
                 "designs with stored values batch at most 2 chains (four valued "
                 "right-hand sides exceed the kernel's register budget)");
@@ -591,7 +668,7 @@ int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,
   for (int c = 0; c < n_chain; ++c) b->chain[c] = chains[c];
   const size_t K = (size_t)n_chain;
   auto body = [&]() -> int {
-    BBX_TRY(ensure_tiled_k(h, n_chain));
+    if (h->sparse) BBX_TRY(ensure_tiled_k(h, n_chain));
     for (DevMem* m : {&b->s, &b->d, &b->x, &b->r, &b->p, &b->sp})
       BBX_TRY(m->alloc(sizeof(double) * (size_t)(h->P + 2) * K));
     BBX_TRY(b->t.alloc(sizeof(double) * (size_t)h->n * K));
@@ -649,7 +726,7 @@ static int bbx_batch_run_impl(bbx_batch* b, int n_iter, int n_burnin, int thin,
   for (int c = 0; c < K; ++c) BBX_TRY(chain_begin_run(b->chain[c], n_sample));
   int n_unconverged = 0;
   for (int it = 1; it <= n_iter; ++it) {
-    int ncg[BATCH_MAX] = {0, 0, 0, 0}, info[BATCH_MAX] = {0, 0, 0, 0};
+    int ncg[BATCH_MAX] = {}, info[BATCH_MAX] = {};
     BBX_TRY(batch_step(b, maxiter, atol, ncg, info));
     for (int c = 0; c < K; ++c)
       if (info[c] > 0) ++n_unconverged;
@@ -688,6 +765,7 @@ int bbx_batch_dot(bbx_batch* b, const double* v, double* out) {
     bbx_design* h = b->h;
     const int K = b->K;
     const int64_t P = h->P, n = h->n;
+    const BatchShape g = batch_shape(h);
     BBX_HIP(hipSetDevice(h->device));
     DevMem dv, dout;
     BBX_TRY(dv.alloc(sizeof(double) * (size_t)(K * P)));
@@ -703,12 +781,10 @@ int bbx_batch_dot(bbx_batch* b, const double* v, double* out) {
     ba.out_stride = 1;
     ba.part_stride = NPART;
     double* sp = b->sp.as<double>();
-    BBX_K_DISPATCH(K, hipLaunchKernelGGL(
-        b_prep_kernel<KK>, dim3(NPART), dim3(VEC_BLOCK), 0, h->stream, P,
-        h->intercept, nullptr, src, nullptr, h->offset.as<double>(), sp,
-        bpart(b, PS_C)));
+    BBX_KC_LAUNCH(K, b_prep_kernel, h->stream, P, K, g.icpt, nullptr, src,
+                  nullptr, g.offset, sp, bpart(b, PS_C));
     BBX_HIP(hipGetLastError());
-    BBX_TRY(launch_dot_tiled_k(h, K, sp, bpart(b, PS_C), ba, nullptr, 0));
+    BBX_TRY(batch_dot(b, sp, ba, false));
     BBX_HIP(hipMemcpyAsync(out, dout.ptr, sizeof(double) * (size_t)(K * n),
                            hipMemcpyDeviceToHost, h->stream));
     BBX_HIP(hipStreamSynchronize(h->stream));
@@ -722,6 +798,7 @@ int bbx_batch_tdot(bbx_batch* b, const double* w, double* out) {
     bbx_design* h = b->h;
     const int K = b->K;
     const int64_t P = h->P, n = h->n;
+    const BatchShape g = batch_shape(h);
     BBX_HIP(hipSetDevice(h->device));
     // interleave on the host: the kernels take [n][K]
     std::vector<double> il((size_t)(K * n)), res((size_t)(K * P));
@@ -730,27 +807,25 @@ int bbx_batch_tdot(bbx_batch* b, const double* w, double* out) {
     double* dw = b->w.as<double>();
     BBX_HIP(hipMemcpyAsync(dw, il.data(), sizeof(double) * il.size(),
                            hipMemcpyHostToDevice, h->stream));
-    // partials of sum(w_c): -sqrt(1) * (-w) = w through the scaling kernel
-    // would round; a plain pass instead: w = w - sqrt(0) * 0
+    // partials of sum(w_c) through the scaling kernel: w = w - sqrt(0) * 0
     DevMem zeros;
     BBX_TRY(zeros.alloc(sizeof(double) * (size_t)n));
     BBX_HIP(hipMemsetAsync(zeros.ptr, 0, sizeof(double) * (size_t)n, h->stream));
     ChainPtrs zp{};
     for (int c = 0; c < K; ++c) zp.p[c] = zeros.as<double>();
-    BBX_K_DISPATCH(K, hipLaunchKernelGGL(
-        b_sqrt_scale_kernel<KK>, dim3(NPART), dim3(VEC_BLOCK), 0, h->stream, n,
-        zp, zp, dw, dw, bpart(b, PS_SUMW)));
+    BBX_KC_LAUNCH(K, b_sqrt_scale_kernel, h->stream, n, K, zp, zp, dw, dw,
+                  bpart(b, PS_SUMW));
     BBX_HIP(hipGetLastError());
     const double* slab = nullptr;
     int G = 0;
-    BBX_TRY(launch_tdot_tiled_k(h, K, dw, &slab, &G));
+    int64_t slab_rows = 0;
+    BBX_TRY(batch_tdot(b, dw, &slab, &G, &slab_rows));
     double* r = b->r.as<double>();
-    BBX_K_DISPATCH(K, hipLaunchKernelGGL(
-        (b_finalize_kernel<KK, TD_PLAIN>), dim3(NPART), dim3(VEC_BLOCK), 0,
-        h->stream, h->p, h->intercept, slab, G, h->offset.as<double>(),
-        bpart(b, PS_SUMW), nullptr, nullptr, nullptr, nullptr, r, ChainPtrs{},
-        ChainPtrs{}, ChainPtrs{}, 0, nullptr, b->state.as<BatchState>(), 0,
-        nullptr, nullptr));
+    BBX_KC_LAUNCH_MODE(K, b_finalize_kernel, TD_PLAIN, h->stream, g.p_main, K,
+                       g.icpt, slab, G, slab_rows, g.offset, batch_sumw(b),
+                       nullptr, nullptr, nullptr, nullptr, r, ChainPtrs{},
+                       ChainPtrs{}, ChainPtrs{}, 0, nullptr,
+                       b->state.as<BatchState>(), 0, nullptr, nullptr);
     BBX_HIP(hipGetLastError());
     BBX_HIP(hipMemcpyAsync(res.data(), r, sizeof(double) * res.size(),
                            hipMemcpyDeviceToHost, h->stream));
@@ -773,7 +848,7 @@ int bbx_batch_run_host(bbx_batch* b, int n_iter, int n_burnin, int thin,
     const int64_t P = b->h->P;
     const int64_t n_sample = (n_iter - n_burnin) / thin;
     DevMem dc[BATCH_MAX];
-    double* ptrs[BATCH_MAX] = {nullptr, nullptr, nullptr, nullptr};
+    double* ptrs[BATCH_MAX] = {};
     if (coef)
       for (int c = 0; c < b->K; ++c) {
         BBX_TRY(dc[c].alloc(sizeof(double) * (size_t)(n_sample * P + 1)));
@@ -796,7 +871,8 @@ int bbx_batch_bytes(const bbx_batch* b, int64_t* dot_bytes,
                     int64_t* tdot_bytes) {
   if (!b || !b->h) return fail(BBX_ERR_INVALID, "batch handle is NULL");
   int64_t db = 0, tb = 0;
-  BBX_TRY(tiled_batch_bytes(b->h, b->K, &db, &tb));
+  if (b->h->sparse) BBX_TRY(tiled_batch_bytes(b->h, b->K, &db, &tb));
+  else BBX_TRY(dense_batch_bytes(b->h, b->K, &db, &tb));
   if (dot_bytes) *dot_bytes = db;
   if (tdot_bytes) *tdot_bytes = tb;
   return BBX_OK;

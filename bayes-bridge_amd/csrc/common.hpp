@@ -101,7 +101,7 @@ int no_throw(F&& f) noexcept {
 
 // Chains that may share one pass over a sparse design (batched chains); the
 // per-chain device pointers the batched kernels take by value.
-constexpr int BATCH_MAX = 4;
+constexpr int BATCH_MAX = 16;  // (sparse designs: 4; dense f32 designs: 16)
 struct ChainPtrs {
   const double* p[BATCH_MAX];
 };
@@ -190,6 +190,7 @@ struct bbx_design {
                       // centred, zero padded), f32 or f64
   bbx::DevMem dense_slab;  // Tdot partial sums [dense_chunks][dense_ld]
   bbx::DevMem dense_fused_slab;  // fused operator: [workgroups][dense_ld]
+  bbx::DevMem dense_batch_slab;  // batched Tdot: [row chunks][dense_ld][K]
   int dense_fused_wgs = 0;
   int64_t dense_ld = 0;
   int dense_chunks = 1;
@@ -348,6 +349,17 @@ int launch_dot_tiled_k(bbx_design* h, int K, const double* d_v,
 int launch_tdot_tiled_k(bbx_design* h, int K, const double* d_w,
                         const double** slab, int* G);
 int tiled_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
+                      int64_t* tdot_bytes);
+// The same two products for dense f32 designs on the matrix cores, K = 2, 4,
+// 8 or 16 (dense_batch.hip): t_c = rowscale_c .* (X v_c) with the partials of
+// <t_c, Omega_c t_c> (d_twt_part[c * NPART + ...], may be null), and the slabs
+// [G][ld][K] of X^T w_c.
+bool dense_batch_applies(const bbx_design* h);
+int launch_dot_dense_k(bbx_design* h, int K, const double* d_v,
+                       const TiledBatchArgs& ba, double* d_twt_part);
+int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
+                        const double** slab, int* G);
+int dense_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
                       int64_t* tdot_bytes);
 // timed_only: count what the timed kernel of each family moves (tiled Tdot:
 // without the epilogue kernel's slab read and P-vector output)

@@ -396,8 +396,10 @@ int bbx_chain_run_host(bbx_chain* c, int n_iter, int n_burnin, int thin,
  * (bit for bit), and differ from `bbx_chain_run` only by the rounding of the
  * differently blocked sums.
  *
- * `chains`: n_chain (2 or 4; dense designs: 2 ... 8) chains created with
- * bbx_chain_create on `design` (sparse: tiled format).  The batch borrows them:
+ * `chains`: n_chain chains created with bbx_chain_create on `design` -- 2 or 4
+ * for sparse designs in the tiled format (2 when values are stored), 2, 4, 8 or
+ * 16 for dense designs with f32 storage (there the K-column products run on
+ * the matrix cores, v_mfma_f64_16x16x4_f64).  The batch borrows them:
  * set/get their state through the bbx_chain_* calls between runs, destroy the
  * batch before its chains.  The first batch of a width builds the matching
  * layout of the design (host pass, ~1 s at 1M x 50k). */

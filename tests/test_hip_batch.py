@@ -167,6 +167,70 @@ def test_batched_chain_on_a_mixed_design_and_resume():
         assert np.array_equal(joined, s[key]), key
 
 
+def _dense_problem(n, p, seed=2):
+    from bayesbridge_amd import HipDenseDesignMatrix
+    rng = np.random.default_rng(seed)
+    # f32-representable entries: the f64 reference sees the stored numbers
+    X = rng.standard_normal((n, p)).astype(np.float32).astype(np.float64)
+    beta = np.zeros(p)
+    beta[:5], beta[5:10] = 1.5, -1.
+    y = X @ beta + rng.standard_normal(n)
+    hip = HipDenseDesignMatrix(X, center_predictor=False, add_intercept=True,
+                               storage_dtype='float32')
+    return X, y, hip
+
+
+@pytest.mark.parametrize("K", [2, 4, 8, 16])
+@pytest.mark.parametrize("shape", [(5000, 700), (20000, 4500), (4097, 8190)])
+def test_dense_batched_products_on_the_matrix_cores(K, shape):
+    """K-column dense products (dense_batch.hip: v_mfma_f64_16x16x4_f64, the
+    chains in the 16 columns of the B operand) against NumPy in f64 on the
+    stored f32 entries: <= 1e-11 of the result's scale (the reference's own
+    bound against the explicit matrix is 1e-5, test_design_matrix.py:12-24),
+    and a column never sees its neighbours (permuted inputs give the permuted
+    outputs bit for bit)."""
+    from bayesbridge_amd import HipChainBatch
+    n, p = shape
+    X, y, hip = _dense_problem(n, p)
+    batch = HipChainBatch(_chains(hip, y, 'linear', list(range(K))))
+    rng = np.random.default_rng(9)
+    P = p + 1
+    v, w = rng.standard_normal((K, P)), rng.standard_normal((K, n))
+    got_v, got_w = batch.dot(v), batch.Tdot(w)
+    Xi = np.hstack([np.ones((n, 1)), X])
+    ref_v, ref_w = v @ Xi.T, w @ Xi
+    assert np.abs(got_v - ref_v).max() <= 1e-11 * np.abs(ref_v).max()
+    assert np.abs(got_w - ref_w).max() <= 1e-11 * np.abs(ref_w).max()
+    perm = np.roll(np.arange(K), 1)
+    assert np.array_equal(batch.dot(v[perm]), got_v[perm])
+    assert np.array_equal(batch.Tdot(w[perm]), got_w[perm])
+    # and the single-chain operator of the same handle (VALU kernels)
+    assert np.abs(hip.dot(v[0]) - got_v[0]).max() <= 1e-11 * np.abs(ref_v).max()
+    assert np.abs(hip.Tdot(w[0]) - got_w[0]).max() <= 1e-11 * np.abs(ref_w).max()
+
+
+@pytest.mark.parametrize("K", [2, 4, 8])
+def test_a_dense_chain_does_not_depend_on_its_batch(K):
+    """The dense counterpart of test_a_chain_does_not_depend_on_its_batch."""
+    from bayesbridge_amd import HipChainBatch
+    X, y, hip = _dense_problem(6000, 400)
+    seeds_1 = [17, 23, 31, 47, 3, 5, 7, 11][:K]
+    seeds_2 = [61, 17, 6, 9, 13, 19, 29, 37][:K]    # A = seed 17 moves to slot 1
+    s1, u1 = HipChainBatch(_chains(hip, y, 'linear', seeds_1)).run(5)
+    s2, u2 = HipChainBatch(_chains(hip, y, 'linear', seeds_2)).run(5)
+    assert u1 == 0 and u2 == 0
+    for key in ('coef', 'global_scale', 'logp', 'n_cg_iter'):
+        assert np.array_equal(s1[key][0], s2[key][1]), key
+    alone = _chains(hip, y, 'linear', [17])[0]
+    kept, _ = alone.run(5, save=('coef',))
+    scale = max(1., np.abs(kept['coef'][0]).max())
+    same_count = kept['n_cg_iter'][0] == s1['n_cg_iter'][0][0]
+    tol = 1e-6 if same_count else 1e-5
+    assert np.abs(kept['coef'][0] - s1['coef'][0][0]).max() <= tol * scale
+    assert abs(kept['n_cg_iter'][0] - s1['n_cg_iter'][0][0]) <= \
+        max(2, .05 * kept['n_cg_iter'][0])
+
+
 def test_batch_argument_checks():
     from bayesbridge_amd import BbxError, HipChainBatch
     X, y, hip = _problem(2000, 100, 'linear')
@@ -174,7 +238,7 @@ def test_batch_argument_checks():
     a, b, c = _chains(hip, y, 'linear', [1, 2, 3])
     other = _chains(hip2, y2, 'linear', [4])[0]
     with pytest.raises(BbxError):
-        HipChainBatch([a, b, c])             # 2 or 4 chains
+        HipChainBatch([a, b, c])             # 2, 4 (8, 16 dense) chains
     with pytest.raises(BbxError):
         HipChainBatch([a, a])                # a chain twice
     with pytest.raises(BbxError):
