@@ -176,6 +176,13 @@ class BayesBridge():
             out = self._gibbs_device(
                 n_iter, n_burnin, thin, seed, init, params_to_save, options,
                 _resume_from)
+        return self._package(out, n_iter, n_burnin, thin, seed, params_to_save,
+                             options, time.time() - start_time)
+
+    def _package(self, out, n_iter, n_burnin, thin, seed, params_to_save,
+                 options, runtime):
+        """(samples, mcmc_info) of one chain in the reference's format
+        (bayesbridge.py:242-277)."""
         samples, sampling_info, state, init_used, optim_info, extra = out
         coef, obs_prec, lscale, gscale = state
         # exact (raw-parametrisation) state: resuming from it is bitwise
@@ -185,7 +192,6 @@ class BayesBridge():
                      'obs_prec': np.array(obs_prec, copy=True),
                      'local_scale': np.array(lscale, copy=True),
                      'global_scale': float(gscale)}
-        runtime = time.time() - start_time
         if self.prior._gscale_paramet == 'coef_magnitude':  # bayesbridge.py:244-251
             gscale, lscale = self.prior.adjust_scale(
                 gscale, lscale, to='coef_magnitude')
@@ -214,6 +220,79 @@ class BayesBridge():
         }
         mcmc_info.update(extra)
         return samples, mcmc_info
+
+    def batch_width(self, n_chain, params_to_save=('coef', 'global_scale',
+                                                   'logp'), options=None):
+        """How many of `n_chain` chains one batch can hold on this model's
+        design (0: batching does not apply): sparse tiled designs 2 or 4 (2
+        with stored values; pairs are what pays), dense f32
+        designs 2, 4, 8 or 16.  Batches keep 'coef', 'global_scale', 'logp'
+        and use the device RNG."""
+        design = self.model.design
+        if options is not None and not isinstance(options, SamplerOptions):
+            options = SamplerOptions.pick_default_and_create(
+                None, options, self.model.name, design)
+        if options is not None and options.rng != 'device':
+            return 0
+        if params_to_save == 'all' or not set(params_to_save) <= {
+                'coef', 'global_scale', 'logp'}:
+            return 0
+        if design.is_sparse:
+            if design.storage_format != 'tiled':
+                return 0
+            widths = (2,)
+        else:
+            if design.storage_dtype != 'float32':
+                return 0
+            widths = (16, 8, 4, 2)
+        for w in widths:
+            if w <= n_chain:
+                return w
+        return 0
+
+    def gibbs_batch(self, seeds, n_iter, n_burnin=0, thin=1,
+                    init={'global_scale': 0.1},
+                    params_to_save=('coef', 'global_scale', 'logp'),
+                    options=None):
+        """len(seeds) chains of `gibbs(...)` stepped as ONE batch that shares
+        every pass over the design (HipChainBatch; csrc/batch.hip).  The
+        reference's way to more chains is more processes (bayesbridge.py:109).
+        Returns a list of (samples, mcmc_info), one per seed, in gibbs()'s
+        format; a chain's samples do not depend on its companions."""
+        import copy
+        from .device_chain import HipChainBatch
+        if not isinstance(options, SamplerOptions):
+            options = SamplerOptions.pick_default_and_create(
+                None, options, self.model.name, self.model.design)
+        if options.rng != 'device':
+            raise ValueError("batched chains use the device RNG")
+        if not set(params_to_save) <= {'coef', 'global_scale', 'logp'}:
+            raise ValueError("a batch keeps 'coef', 'global_scale' and 'logp'")
+        start_time = time.time()
+        seeds = [int(sd) for sd in seeds]
+        chains, setups = [], []
+        for sd in seeds:
+            chain = self._new_chain(sd)
+            setups.append(self._device_setup(chain, sd, copy.deepcopy(init),
+                                             options))
+            chains.append(chain)
+        batch = HipChainBatch(chains)
+        kept, n_unconv = batch.run(n_iter, n_burnin, thin, maxiter=500,
+                                   atol=0., save_coef='coef' in params_to_save)
+        batch.close()
+        runtime = time.time() - start_time
+        results = []
+        for k, (chain, sd) in enumerate(zip(chains, seeds)):
+            mine = {key: val[k] for key, val in kept.items()}
+            out = self._device_collect(chain, sd, mine,
+                                       n_unconv if k == 0 else 0, n_iter,
+                                       n_burnin, thin, params_to_save,
+                                       *setups[k])
+            results.append(self._package(out, n_iter, n_burnin, thin, sd,
+                                         params_to_save, options, runtime))
+            results[-1][1]['batch'] = {'width': len(seeds), 'slot': k}
+            chain.close()
+        return results
 
     def gibbs_multichain(self, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
                          init={'global_scale': 0.1},
@@ -480,17 +559,20 @@ class BayesBridge():
                 init_used, optim_info, extra)
 
     # -------------------------------------------------- mode 2: device chain
-    def _make_chain(self, seed):
-        self._destroy_chain()
+    def _new_chain(self, seed):
         model, prior = self.model, self.prior
         hyper = prior.param['gscale_neg_power']
-        self._chain = HipGibbsChain(
+        return HipGibbsChain(
             model.design, model.name,
             model.y if model.name == 'linear' else model.n_success,
             n_trial=model.n_trial if model.name == 'logit' else None,
             sd_unshrunk=self.prior_sd_for_unshrunk,
             bridge_exponent=prior.bridge_exp, slab_size=prior.slab_size,
             gscale_shape=hyper['shape'], gscale_rate=hyper['rate'], seed=seed)
+
+    def _make_chain(self, seed):
+        self._destroy_chain()
+        self._chain = self._new_chain(seed)
         self._chain_seed = seed
 
     def _gibbs_device(self, n_iter, n_burnin, thin, seed, init,
@@ -501,8 +583,6 @@ class BayesBridge():
             seed = resume_from['_random_gen_state']['seed']
         elif seed is None:
             seed = int(np.random.SeedSequence().generate_state(1)[0])
-        sampler = HipRegressionCoefficientSampler(
-            self.n_pred, self.prior_sd_for_unshrunk, 'cg', prior.slab_size)
         if resume_from is None or self._chain is None:
             self._make_chain(seed)
         elif self._chain_seed != seed:
@@ -511,6 +591,26 @@ class BayesBridge():
             self._chain.seed = seed
             self._chain_seed = seed
         chain = self._chain
+        init_used, optim_info = self._device_setup(chain, seed, init, options,
+                                                   resume_from)
+        samples, _ = self._pre_allocate(n_iter - n_burnin, thin,
+                                        params_to_save)
+        kept, n_unconv = chain.run(
+            n_iter, n_burnin, thin, maxiter=500, atol=0.,
+            save=[k for k in ('coef', 'local_scale', 'obs_prec')
+                  if k in samples])
+        return self._device_collect(chain, seed, kept, n_unconv, n_iter,
+                                    n_burnin, thin, params_to_save, init_used,
+                                    optim_info)
+
+    def _device_setup(self, chain, seed, init, options, resume_from=None):
+        """Brings a device chain to its initial state (bayesbridge.py:279-333:
+        initial values, optional mode search); returns (init_used,
+        optim_info)."""
+        model, prior = self.model, self.prior
+        bridge_exp = prior.bridge_exp
+        sampler = HipRegressionCoefficientSampler(
+            self.n_pred, self.prior_sd_for_unshrunk, 'cg', prior.slab_size)
         chain.set_gscale_update(options.gscale_update)
         if resume_from is not None:
             st = resume_from['_reg_coef_sampler_state']
@@ -570,13 +670,14 @@ class BayesBridge():
                                    update_obs_precision, update_global_scale,
                                    sampler)
         chain.set_state(coef, obs_prec, lscale, gscale)
+        return init_used, optim_info
 
+    def _device_collect(self, chain, seed, kept, n_unconv, n_iter, n_burnin,
+                        thin, params_to_save, init_used, optim_info):
+        """Sample-major device output -> the reference's `samples` layout."""
+        model = self.model
         samples, sampling_info = self._pre_allocate(
             n_iter - n_burnin, thin, params_to_save)
-        kept, n_unconv = chain.run(
-            n_iter, n_burnin, thin, maxiter=500, atol=0.,
-            save=[k for k in ('coef', 'local_scale', 'obs_prec')
-                  if k in samples])
         if n_unconv > 0:
             warn("The conjugate gradient algorithm did not achieve the "
                  "requested tolerance level in %d iteration(s)." % n_unconv)

@@ -150,17 +150,38 @@ def run_chains(bridge, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
     per_rank = -(-n_chain // world)               # ranks pad to equal counts
     init = {'global_scale': .1} if init is None else init
     kept, infos = {}, []
-    for k in mine:
-        samples, info = bridge.gibbs(
-            n_iter, n_burnin, thin, seed=chain_seed(seed, k),
-            init=copy.deepcopy(init), params_to_save=params_to_save,
-            coef_sampler_type='cg', options=options)
+
+    def keep(k, samples, info):
         info['chain'] = k
         infos.append(info)
         samples = dict(samples)
         samples['n_cg_iter'] = info['_reg_coef_sampling_info']['n_cg_iter']
         for name, arr in samples.items():
             kept.setdefault(name, []).append(np.asarray(arr, dtype=np.float64))
+    # More chains than ranks: this rank's chains go through the design in
+    # BATCHES that share every pass over X (BayesBridge.gibbs_batch) instead of
+    # one after the other; what does not fill a batch runs alone.  A chain's
+    # seed (hence its Philox streams) is seed + k either way; batched and
+    # single runs of a chain agree to rounding, not bit for bit.
+    todo = list(mine)
+    width_of = getattr(bridge, 'batch_width', None)
+    while todo:
+        width = width_of(len(todo), params_to_save, options) if width_of else 0
+        if width >= 2:
+            group, todo = todo[:width], todo[width:]
+            results = bridge.gibbs_batch(
+                [chain_seed(seed, k) for k in group], n_iter, n_burnin, thin,
+                init=copy.deepcopy(init), params_to_save=params_to_save,
+                options=options)
+            for k, (samples, info) in zip(group, results):
+                keep(k, samples, info)
+        else:
+            k = todo.pop(0)
+            samples, info = bridge.gibbs(
+                n_iter, n_burnin, thin, seed=chain_seed(seed, k),
+                init=copy.deepcopy(init), params_to_save=params_to_save,
+                coef_sampler_type='cg', options=options)
+            keep(k, samples, info)
     names = sorted(kept) if kept else None
     if world > 1:                                 # ranks without a chain
         import torch.distributed as dist

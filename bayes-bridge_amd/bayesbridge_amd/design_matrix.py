@@ -356,6 +356,7 @@ class HipDenseDesignMatrix(HipDesignMatrix):
                 np.mean(X, axis=0, dtype=np.float64), dtype=np.float64)
         self.column_offset = offset
         st = {'float64': _lib.F64, 'float32': _lib.F32}[storage_dtype]
+        self.storage_dtype = storage_dtype
         _lib.check(self._lib.bbx_design_create_dense(
             n, p, _ptr(X), in_dtype, st, _ptr(offset),
             int(bool(add_intercept)), int(device), byref(self._h)))
@@ -373,6 +374,7 @@ class HipDenseDesignMatrix(HipDesignMatrix):
         self.centered = offset_ptr is not None
         self.intercept_added = add_intercept
         self.column_offset = None
+        self.storage_dtype = storage_dtype
         code = {'float64': _lib.F64, 'float32': _lib.F32}
         _lib.check(self._lib.bbx_design_create_dense_dev(
             n, p, c_void_p(X_ptr), code[in_dtype], code[storage_dtype],

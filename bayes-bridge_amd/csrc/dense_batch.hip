@@ -32,16 +32,37 @@
 // numbers do not depend on the other chains of the batch (bit for bit).
 #include "common.hpp"
 
+// -DDK_ABLATE=1: no DMA (stale LDS), =2: no MFMAs -- timing only, wrong results
+#ifndef DK_ABLATE
+#define DK_ABLATE 0
+#endif
+
 namespace bbx {
 
 typedef double dk_d4 __attribute__((ext_vector_type(4)));
 
-constexpr int DK_ROWS = 64;                 // rows of a stage
+// Stage geometry, measured at 200k x 8k, K = 16 (profiles/r03_dense_batch.txt):
+//   X V   : 64 rows x 4 waves 3.51 ms, 32 rows x 8 waves 2.09 ms, 16 x 16 4.14
+//   X^T W : 64 rows x 4 waves 2.08 ms, 32 rows x 8 waves 2.95 ms, 16 x 16 5.36
+// (128 KB of LDS per CU either way, two stages per wave)
+#ifndef DK_DOT_ROWS
+#define DK_DOT_ROWS 32
+#endif
+#ifndef DK_TDOT_ROWS
+#define DK_TDOT_ROWS 64
+#endif
 constexpr int DK_COLS = 64;                 // columns of a stage (256 B of f32)
-constexpr int DK_STAGE_BYTES = DK_ROWS * DK_COLS * 4;
-constexpr int DK_WAVES = 4;                 // per workgroup: one per SIMD
 constexpr int DK_STAGES = 2;
-constexpr int DK_LDS_BYTES = DK_WAVES * DK_STAGES * DK_STAGE_BYTES;  // 128 KB
+template <int ROWS>
+struct DkGeom {
+  static constexpr int rows = ROWS;             // rows of a stage
+  static constexpr int nt = ROWS / 16;          // 16-row tiles of a stage
+  static constexpr int stage_bytes = ROWS * DK_COLS * 4;
+  static constexpr int waves = 256 / ROWS;      // per workgroup (and CU)
+  static constexpr int lds_bytes = waves * DK_STAGES * stage_bytes;  // 128 KB
+};
+using DkDot = DkGeom<DK_DOT_ROWS>;
+using DkTdot = DkGeom<DK_TDOT_ROWS>;
 constexpr int DK_DOT_WGS = 256;             // one workgroup per CU
 constexpr int DK_TDOT_CHUNKS = 8;           // row chunks of the transposed product
 
@@ -55,10 +76,11 @@ __device__ __forceinline__ void dk_glds16(const void* gsrc, unsigned lds_dst) {
       : "memory");
 }
 
-// 16 DMA instructions: rows [row0, row0 + 64) x columns [col0, col0 + 64) of
+// ROWS / 4 DMA instructions: rows [row0, row0 + ROWS) x columns [col0, col0 + 64) of
 // the row-major f32 matrix into the wave's stage.  Rows / quads past the end
 // are clamped to the last valid ones (finite values that only ever meet a zero
 // B operand), so that every wave issues the same number of DMAs.
+template <int ROWS>
 __device__ __forceinline__ void dk_issue_stage(const float* __restrict__ X,
                                                int64_t n /* row clamp */,
                                                int64_t ld, int64_t row0,
@@ -66,7 +88,7 @@ __device__ __forceinline__ void dk_issue_stage(const float* __restrict__ X,
                                                unsigned stage_lds, int lane) {
   const int64_t ldq = ld / 4;
 #pragma unroll
-  for (int d = 0; d < DK_ROWS / 4; ++d) {
+  for (int d = 0; d < ROWS / 4; ++d) {
     const int r_in = 4 * d + (lane >> 4);
     int64_t row = row0 + r_in;
     if (row >= n) row = n - 1;
@@ -74,7 +96,105 @@ __device__ __forceinline__ void dk_issue_stage(const float* __restrict__ X,
     if (quad >= ldq) quad = ldq - 1;
     const unsigned dst =
         __builtin_amdgcn_readfirstlane(stage_lds + (unsigned)(d * 1024));
-    dk_glds16(reinterpret_cast<const float4*>(X) + row * ldq + quad, dst);
+    if (DK_ABLATE != 1)
+      dk_glds16(reinterpret_cast<const float4*>(X) + row * ldq + quad, dst);
+  }
+}
+
+// One group of NT 16-row tiles of T = X V (NT = DkDot::nt: the B operand of a stage
+// is used NT times, consecutive MFMAs go to NT accumulators; NT = 1, the
+// remainder of a wave's range: one accumulator per k-slot, added at the end).
+// Straight-line per stage: no branch sits between two MFMAs.
+template <int K, int NT>
+__device__ __forceinline__ void dk_dot_group(
+    int64_t n, int64_t P, int64_t ld, const float* __restrict__ X,
+    const double* __restrict__ v, const ChainPtrs& rowscale,
+    const ChainOut& out, int out_stride, int64_t tile, unsigned my_lds,
+    const unsigned char* my_stage, int lane, double& twt) {
+  const int i = lane & 15, k = lane >> 4;
+  const int64_t row0 = tile * 16;
+  int64_t row_lim = (tile + NT) * 16;  // rows past the group: its last row again
+  if (row_lim > n) row_lim = n;
+  const int n_stage = (int)((ld + DK_COLS - 1) / DK_COLS);
+  constexpr int NACC = NT == 1 ? 4 : NT;  // NT == 1: one accumulator per m
+  dk_d4 D[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) D[a] = dk_d4{0., 0., 0., 0.};
+  double bn[16], bc[16];
+  const int ic = i < K ? i : K - 1;  // clamped: the load is unconditional
+  auto load_b = [&](int s, double (&b)[16]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int64_t col = (int64_t)s * DK_COLS + 16 * c + 4 * k + m;
+        const double val = v[(col < P ? col : P - 1) * K + ic];
+        b[4 * c + m] = (i < K && col < P) ? val : 0.;
+      }
+  };
+  dk_issue_stage<DkDot::rows>(X, row_lim, ld, row0, 0, my_lds, lane);
+  load_b(0, bn);
+  for (int s = 0; s < n_stage; ++s) {
+    const int slot = s & 1;
+    // Stage s and its B operands have landed.  (The B loads are visible to the
+    // compiler, which would wait for them with vmcnt(0) anyway -- it does not
+    // count the DMAs -- so the wait comes BEFORE the next stage's requests are
+    // issued: exactly one stage is in flight during the MFMAs.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bc[u] = bn[u];
+    if (s + 1 < n_stage) {
+      dk_issue_stage<DkDot::rows>(X, row_lim, ld, row0, (int64_t)(s + 1) * DK_COLS,
+                     my_lds + (unsigned)((slot ^ 1) * DkDot::stage_bytes), lane);
+      load_b(s + 1, bn);
+    }
+    const float4* st4 =
+        reinterpret_cast<const float4*>(my_stage + slot * DkDot::stage_bytes);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double a[NT][4];
+#pragma unroll
+      for (int rt = 0; rt < NT; ++rt) {
+        const float4 x = st4[(16 * rt + i) * 16 + ((4 * c + k) ^ i)];
+        a[rt][0] = (double)x.x;
+        a[rt][1] = (double)x.y;
+        a[rt][2] = (double)x.z;
+        a[rt][3] = (double)x.w;
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+          constexpr bool split = NT == 1;
+          dk_d4& acc = D[split ? m : rt];
+          if (DK_ABLATE == 2) acc[0] += a[rt][m] * bc[4 * c + m];
+          else
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt][m], bc[4 * c + m], acc,
+                                                     0, 0, 0);
+        }
+    }
+    // every lane has read its part of the stage before this slot is refilled
+    // (next iteration, same wave: program order plus the LDS counter)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if (NT == 1) D[0] = (D[0] + D[1]) + (D[2] + D[3]);
+  // D[rt][reg] = t[row0 + 16 rt + k + 4 reg][chain i]
+  if (i < K) {
+    const double* rs = rowscale.p[i];
+    double* o = out.p[i];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t row = row0 + 16 * rt + k + 4 * reg;
+        if (row < n) {
+          const double t = D[rt][reg];
+          double w = t;
+          if (rs) w *= rs[row];
+          o[row * out_stride] = w;
+          twt = fma(w, t, twt);
+        }
+      }
   }
 }
 
@@ -82,122 +202,44 @@ __device__ __forceinline__ void dk_issue_stage(const float* __restrict__ X,
 // rowscale_c[row] * <X[row, :], v_c>, and per workgroup and chain the partials
 // of sum_i rowscale_c,i t_c,i^2 (twt_part[c * NPART + blockIdx.x]).
 template <int K>
-__global__ __launch_bounds__(DK_WAVES * WAVE) void dense_dot_k_kernel(
+__global__ __launch_bounds__(DkDot::waves * WAVE) void dense_dot_k_kernel(
     int64_t n, int64_t P, int64_t ld, const float* __restrict__ X,
     const double* __restrict__ v, ChainPtrs rowscale, ChainOut out,
     int out_stride, double* __restrict__ twt_part,
     const int* __restrict__ skip_flag) {
   if (skip_flag && *skip_flag) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char dk_smem[];
-  __shared__ double s_twt[DK_WAVES][16];
+  __shared__ double s_twt[DkDot::waves][16];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
-  const int i = lane & 15, k = lane >> 4;   // A: row i, k-slot k;  B/D: column i
   const unsigned my_lds = (unsigned)(uintptr_t)dk_smem +
-                          (unsigned)(wave * DK_STAGES * DK_STAGE_BYTES);
-  const unsigned char* my_stage = dk_smem + wave * DK_STAGES * DK_STAGE_BYTES;
+                          (unsigned)(wave * DK_STAGES * DkDot::stage_bytes);
+  const unsigned char* my_stage = dk_smem + wave * DK_STAGES * DkDot::stage_bytes;
   // contiguous ranges of 16-row tiles per wave, as even as 16-row tiles allow
   const int64_t n_tile = (n + 15) / 16;
-  const int64_t n_wave = (int64_t)gridDim.x * DK_WAVES;
-  const int64_t gw = (int64_t)blockIdx.x * DK_WAVES + wave;
+  const int64_t n_wave = (int64_t)gridDim.x * DkDot::waves;
+  const int64_t gw = (int64_t)blockIdx.x * DkDot::waves + wave;
   const int64_t base = n_tile / n_wave, extra = n_tile % n_wave;
   const int64_t t0 = gw * base + (gw < extra ? gw : extra);
   const int64_t t1 = t0 + base + (gw < extra ? 1 : 0);
-  const int n_stage = (int)((ld + DK_COLS - 1) / DK_COLS);
   double twt = 0.;  // this lane's part of <t_c, Omega_c t_c>, c = lane & 15
-  for (int64_t tile = t0; tile < t1; tile += 4) {
-    const int64_t row0 = tile * 16;
-    // a last, partial group: absent tiles cost neither HBM traffic (their rows
-    // are clamped to the group's last row: the same lines again) nor MFMAs
-    const int nt = (int)((t1 - tile < 4) ? (t1 - tile) : 4);
-    int64_t row_lim = (tile + nt) * 16;
-    if (row_lim > n) row_lim = n;
-    dk_d4 D[4];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) D[rt] = dk_d4{0., 0., 0., 0.};
-    double bn[16], bc[16];
-    auto load_b = [&](int s, double (&b)[16]) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int64_t col = (int64_t)s * DK_COLS + 16 * c + 4 * k + m;
-          b[4 * c + m] = (i < K && col < P) ? v[col * K + i] : 0.;
-        }
-    };
-    dk_issue_stage(X, row_lim, ld, row0, 0, my_lds, lane);
-    load_b(0, bn);
-    for (int s = 0; s < n_stage; ++s) {
-      const int slot = s & 1;
-      // Stage s and its B operands have landed.  (The B loads are visible to
-      // the compiler, which would wait for them with vmcnt(0) anyway -- it
-      // does not count the DMAs -- so the wait comes BEFORE the next stage's
-      // requests are issued: exactly one stage is in flight during the MFMAs.)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int u = 0; u < 16; ++u) bc[u] = bn[u];
-      if (s + 1 < n_stage) {
-        dk_issue_stage(X, row_lim, ld, row0, (int64_t)(s + 1) * DK_COLS,
-                       my_lds + (unsigned)((slot ^ 1) * DK_STAGE_BYTES), lane);
-        load_b(s + 1, bn);
-      }
-      const float4* st4 =
-          reinterpret_cast<const float4*>(my_stage + slot * DK_STAGE_BYTES);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        double a[4][4];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-          const int row = 16 * rt + i;
-          const float4 x = st4[row * 16 + ((4 * c + k) ^ i)];
-          a[rt][0] = (double)x.x;
-          a[rt][1] = (double)x.y;
-          a[rt][2] = (double)x.z;
-          a[rt][3] = (double)x.w;
-        }
-        // consecutive MFMAs go to different accumulators
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt)
-            if (rt < nt)
-              D[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rt][m], bc[4 * c + m],
-                                                           D[rt], 0, 0, 0);
-      }
-      // every lane has read its part of the stage before this slot is refilled
-      // (next iteration, same wave: program order plus the LDS counter)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    // epilogue of the group: D[rt][reg] = t[row0 + 16 rt + k + 4 reg][chain i]
-    if (i < K) {
-      const double* rs = rowscale.p[i];
-      double* o = out.p[i];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        if (rt >= nt) continue;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int64_t row = row0 + 16 * rt + k + 4 * reg;
-          if (row < n) {
-            const double t = D[rt][reg];
-            double w = t;
-            if (rs) w *= rs[row];
-            o[row * out_stride] = w;
-            twt = fma(w, t, twt);
-          }
-        }
-      }
-    }
-  }
+  int64_t tile = t0;
+  for (; tile + DkDot::nt <= t1; tile += DkDot::nt)
+    dk_dot_group<K, DkDot::nt>(n, P, ld, X, v, rowscale, out, out_stride, tile, my_lds,
+                       my_stage, lane, twt);
+  for (; tile < t1; ++tile)
+    dk_dot_group<K, 1>(n, P, ld, X, v, rowscale, out, out_stride, tile, my_lds,
+                       my_stage, lane, twt);
   if (twt_part) {
     // lanes i, i + 16, i + 32, i + 48 hold chain i's parts: fixed order
-    const double a = (lane_value(twt, i) + lane_value(twt, i + 16)) +
-                     (lane_value(twt, i + 32) + lane_value(twt, i + 48));
+    // (t_l + t_l+16) + (t_l+32 + t_l+48) in lanes 0-15
+    double a = twt + __shfl_xor(twt, 16);
+    a = a + __shfl_xor(a, 32);
     if (lane < 16) s_twt[wave][lane] = a;
     __syncthreads();
     if (tid < K) {
       double tot = 0.;
-      for (int wv = 0; wv < DK_WAVES; ++wv) tot += s_twt[wv][tid];
+      for (int wv = 0; wv < DkDot::waves; ++wv) tot += s_twt[wv][tid];
       twt_part[tid * NPART + blockIdx.x] = tot;
     }
   }
@@ -207,7 +249,7 @@ __global__ __launch_bounds__(DK_WAVES * WAVE) void dense_dot_k_kernel(
 // columns of X and one of DK_TDOT_CHUNKS row ranges;
 // slab[(chunk * ld + col) * K + c] = sum over the chunk's rows.
 template <int K>
-__global__ __launch_bounds__(DK_WAVES * WAVE) void dense_tdot_k_kernel(
+__global__ __launch_bounds__(DkTdot::waves * WAVE) void dense_tdot_k_kernel(
     int64_t n, int64_t ld, int64_t rows_per_chunk, int n_colblk,
     const float* __restrict__ X, const double* __restrict__ w,
     double* __restrict__ slab, const int* __restrict__ skip_flag) {
@@ -217,10 +259,10 @@ __global__ __launch_bounds__(DK_WAVES * WAVE) void dense_tdot_k_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int i = lane & 15, k = lane >> 4;
   const unsigned my_lds = (unsigned)(uintptr_t)dk_smem +
-                          (unsigned)(wave * DK_STAGES * DK_STAGE_BYTES);
-  const unsigned char* my_stage = dk_smem + wave * DK_STAGES * DK_STAGE_BYTES;
+                          (unsigned)(wave * DK_STAGES * DkTdot::stage_bytes);
+  const unsigned char* my_stage = dk_smem + wave * DK_STAGES * DkTdot::stage_bytes;
   // consecutive waves take adjacent column blocks of the same row chunk
-  const int64_t gw = (int64_t)blockIdx.x * DK_WAVES + wave;
+  const int64_t gw = (int64_t)blockIdx.x * DkTdot::waves + wave;
   const int chunk = (int)(gw / n_colblk);
   const int colblk = (int)(gw - (int64_t)chunk * n_colblk);
   if (chunk >= DK_TDOT_CHUNKS) return;
@@ -229,20 +271,21 @@ __global__ __launch_bounds__(DK_WAVES * WAVE) void dense_tdot_k_kernel(
   int64_t r_end = r_begin + rows_per_chunk;
   if (r_end > n) r_end = n;
   const int n_stage =
-      r_end > r_begin ? (int)((r_end - r_begin + DK_ROWS - 1) / DK_ROWS) : 0;
+      r_end > r_begin ? (int)((r_end - r_begin + DkTdot::rows - 1) / DkTdot::rows) : 0;
   dk_d4 D[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) D[ct] = dk_d4{0., 0., 0., 0.};
   double bn[16], bc[16];
   auto load_b = [&](int s, double (&b)[16]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = r_begin + (int64_t)s * DK_ROWS + 4 * r + k;
-      b[r] = (i < K && row < r_end) ? w[row * K + i] : 0.;
+    for (int r = 0; r < DkTdot::rows / 4; ++r) {
+      const int64_t row = r_begin + (int64_t)s * DkTdot::rows + 4 * r + k;
+      const double val = w[(row < r_end ? row : r_end - 1) * K + (i < K ? i : K - 1)];
+      b[r] = (i < K && row < r_end) ? val : 0.;
     }
   };
   if (n_stage > 0) {
-    dk_issue_stage(X, n, ld, r_begin, col0, my_lds, lane);
+    dk_issue_stage<DkTdot::rows>(X, n, ld, r_begin, col0, my_lds, lane);
     load_b(0, bn);
   }
   for (int s = 0; s < n_stage; ++s) {
@@ -251,15 +294,15 @@ __global__ __launch_bounds__(DK_WAVES * WAVE) void dense_tdot_k_kernel(
 #pragma unroll
     for (int u = 0; u < 16; ++u) bc[u] = bn[u];
     if (s + 1 < n_stage) {
-      dk_issue_stage(X, n, ld, r_begin + (int64_t)(s + 1) * DK_ROWS, col0,
-                     my_lds + (unsigned)((slot ^ 1) * DK_STAGE_BYTES), lane);
+      dk_issue_stage<DkTdot::rows>(X, n, ld, r_begin + (int64_t)(s + 1) * DkTdot::rows, col0,
+                     my_lds + (unsigned)((slot ^ 1) * DkTdot::stage_bytes), lane);
       load_b(s + 1, bn);
     }
     const float* st1 =
-        reinterpret_cast<const float*>(my_stage + slot * DK_STAGE_BYTES);
+        reinterpret_cast<const float*>(my_stage + slot * DkTdot::stage_bytes);
     // A[i][k] of (row group r, column tile ct) = X[4 r + k][16 ct + i]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < DkTdot::rows / 4; ++r) {
       const int row = 4 * r + k;
       double a[4];
 #pragma unroll
@@ -268,6 +311,8 @@ __global__ __launch_bounds__(DK_WAVES * WAVE) void dense_tdot_k_kernel(
                             (i & 3)];
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
+        if (DK_ABLATE == 2) D[ct][0] += a[ct] * bc[r];
+        else
         D[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ct], bc[r], D[ct], 0, 0, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -300,10 +345,10 @@ static int dk_set_attr(int K) {
   BBX_DK_DISPATCH(K, {
     BBX_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&dense_dot_k_kernel<KK>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipFuncAttributeMaxDynamicSharedMemorySize, DkDot::lds_bytes));
     BBX_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&dense_tdot_k_kernel<KK>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipFuncAttributeMaxDynamicSharedMemorySize, DkTdot::lds_bytes));
   });
   return BBX_OK;
 }
@@ -316,8 +361,8 @@ int launch_dot_dense_k(bbx_design* h, int K, const double* d_v,
   h->n_dot += 1;
   BBX_TRY(timer_begin(h, 0));
   BBX_DK_DISPATCH(K, hipLaunchKernelGGL(
-      dense_dot_k_kernel<KK>, dim3(DK_DOT_WGS), dim3(DK_WAVES * WAVE),
-      DK_LDS_BYTES, h->stream, h->n, h->P, h->dense_ld, h->dense.as<float>(),
+      dense_dot_k_kernel<KK>, dim3(DK_DOT_WGS), dim3(DkDot::waves * WAVE),
+      DkDot::lds_bytes, h->stream, h->n, h->P, h->dense_ld, h->dense.as<float>(),
       d_v, ba.rowscale, ba.out, ba.out_stride, d_twt_part, h->skip_flag));
   BBX_HIP(hipGetLastError());
   return timer_end(h, 0);
@@ -333,14 +378,14 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
   if (h->dense_batch_slab.bytes < need) BBX_TRY(h->dense_batch_slab.alloc(need));
   const int n_colblk = (int)((h->dense_ld + DK_COLS - 1) / DK_COLS);
   const int64_t rows_per_chunk =
-      ((h->n + DK_TDOT_CHUNKS - 1) / DK_TDOT_CHUNKS + DK_ROWS - 1) / DK_ROWS *
-      DK_ROWS;
+      ((h->n + DK_TDOT_CHUNKS - 1) / DK_TDOT_CHUNKS + DkTdot::rows - 1) / DkTdot::rows *
+      DkTdot::rows;
   const int n_wave = n_colblk * DK_TDOT_CHUNKS;
-  const unsigned grid = (unsigned)((n_wave + DK_WAVES - 1) / DK_WAVES);
+  const unsigned grid = (unsigned)((n_wave + DkTdot::waves - 1) / DkTdot::waves);
   h->n_tdot += 1;
   BBX_TRY(timer_begin(h, 1));
   BBX_DK_DISPATCH(K, hipLaunchKernelGGL(
-      dense_tdot_k_kernel<KK>, dim3(grid), dim3(DK_WAVES * WAVE), DK_LDS_BYTES,
+      dense_tdot_k_kernel<KK>, dim3(grid), dim3(DkTdot::waves * WAVE), DkTdot::lds_bytes,
       h->stream, h->n, h->dense_ld, rows_per_chunk, n_colblk,
       h->dense.as<float>(), d_w, h->dense_batch_slab.as<double>(),
       h->skip_flag));

@@ -231,6 +231,43 @@ def test_a_dense_chain_does_not_depend_on_its_batch(K):
         max(2, .05 * kept['n_cg_iter'][0])
 
 
+def test_gibbs_batch_and_run_chains_go_through_batches():
+    """BayesBridge.gibbs_batch returns per-chain (samples, mcmc_info) in
+    gibbs()'s format; chains.run_chains (one process, 5 chains) pairs its
+    chains into batches and runs the odd one alone -- chain k has seed + k
+    either way, and a batched chain equals the same chain from gibbs_batch."""
+    from bayesbridge_amd import (BayesBridge, HipSparseDesignMatrix,
+                                 RegressionCoefPrior, RegressionModel, chains,
+                                 simulate)
+    X = simulate.simulate_binary_csr_fast(4000, 300, .05, seed=3)
+    beta = np.zeros(300)
+    beta[:5] = 1.
+    y = simulate.simulate_outcome(X, beta, 'logit', seed=4)
+    hip = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True)
+    bridge = BayesBridge(RegressionModel(y, hip, 'logit'),
+                         RegressionCoefPrior(bridge_exponent=.5,
+                                             regularizing_slab_size=2.))
+    assert bridge.batch_width(5) == 2 and bridge.batch_width(1) == 0
+    assert bridge.batch_width(4, params_to_save='all') == 0
+    init = {'global_scale': .05, 'coef': np.zeros(301)}
+    res = bridge.gibbs_batch([11, 12], 6, n_burnin=2, init=init)
+    assert len(res) == 2
+    for samples, info in res:
+        assert samples['coef'].shape == (301, 4)          # MCMC index last
+        assert samples['logp'].shape == (4,)
+        assert info['_reg_coef_sampling_info']['n_cg_iter'].shape == (4,)
+        assert info['batch']['width'] == 2
+    merged, infos = chains.run_chains(bridge, 5, 6, n_burnin=2, seed=11,
+                                      init=init)
+    assert merged['coef'].shape == (5, 301, 4)
+    assert [i['chain'] for i in infos] == [0, 1, 2, 3, 4]
+    assert ['batch' in i for i in infos] == [True] * 4 + [False]
+    for k in range(2):
+        assert np.array_equal(merged['coef'][k], res[k][0]['coef'])
+    alone, _ = bridge.gibbs(6, n_burnin=2, seed=15, init=init)
+    assert np.array_equal(merged['coef'][4], alone['coef'])
+
+
 def test_batch_argument_checks():
     from bayesbridge_amd import BbxError, HipChainBatch
     X, y, hip = _problem(2000, 100, 'linear')
