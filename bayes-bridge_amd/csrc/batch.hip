@@ -42,10 +42,11 @@ struct BatchState {
 
 struct bbx_batch {
   bbx_design* h = nullptr;
-  int K = 0;
+  int K = 0;   // chains
+  int KS = 0;  // interleave stride of the batch's vectors: K (sparse), 16 (dense)
   bbx_chain* chain[bbx::BATCH_MAX] = {};
-  bbx::DevMem s, d, x, r, p, sp;  // (P + 2) * K doubles, interleaved [j][c]
-  bbx::DevMem t, w;               // n * K doubles
+  bbx::DevMem s, d, x, r, p, sp;  // (P + 2) * KS doubles, interleaved [j][c]
+  bbx::DevMem t, w;               // n * KS doubles (dense: zero-padded rows too)
   bbx::DevMem eta1[bbx::BATCH_MAX], eta2[bbx::BATCH_MAX];  // n, P per chain
   bbx::DevMem part;               // [PS_COUNT][K][NPART]
   bbx::DevMem state;              // BatchState
@@ -62,9 +63,11 @@ static inline double* bpart(const bbx_batch* b, int slot) {
 
 // ------------------------------------------------------------------ kernels
 //
-// The vector kernels of a batch handle KC = min(K, 4) chains per thread (their
-// elements of the interleaved vectors are adjacent) and K / KC groups of
-// chains in blockIdx.y; `c0` is the group's first chain.
+// The vector kernels of a batch handle KC = min(chains, 4) chains per thread
+// (their elements of the interleaved vectors are adjacent) and chains / KC
+// groups of chains in blockIdx.y; `c0` is the group's first chain.  Their
+// parameter `K` is the interleave STRIDE of the vectors (the number of chains
+// for sparse designs, 16 for dense ones).
 
 // the sum of one NPART-block, same adds in the same order in every thread
 // (vecops.hip part_issue / part_finish, without the LDS round)
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void b_sqrt_scale_kernel(
 // <offset, (s p)[1:]> and <p, d p>.
 template <int KC>
 __global__ __launch_bounds__(VEC_BLOCK) void b_direction_kernel(
-    int64_t P, int K, int intercept, int k, BatchState* __restrict__ bs,
+    int64_t P, int K, int n_chain, int intercept, int k,
+    BatchState* __restrict__ bs,
     const double* __restrict__ rr_part, const double* __restrict__ r,
     double* __restrict__ pvec, const double* __restrict__ s,
     const double* __restrict__ offset, double* __restrict__ sp,
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void b_direction_kernel(
         bs->st[c0 + c].done = 1;
         if (!finite) bs->st[c0 + c].bad = 1;
         // the last chain to stop raises the flag the operator kernels read
-        if (atomicAdd(&bs->n_done, 1) + 1 == K) bs->all_done = 1;
+        if (atomicAdd(&bs->n_done, 1) + 1 == n_chain) bs->all_done = 1;
       } else if (run[c]) {
         bs->st[c0 + c].rho[k & 1] = rho[c];
       }
@@ -447,7 +451,7 @@ static int batch_linear_predictor(bbx_batch* b) {
   const BatchShape g = batch_shape(h);
   const ChainPtrs coef = gather_ptrs(b, &bbx_chain::coef);
   double* sp = b->sp.as<double>();
-  BBX_KC_LAUNCH(K, b_prep_kernel, h->stream, h->P, K, g.icpt, nullptr, coef,
+  BBX_KC_LAUNCH(K, b_prep_kernel, h->stream, h->P, b->KS, g.icpt, nullptr, coef,
                 nullptr, g.offset, sp, bpart(b, PS_C));
   BBX_HIP(hipGetLastError());
   TiledBatchArgs ba;
@@ -462,7 +466,7 @@ static int batch_linear_predictor(bbx_batch* b) {
 static int cg_sample_batch(bbx_batch* b, int maxiter, double atol,
                            bool cold, int* n_iter_out, int* info_out) {
   bbx_design* h = b->h;
-  const int K = b->K;
+  const int K = b->K, KS = b->KS;
   const int64_t P = h->P, n = h->n;
   const BatchShape g = batch_shape(h);
   hipStream_t st_ = h->stream;
@@ -498,28 +502,28 @@ static int cg_sample_batch(bbx_batch* b, int maxiter, double atol,
     dot_args.rowscale.p[c] = omega.p[c];
     dot_args.out.p[c] = t + c;
   }
-  dot_args.out_stride = K;
+  dot_args.out_stride = KS;
   dot_args.part_stride = NPART;
 
-  BBX_KC_LAUNCH(K, b_setup_kernel, st_, P, K, n_unshrunk, phi, sd, x0, s, d, x,
+  BBX_KC_LAUNCH(K, b_setup_kernel, st_, P, KS, n_unshrunk, phi, sd, x0, s, d, x,
                 bs, atol);
   // r = b - A x0 through ONE transposed product (cg_sampler.hip, TD_RESID)
   const double* t0 = nullptr;
   if (!cold) {
-    BBX_KC_LAUNCH(K, b_prep_kernel, st_, P, K, g.icpt, x, ChainPtrs{}, s,
+    BBX_KC_LAUNCH(K, b_prep_kernel, st_, P, KS, g.icpt, x, ChainPtrs{}, s,
                   g.offset, sp, bpart(b, PS_C));
     BBX_HIP(hipGetLastError());
     BBX_TRY(batch_dot(b, sp, dot_args, false));
     t0 = t;
   }
-  BBX_KC_LAUNCH(K, b_sqrt_scale_kernel, st_, n, K, omega, e1, t0, w,
+  BBX_KC_LAUNCH(K, b_sqrt_scale_kernel, st_, n, KS, omega, e1, t0, w,
                 bpart(b, PS_SUMW));
   BBX_HIP(hipGetLastError());
   const double* slab = nullptr;
   int G = 0;
   int64_t slab_rows = 0;
   BBX_TRY(batch_tdot(b, w, &slab, &G, &slab_rows));
-  BBX_KC_LAUNCH_MODE(K, b_finalize_kernel, TD_RESID, st_, g.p_main, K, g.icpt,
+  BBX_KC_LAUNCH_MODE(K, b_finalize_kernel, TD_RESID, st_, g.p_main, KS, g.icpt,
                      slab, G, slab_rows, g.offset, batch_sumw(b), s, d, pvec, x,
                      r, z, phi, e2, cold ? 0 : 1, bpart(b, PS_RR), bs, 0,
                      nullptr, nullptr);
@@ -534,7 +538,7 @@ static int cg_sample_batch(bbx_batch* b, int maxiter, double atol,
   } skip_scope{h};
   h->skip_flag = &bs->all_done;
   auto direction = [&](int kk) -> int {
-    BBX_KC_LAUNCH(K, b_direction_kernel, st_, P, K, g.icpt, kk, bs,
+    BBX_KC_LAUNCH(K, b_direction_kernel, st_, P, KS, K, g.icpt, kk, bs,
                   bpart(b, PS_RR), r, pvec, s, g.offset, sp, bpart(b, PS_C), d,
                   bpart(b, PS_PDP));
     BBX_HIP(hipGetLastError());
@@ -545,7 +549,7 @@ static int cg_sample_batch(bbx_batch* b, int maxiter, double atol,
     BBX_TRY(timer_begin(h, 2));
     BBX_TRY(batch_dot(b, sp, dot_args, true));
     BBX_TRY(batch_tdot(b, t, &slab, &G, &slab_rows));
-    BBX_KC_LAUNCH_MODE(K, b_finalize_kernel, TD_OPER_UPD, st_, g.p_main, K,
+    BBX_KC_LAUNCH_MODE(K, b_finalize_kernel, TD_OPER_UPD, st_, g.p_main, KS,
                        g.icpt, slab, G, slab_rows, g.offset, batch_sumw(b), s, d,
                        pvec, x, r, ChainPtrs{}, ChainPtrs{}, ChainPtrs{}, 0,
                        bpart(b, PS_RR), bs, kk, bpart(b, PS_PDP),
@@ -554,7 +558,7 @@ static int cg_sample_batch(bbx_batch* b, int maxiter, double atol,
     return timer_end(h, 2);
   };
   auto finish = [&]() -> int {
-    BBX_KC_LAUNCH(K, b_finish_kernel, st_, P, K, s, x, coef);
+    BBX_KC_LAUNCH(K, b_finish_kernel, st_, P, KS, s, x, coef);
     BBX_HIP(hipGetLastError());
     BBX_HIP(hipMemcpyAsync(host_bs, bs, sizeof(BatchState),
                            hipMemcpyDeviceToHost, st_));
@@ -666,13 +670,24 @@ int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,
   b->h = h;
   b->K = n_chain;
   for (int c = 0; c < n_chain; ++c) b->chain[c] = chains[c];
-  const size_t K = (size_t)n_chain;
+  b->KS = h->sparse ? n_chain : DENSE_BATCH_STRIDE;
+  const size_t K = (size_t)n_chain, KS = (size_t)b->KS;
+  // dense: the product kernels read whole 64-row / 64-column stages of their
+  // 16-column operands; rows past P / n and columns past the chains stay zero
+  const size_t rows_P = h->sparse ? (size_t)(h->P + 2)
+                                  : (size_t)(h->dense_ld + DENSE_BATCH_ROW_PAD + 2);
+  const size_t rows_n = h->sparse ? (size_t)h->n
+                                  : (size_t)(h->n + DENSE_BATCH_ROW_PAD);
   auto body = [&]() -> int {
     if (h->sparse) BBX_TRY(ensure_tiled_k(h, n_chain));
-    for (DevMem* m : {&b->s, &b->d, &b->x, &b->r, &b->p, &b->sp})
-      BBX_TRY(m->alloc(sizeof(double) * (size_t)(h->P + 2) * K));
-    BBX_TRY(b->t.alloc(sizeof(double) * (size_t)h->n * K));
-    BBX_TRY(b->w.alloc(sizeof(double) * (size_t)h->n * K));
+    for (DevMem* m : {&b->s, &b->d, &b->x, &b->r, &b->p, &b->sp}) {
+      BBX_TRY(m->alloc(sizeof(double) * rows_P * KS));
+      BBX_HIP(hipMemset(m->ptr, 0, sizeof(double) * rows_P * KS));
+    }
+    for (DevMem* m : {&b->t, &b->w}) {
+      BBX_TRY(m->alloc(sizeof(double) * rows_n * KS));
+      BBX_HIP(hipMemset(m->ptr, 0, sizeof(double) * rows_n * KS));
+    }
     for (int c = 0; c < n_chain; ++c) {
       BBX_TRY(b->eta1[c].alloc(sizeof(double) * (size_t)h->n));
       BBX_TRY(b->eta2[c].alloc(sizeof(double) * (size_t)h->P));
@@ -781,7 +796,7 @@ int bbx_batch_dot(bbx_batch* b, const double* v, double* out) {
     ba.out_stride = 1;
     ba.part_stride = NPART;
     double* sp = b->sp.as<double>();
-    BBX_KC_LAUNCH(K, b_prep_kernel, h->stream, P, K, g.icpt, nullptr, src,
+    BBX_KC_LAUNCH(K, b_prep_kernel, h->stream, P, b->KS, g.icpt, nullptr, src,
                   nullptr, g.offset, sp, bpart(b, PS_C));
     BBX_HIP(hipGetLastError());
     BBX_TRY(batch_dot(b, sp, ba, false));
@@ -801,9 +816,10 @@ int bbx_batch_tdot(bbx_batch* b, const double* w, double* out) {
     const BatchShape g = batch_shape(h);
     BBX_HIP(hipSetDevice(h->device));
     // interleave on the host: the kernels take [n][K]
-    std::vector<double> il((size_t)(K * n)), res((size_t)(K * P));
+    const int KS = b->KS;
+    std::vector<double> il((size_t)(KS * n), 0.), res((size_t)(KS * P));
     for (int c = 0; c < K; ++c)
-      for (int64_t i = 0; i < n; ++i) il[(size_t)(i * K + c)] = w[(size_t)c * n + i];
+      for (int64_t i = 0; i < n; ++i) il[(size_t)(i * KS + c)] = w[(size_t)c * n + i];
     double* dw = b->w.as<double>();
     BBX_HIP(hipMemcpyAsync(dw, il.data(), sizeof(double) * il.size(),
                            hipMemcpyHostToDevice, h->stream));
@@ -813,7 +829,7 @@ int bbx_batch_tdot(bbx_batch* b, const double* w, double* out) {
     BBX_HIP(hipMemsetAsync(zeros.ptr, 0, sizeof(double) * (size_t)n, h->stream));
     ChainPtrs zp{};
     for (int c = 0; c < K; ++c) zp.p[c] = zeros.as<double>();
-    BBX_KC_LAUNCH(K, b_sqrt_scale_kernel, h->stream, n, K, zp, zp, dw, dw,
+    BBX_KC_LAUNCH(K, b_sqrt_scale_kernel, h->stream, n, KS, zp, zp, dw, dw,
                   bpart(b, PS_SUMW));
     BBX_HIP(hipGetLastError());
     const double* slab = nullptr;
@@ -821,7 +837,7 @@ int bbx_batch_tdot(bbx_batch* b, const double* w, double* out) {
     int64_t slab_rows = 0;
     BBX_TRY(batch_tdot(b, dw, &slab, &G, &slab_rows));
     double* r = b->r.as<double>();
-    BBX_KC_LAUNCH_MODE(K, b_finalize_kernel, TD_PLAIN, h->stream, g.p_main, K,
+    BBX_KC_LAUNCH_MODE(K, b_finalize_kernel, TD_PLAIN, h->stream, g.p_main, KS,
                        g.icpt, slab, G, slab_rows, g.offset, batch_sumw(b),
                        nullptr, nullptr, nullptr, nullptr, r, ChainPtrs{},
                        ChainPtrs{}, ChainPtrs{}, 0, nullptr,
@@ -831,7 +847,7 @@ int bbx_batch_tdot(bbx_batch* b, const double* w, double* out) {
                            hipMemcpyDeviceToHost, h->stream));
     BBX_HIP(hipStreamSynchronize(h->stream));
     for (int c = 0; c < K; ++c)
-      for (int64_t j = 0; j < P; ++j) out[(size_t)c * P + j] = res[(size_t)(j * K + c)];
+      for (int64_t j = 0; j < P; ++j) out[(size_t)c * P + j] = res[(size_t)(j * KS + c)];
     return BBX_OK;
   });
 }

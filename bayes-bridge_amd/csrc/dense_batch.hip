@@ -53,6 +53,7 @@ typedef double dk_d4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int DK_COLS = 64;                 // columns of a stage (256 B of f32)
 constexpr int DK_STAGES = 2;
+constexpr int DK_KS = DENSE_BATCH_STRIDE;   // interleave stride: the 16 columns of B
 template <int ROWS>
 struct DkGeom {
   static constexpr int rows = ROWS;             // rows of a stage
@@ -105,8 +106,8 @@ __device__ __forceinline__ void dk_issue_stage(const float* __restrict__ X,
 // is used NT times, consecutive MFMAs go to NT accumulators; NT = 1, the
 // remainder of a wave's range: one accumulator per k-slot, added at the end).
 // Straight-line per stage: no branch sits between two MFMAs.
-template <int K, int NT>
-__device__ __forceinline__ void dk_dot_group(
+template <int NT>
+__device__ __forceinline__ void dk_dot_group(int K, 
     int64_t n, int64_t P, int64_t ld, const float* __restrict__ X,
     const double* __restrict__ v, const ChainPtrs& rowscale,
     const ChainOut& out, int out_stride, int64_t tile, unsigned my_lds,
@@ -121,15 +122,15 @@ __device__ __forceinline__ void dk_dot_group(
 #pragma unroll
   for (int a = 0; a < NACC; ++a) D[a] = dk_d4{0., 0., 0., 0.};
   double bn[16], bc[16];
-  const int ic = i < K ? i : K - 1;  // clamped: the load is unconditional
+  // B operand: V is [ld + 64][16], zero padded in both directions (rows past
+  // P, columns past the batch's chains), so the loads carry no condition
   auto load_b = [&](int s, double (&b)[16]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int64_t col = (int64_t)s * DK_COLS + 16 * c + 4 * k + m;
-        const double val = v[(col < P ? col : P - 1) * K + ic];
-        b[4 * c + m] = (i < K && col < P) ? val : 0.;
+        b[4 * c + m] = v[col * DK_KS + i];
       }
   };
   dk_issue_stage<DkDot::rows>(X, row_lim, ld, row0, 0, my_lds, lane);
@@ -201,9 +202,8 @@ __device__ __forceinline__ void dk_dot_group(
 // T = X V for K interleaved right-hand sides: out.p[c][row * out_stride] =
 // rowscale_c[row] * <X[row, :], v_c>, and per workgroup and chain the partials
 // of sum_i rowscale_c,i t_c,i^2 (twt_part[c * NPART + blockIdx.x]).
-template <int K>
 __global__ __launch_bounds__(DkDot::waves * WAVE) void dense_dot_k_kernel(
-    int64_t n, int64_t P, int64_t ld, const float* __restrict__ X,
+    int K, int64_t n, int64_t P, int64_t ld, const float* __restrict__ X,
     const double* __restrict__ v, ChainPtrs rowscale, ChainOut out,
     int out_stride, double* __restrict__ twt_part,
     const int* __restrict__ skip_flag) {
@@ -225,10 +225,10 @@ __global__ __launch_bounds__(DkDot::waves * WAVE) void dense_dot_k_kernel(
   double twt = 0.;  // this lane's part of <t_c, Omega_c t_c>, c = lane & 15
   int64_t tile = t0;
   for (; tile + DkDot::nt <= t1; tile += DkDot::nt)
-    dk_dot_group<K, DkDot::nt>(n, P, ld, X, v, rowscale, out, out_stride, tile, my_lds,
+    dk_dot_group<DkDot::nt>(K, n, P, ld, X, v, rowscale, out, out_stride, tile, my_lds,
                        my_stage, lane, twt);
   for (; tile < t1; ++tile)
-    dk_dot_group<K, 1>(n, P, ld, X, v, rowscale, out, out_stride, tile, my_lds,
+    dk_dot_group<1>(K, n, P, ld, X, v, rowscale, out, out_stride, tile, my_lds,
                        my_stage, lane, twt);
   if (twt_part) {
     // lanes i, i + 16, i + 32, i + 48 hold chain i's parts: fixed order
@@ -248,9 +248,8 @@ __global__ __launch_bounds__(DkDot::waves * WAVE) void dense_dot_k_kernel(
 // Slabs of G = X^T W for K interleaved right-hand sides: a wave owns 64
 // columns of X and one of DK_TDOT_CHUNKS row ranges;
 // slab[(chunk * ld + col) * K + c] = sum over the chunk's rows.
-template <int K>
 __global__ __launch_bounds__(DkTdot::waves * WAVE) void dense_tdot_k_kernel(
-    int64_t n, int64_t ld, int64_t rows_per_chunk, int n_colblk,
+    int K, int64_t n, int64_t ld, int64_t rows_per_chunk, int n_colblk,
     const float* __restrict__ X, const double* __restrict__ w,
     double* __restrict__ slab, const int* __restrict__ skip_flag) {
   if (skip_flag && *skip_flag) return;
@@ -279,9 +278,10 @@ __global__ __launch_bounds__(DkTdot::waves * WAVE) void dense_tdot_k_kernel(
   auto load_b = [&](int s, double (&b)[16]) {
 #pragma unroll
     for (int r = 0; r < DkTdot::rows / 4; ++r) {
+      // W is [n + 64][16], zero padded (rows past n, columns past the batch's
+      // chains); a chunk is a whole number of stages, so no stage straddles two
       const int64_t row = r_begin + (int64_t)s * DkTdot::rows + 4 * r + k;
-      const double val = w[(row < r_end ? row : r_end - 1) * K + (i < K ? i : K - 1)];
-      b[r] = (i < K && row < r_end) ? val : 0.;
+      b[r] = w[row * DK_KS + i];
     }
   };
   if (n_stage > 0) {
@@ -324,32 +324,22 @@ __global__ __launch_bounds__(DkTdot::waves * WAVE) void dense_tdot_k_kernel(
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int64_t col = col0 + 16 * ct + k + 4 * reg;
-        if (col < ld) slab[((int64_t)chunk * ld + col) * K + i] = D[ct][reg];
+        if (col < ld) slab[((int64_t)chunk * ld + col) * DK_KS + i] = D[ct][reg];
       }
   }
 }
-
-#define BBX_DK_DISPATCH(K, CALL)                                               \
-  do {                                                                         \
-    if ((K) == 2) { constexpr int KK = 2; CALL; }                              \
-    else if ((K) == 4) { constexpr int KK = 4; CALL; }                         \
-    else if ((K) == 8) { constexpr int KK = 8; CALL; }                         \
-    else { constexpr int KK = 16; CALL; }                                      \
-  } while (0)
 
 bool dense_batch_applies(const bbx_design* h) {
   return !h->sparse && h->dense_dtype == BBX_F32 && h->dense_ld % 8 == 0;
 }
 
-static int dk_set_attr(int K) {
-  BBX_DK_DISPATCH(K, {
-    BBX_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&dense_dot_k_kernel<KK>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, DkDot::lds_bytes));
-    BBX_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&dense_tdot_k_kernel<KK>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, DkTdot::lds_bytes));
-  });
+static int dk_set_attr() {
+  BBX_HIP(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&dense_dot_k_kernel),
+      hipFuncAttributeMaxDynamicSharedMemorySize, DkDot::lds_bytes));
+  BBX_HIP(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&dense_tdot_k_kernel),
+      hipFuncAttributeMaxDynamicSharedMemorySize, DkTdot::lds_bytes));
   return BBX_OK;
 }
 
@@ -357,13 +347,14 @@ int launch_dot_dense_k(bbx_design* h, int K, const double* d_v,
                        const TiledBatchArgs& ba, double* d_twt_part) {
   if (!dense_batch_applies(h))
     return fail(BBX_ERR_STATE, "batched dense products need f32 storage");
-  BBX_TRY(dk_set_attr(K));
+  BBX_TRY(dk_set_attr());
   h->n_dot += 1;
   BBX_TRY(timer_begin(h, 0));
-  BBX_DK_DISPATCH(K, hipLaunchKernelGGL(
-      dense_dot_k_kernel<KK>, dim3(DK_DOT_WGS), dim3(DkDot::waves * WAVE),
-      DkDot::lds_bytes, h->stream, h->n, h->P, h->dense_ld, h->dense.as<float>(),
-      d_v, ba.rowscale, ba.out, ba.out_stride, d_twt_part, h->skip_flag));
+  hipLaunchKernelGGL(dense_dot_k_kernel, dim3(DK_DOT_WGS),
+                     dim3(DkDot::waves * WAVE), DkDot::lds_bytes, h->stream, K,
+                     h->n, h->P, h->dense_ld, h->dense.as<float>(), d_v,
+                     ba.rowscale, ba.out, ba.out_stride, d_twt_part,
+                     h->skip_flag);
   BBX_HIP(hipGetLastError());
   return timer_end(h, 0);
 }
@@ -372,23 +363,27 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
                         const double** slab, int* G) {
   if (!dense_batch_applies(h))
     return fail(BBX_ERR_STATE, "batched dense products need f32 storage");
-  BBX_TRY(dk_set_attr(K));
+  BBX_TRY(dk_set_attr());
   const size_t need = sizeof(double) * (size_t)DK_TDOT_CHUNKS *
-                      (size_t)h->dense_ld * (size_t)K;
-  if (h->dense_batch_slab.bytes < need) BBX_TRY(h->dense_batch_slab.alloc(need));
+                      (size_t)h->dense_ld * (size_t)DK_KS;
+  if (h->dense_batch_slab.bytes < need) {
+    BBX_TRY(h->dense_batch_slab.alloc(need));
+    // columns past the batch's chains are never written: keep them zero
+    BBX_HIP(hipMemsetAsync(h->dense_batch_slab.ptr, 0, need, h->stream));
+  }
   const int n_colblk = (int)((h->dense_ld + DK_COLS - 1) / DK_COLS);
   const int64_t rows_per_chunk =
-      ((h->n + DK_TDOT_CHUNKS - 1) / DK_TDOT_CHUNKS + DkTdot::rows - 1) / DkTdot::rows *
-      DkTdot::rows;
+      ((h->n + DK_TDOT_CHUNKS - 1) / DK_TDOT_CHUNKS + DkTdot::rows - 1) /
+      DkTdot::rows * DkTdot::rows;
   const int n_wave = n_colblk * DK_TDOT_CHUNKS;
   const unsigned grid = (unsigned)((n_wave + DkTdot::waves - 1) / DkTdot::waves);
   h->n_tdot += 1;
   BBX_TRY(timer_begin(h, 1));
-  BBX_DK_DISPATCH(K, hipLaunchKernelGGL(
-      dense_tdot_k_kernel<KK>, dim3(grid), dim3(DkTdot::waves * WAVE), DkTdot::lds_bytes,
-      h->stream, h->n, h->dense_ld, rows_per_chunk, n_colblk,
-      h->dense.as<float>(), d_w, h->dense_batch_slab.as<double>(),
-      h->skip_flag));
+  hipLaunchKernelGGL(dense_tdot_k_kernel, dim3(grid),
+                     dim3(DkTdot::waves * WAVE), DkTdot::lds_bytes, h->stream,
+                     K, h->n, h->dense_ld, rows_per_chunk, n_colblk,
+                     h->dense.as<float>(), d_w,
+                     h->dense_batch_slab.as<double>(), h->skip_flag);
   BBX_HIP(hipGetLastError());
   BBX_TRY(timer_end(h, 1));
   *slab = h->dense_batch_slab.as<double>();
@@ -398,9 +393,11 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
 
 int dense_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
                       int64_t* tdot_bytes) {
+  // the matrix once + the 16-column operands (padding columns are read too)
+  // + what the chains' columns write
   const int64_t mat = h->n * h->dense_ld * 4;
-  *dot_bytes = mat + 8 * (int64_t)K * (h->P + h->n);
-  *tdot_bytes = mat + 8 * (int64_t)K * h->n +
+  *dot_bytes = mat + 8 * (int64_t)DK_KS * h->dense_ld + 8 * (int64_t)K * h->n;
+  *tdot_bytes = mat + 8 * (int64_t)DK_KS * h->n +
                 8 * (int64_t)K * DK_TDOT_CHUNKS * h->dense_ld;
   return BBX_OK;
 }
