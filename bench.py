@@ -116,13 +116,14 @@ def cpu_baselines(prob, state, n_iters, seed):
     post-warm-up state, for `n_iters` Gibbs iterations each:
       port      SciPy CSR products + scipy.sparse.linalg.cg -- the primitives
                 the reference runs (single-threaded, like SciPy's SpMV)
-      port-omp  the same chain with OpenMP products and CG on all host cores
-                (oracle/csrc/oracle_cg_omp.cpp); the scalar samplers stay on
-                one thread (their PCG64 streams are sequential)."""
+      port-omp  the same chain with OpenMP products and CG on every core of
+                the affinity mask (oracle/csrc/oracle_cg_omp.cpp: value-free
+                int32 CSR, each thread's rows first-touched by that thread) and
+                the scalar samplers on a thread pool with per-block PCG64
+                streams; reports the products' effective GB/s beside it."""
     import numpy as np
     import scipy.sparse as sparse
     from oracle.gibbs import OracleGibbs
-    from oracle.omp_baseline import load as load_omp
     from oracle.rng import OracleRandom
     from oracle.summarizer import CoefSummarizer
     n, p = prob["n"], prob["p"]
@@ -131,14 +132,40 @@ def cpu_baselines(prob, state, n_iters, seed):
          prob["indptr"].cpu().numpy()), shape=(n, p))
     n_success = prob["n_success"].cpu().numpy()
     coef0, obs0, ls0, g0, mean, square, n_avg = state
+    from oracle.omp_baseline import usable_cores
+    from oracle.rng import ParallelOracleRandom
     host_cores = os.cpu_count()
-    omp_cores = min(load_omp().oracle_omp_max_threads(), host_cores or 1)
+    omp_cores = usable_cores()      # the affinity mask, every core of it
 
     def run(kind, cores, **kw):
         chain = OracleGibbs((n_success, np.ones(n)), X, 'logit',
                             bridge_exponent=ALPHA,
                             regularizing_slab_size=SLAB, **kw)
-        chain.rng = OracleRandom(seed)
+        extra = {}
+        if kind == "port":
+            chain.rng = OracleRandom(seed)
+        else:
+            # scalar samplers on a thread pool with per-block PCG64 streams
+            chain.rng = ParallelOracleRandom(seed, min(cores, 64))
+            # effective rate of the products alone (value-free int32 CSR,
+            # SURVEY 8(d)'s bytes of the format actually read)
+            d = chain.design
+            v, w = np.ones(d.shape[1]), np.ones(d.shape[0])
+            d.dot(v), d.Tdot(w)
+            reps = 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                d.dot(v)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                d.Tdot(w)
+            t2 = time.perf_counter()
+            db, tb = d.product_bytes
+            extra = dict(
+                dot_gbs=round(db * reps / (t1 - t0) / 1e9, 1),
+                tdot_gbs=round(tb * reps / (t2 - t1) / 1e9, 1),
+                product_format="value-free int32 CSR of X and of X^T, each "
+                               "thread's rows first-touched by that thread")
         summ = CoefSummarizer(chain.P, chain.nu, chain.slab)
         summ.set_state({'mean': mean, 'square': square, 'n_averaged': n_avg})
         coef, obs_prec, lscale, gscale = coef0, obs0, ls0, g0
@@ -152,21 +179,43 @@ def cpu_baselines(prob, state, n_iters, seed):
             chain.logp(coef, gscale, obs_prec)
             n_cg.append(info['n_iter'])
         dt = time.perf_counter() - t0
-        what = ("scipy.sparse CSR @, .T @, scipy.sparse.linalg.cg"
+        what = ("scipy.sparse CSR @, .T @, scipy.sparse.linalg.cg; C "
+                "Polya-Gamma/tilted-stable samplers on 1 thread"
                 if kind == "port" else
-                "OpenMP CSR / CSR-of-X^T products and CG loop in C++")
-        return dict(value=round(n_iters / dt, 5), unit="Gibbs iters/sec",
-                    cores=cores, kind=kind,
-                    sample="%d Gibbs iterations of the CPU oracle chain (%s; "
-                           "C Polya-Gamma/tilted-stable samplers on 1 "
-                           "thread) on the same %dx%d nnz=%d design from the "
-                           "GPU chain's post-warm-up state; mean n_cg=%.1f; "
-                           "%.1f s" % (n_iters, what, n, p, prob["nnz"],
-                                       float(np.mean(n_cg)), dt),
-                    host_cores=host_cores)
+                "OpenMP value-free CSR / CSR-of-X^T products (NUMA first "
+                "touch) and CG loop in C++ on %d threads; C samplers on a "
+                "%d-thread pool" % (cores, min(cores, 64)))
+        out = dict(value=round(n_iters / dt, 5), unit="Gibbs iters/sec",
+                   cores=cores, kind=kind,
+                   sample="%d Gibbs iterations of the CPU oracle chain (%s) "
+                          "on the same %dx%d nnz=%d design from the GPU "
+                          "chain's post-warm-up state; mean n_cg=%.1f; "
+                          "%.1f s" % (n_iters, what, n, p, prob["nnz"],
+                                      float(np.mean(n_cg)), dt),
+                   host_cores=host_cores)
+        out.update(extra)
+        return out
     port = run("port", 1, use_scipy_cg=True)
     omp = run("port-omp", omp_cores, omp_threads=omp_cores)
     return port, omp
+
+
+def iteration_bytes(mean_ncg, op_bytes, dot_bytes, tdot_bytes, n, P,
+                    dense_single_pass=False):
+    """Algorithmic bytes of ONE whole Gibbs iteration (`roofline.iteration`):
+    n_cg operator applications; for the warm start one more application (dense
+    single-pass kernel) or one product with X~ plus ONE with X~^T for the
+    initial residual (cg_sampler.hip TD_RESID); the linear predictor of the
+    Omega update; 10 P-vector passes per CG iteration (direction 6, update in
+    the Tdot epilogue 4), ~64 bytes per row and ~30 P-vector passes for the
+    eta draws and the chain kernels.  Only bytes that are moved are credited.
+    Pinned against the PMC counters of a profiled chain
+    (profiles/r03_iteration_traffic.json, tests/test_bench_byte_model.py)."""
+    if dense_single_pass:
+        total = (mean_ncg + 1) * op_bytes + dot_bytes
+    else:
+        total = mean_ncg * op_bytes + 2 * dot_bytes + tdot_bytes
+    return total + mean_ncg * 10 * 8 * P + 64 * n + 30 * 8 * P
 
 
 def multi_chain_block(design, make_chain, state, widths, steps, warmup,
@@ -422,25 +471,27 @@ def main():
         else:
             op_bytes = dot_wb + tdot_wb
         op_gbs = op_bytes / op_avg / 1e6 if op_avg > 0 else 0.
-        # whole Gibbs iteration: n_cg operator applications; for the warm
-        # start one more application (dense single-pass kernel) or one product
-        # with X~ plus ONE with X~^T for the initial residual (the reference's
-        # RHS Tdot and the Tdot inside A x0 are a single pass over X~^T,
-        # cg_sampler.hip TD_RESID); the linear predictor of the Omega update;
-        # 10 P-vector passes per CG iteration (direction 6, update in the Tdot
-        # epilogue 4: q is no longer stored), ~64 bytes per row and ~30
-        # P-vector passes for the eta draws and the chain kernels.  Only bytes
-        # that are moved are credited.
-        if dense and fused_b:
-            iter_bytes = (mean_ncg + 1) * op_bytes + dot_wb
-        else:
-            iter_bytes = mean_ncg * op_bytes + 2 * dot_wb + tdot_wb
-        iter_bytes += mean_ncg * 10 * 8 * P + 64 * n + 30 * 8 * P
+        iter_bytes = iteration_bytes(mean_ncg, op_bytes, dot_wb, tdot_wb, n, P,
+                                     bool(dense and fused_b))
         iter_gbs = iter_bytes / ms_step / 1e6
         # measured on this box, same size as one launch's algorithmic bytes
         # and at 2 GB: what a plain streaming kernel reaches
         probe_small = _lib.hbm_probe(int(per[dom]["bytes"]), 50, dev_index)
         probe_large = _lib.hbm_probe(2 << 30, 10, dev_index)
+        # Workloads whose two orientations fit the 256 MiB Infinity Cache next
+        # to each other are re-read from the die, launch after launch: the HBM
+        # peak is not their ceiling.  The same-size read probe above re-reads
+        # its buffer 50 times, i.e. measures exactly that on-die rate.
+        cache_bound = None
+        if not dense and (dot_wb + tdot_wb) <= (256 << 20):
+            cache_bound = dict(
+                resident_bytes=int(dot_wb + tdot_wb),
+                ceiling="plain read stream of the launch's bytes, re-read "
+                        "50 times on this box (stream_probe_gbs."
+                        "read_same_bytes): served by L2 / Infinity Cache",
+                ceiling_gbs=round(probe_small[0], 1),
+                frac=round(ach / probe_small[0], 4) if probe_small[0] > 0
+                else None)
         kernel_name = ("operator X^T(Omega(X v)), one pass (dense f32)"
                        if dense and fused_b and dom == "dot"
                        else dom + " (" + design.storage_format + ")")
@@ -465,6 +516,7 @@ def main():
             iteration=dict(bytes=int(iter_bytes), gbs=round(iter_gbs, 1),
                            what="algorithmic bytes of one whole Gibbs "
                                 "iteration / ms_per_step"),
+            cache_bound=cache_bound,
             stream_probe_gbs={
                 "read_same_bytes": round(probe_small[0], 1),
                 "copy_same_bytes": round(probe_small[1], 1),

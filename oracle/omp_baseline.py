@@ -24,16 +24,26 @@ def load():
                                   stdout=subprocess.DEVNULL)
         lib = ctypes.CDLL(_LIB_PATH)
         lib.oracle_omp_max_threads.restype = c_int
-        lib.oracle_omp_dot.argtypes = [
-            c_int64, c_int64, c_int] + [c_void_p] * 6 + [c_int]
-        lib.oracle_omp_tdot.argtypes = [
-            c_int64, c_int64, c_int] + [c_void_p] * 6 + [c_int]
+        lib.oracle_omp_design_create.restype = c_void_p
+        lib.oracle_omp_design_create.argtypes = (
+            [c_int64, c_int64, c_int] + [c_void_p] * 7 + [c_int])
+        lib.oracle_omp_design_destroy.argtypes = [c_void_p]
+        lib.oracle_omp_design_destroy.restype = None
+        lib.oracle_omp_dot.argtypes = [c_void_p] * 3
+        lib.oracle_omp_tdot.argtypes = [c_void_p] * 3
         lib.oracle_omp_cg_sample.argtypes = (
-            [c_int64, c_int64, c_int] + [c_void_p] * 12 + [c_int]
-            + [c_void_p] * 2 + [c_int, c_double, c_void_p, POINTER(c_int),
-                                c_int])
+            [c_void_p] * 6 + [c_int] + [c_void_p] * 2 +
+            [c_int, c_double, c_void_p, POINTER(c_int)])
         _lib = lib
     return _lib
+
+
+def usable_cores():
+    """Cores this process may run on (the affinity mask, not the machine)."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
 def _p(a):
@@ -42,7 +52,9 @@ def _p(a):
 
 class OmpSparseDesign:
     """X~ = [1 | X - 1 offset^T] (sparse_matrix.py:68-129) with both
-    orientations stored as CSR; products run on `n_threads` cores."""
+    orientations stored as value-free (binary designs) CSR inside the C++
+    library, each thread's share first-touched by that thread (NUMA); products
+    run on `n_threads` cores (default: every core of the affinity mask)."""
     use_cupy = False
 
     def __init__(self, X, center_predictor=True, add_intercept=True,
@@ -53,38 +65,56 @@ class OmpSparseDesign:
         Xt = X.T.tocsr()
         Xt.sort_indices()
         self.n, self.p = X.shape
+        self.nnz = X.nnz
         self.intercept = 1 if add_intercept else 0
-        binary = bool(np.all(X.data == 1.))
-        self.indptr = np.ascontiguousarray(X.indptr, dtype=np.int32)
-        self.indices = np.ascontiguousarray(X.indices, dtype=np.int32)
-        self.data = None if binary else np.ascontiguousarray(X.data)
-        self.t_indptr = np.ascontiguousarray(Xt.indptr, dtype=np.int32)
-        self.t_indices = np.ascontiguousarray(Xt.indices, dtype=np.int32)
-        self.t_data = None if binary else np.ascontiguousarray(Xt.data)
+        self.binary = bool(np.all(X.data == 1.))
+        indptr = np.ascontiguousarray(X.indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(X.indices, dtype=np.int32)
+        data = None if self.binary else np.ascontiguousarray(X.data)
+        t_indptr = np.ascontiguousarray(Xt.indptr, dtype=np.int32)
+        t_indices = np.ascontiguousarray(Xt.indices, dtype=np.int32)
+        t_data = None if self.binary else np.ascontiguousarray(Xt.data)
         self.offset = np.asarray(X.mean(axis=0)).ravel() if center_predictor \
             else np.zeros(self.p)
-        self.n_threads = int(n_threads) or self.lib.oracle_omp_max_threads()
+        self.offset = np.ascontiguousarray(self.offset, dtype=np.float64)
+        self.n_threads = int(n_threads) or usable_cores()
+        self._h = self.lib.oracle_omp_design_create(
+            self.n, self.p, self.intercept, _p(indptr), _p(indices), _p(data),
+            _p(t_indptr), _p(t_indices), _p(t_data), _p(self.offset),
+            self.n_threads)
+        if not self._h:
+            raise MemoryError("oracle_omp_design_create failed")
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            self.lib.oracle_omp_design_destroy(h)
+            self._h = None
 
     @property
     def shape(self):
         return self.n, self.p + self.intercept
 
+    @property
+    def product_bytes(self):
+        """(X~ v, X~^T w): bytes one product streams -- SURVEY.md 8(d)'s
+        formula for the format actually read (int32 ids, values only when
+        stored, row pointers, vector in and out)."""
+        per = 4 + (0 if self.binary else 8)
+        P = self.p + self.intercept
+        return (self.nnz * per + 4 * (self.n + 1) + 8 * (P + self.n),
+                self.nnz * per + 4 * (self.p + 1) + 8 * (P + self.n))
+
     def dot(self, v):
         v = np.ascontiguousarray(v, dtype=np.float64)
         out = np.empty(self.n)
-        self.lib.oracle_omp_dot(self.n, self.p, self.intercept,
-                                _p(self.indptr), _p(self.indices),
-                                _p(self.data), _p(self.offset), _p(v), _p(out),
-                                self.n_threads)
+        self.lib.oracle_omp_dot(self._h, _p(v), _p(out))
         return out
 
     def Tdot(self, w):
         w = np.ascontiguousarray(w, dtype=np.float64)
         out = np.empty(self.p + self.intercept)
-        self.lib.oracle_omp_tdot(self.n, self.p, self.intercept,
-                                 _p(self.t_indptr), _p(self.t_indices),
-                                 _p(self.t_data), _p(self.offset), _p(w),
-                                 _p(out), self.n_threads)
+        self.lib.oracle_omp_tdot(self._h, _p(w), _p(out))
         return out
 
     def cg_sample(self, obs_prec, prior_prec_sqrt, z, coef_cg_init,
@@ -98,10 +128,8 @@ class OmpSparseDesign:
         coef = np.empty(P)
         n_iter = c_int(0)
         info = self.lib.oracle_omp_cg_sample(
-            self.n, self.p, self.intercept, _p(self.indptr), _p(self.indices),
-            _p(self.data), _p(self.t_indptr), _p(self.t_indices),
-            _p(self.t_data), _p(self.offset), _p(omega), _p(phi), _p(z),
-            _p(x0), _p(sd), int(n_unshrunk), _p(e1), _p(e2), int(maxiter),
-            float(atol), _p(coef), byref(n_iter), self.n_threads)
+            self._h, _p(omega), _p(phi), _p(z), _p(x0), _p(sd),
+            int(n_unshrunk), _p(e1), _p(e2), int(maxiter), float(atol),
+            _p(coef), byref(n_iter))
         return coef, {'n_iter': n_iter.value, 'valid_input': info >= 0,
                       'converged': info == 0}

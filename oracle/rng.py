@@ -72,6 +72,57 @@ class OracleRandom:
         return out
 
 
+class ParallelOracleRandom(OracleRandom):
+    """The same samplers on `n_threads` cores, for the multi-core CPU BASELINE
+    only (bench.py `cpu_baseline_omp`): the draws of an update are cut into
+    equal blocks, every block has its own PCG64 stream (spawned from the
+    reference's two seeds), and the C samplers -- which release the GIL under
+    ctypes -- run from a thread pool.  Same distributions, not the reference's
+    stream (its samplers consume ONE sequential stream each, random.py:17-22)."""
+
+    def __init__(self, seed=None, n_threads=1):
+        from concurrent.futures import ThreadPoolExecutor
+        self.n_threads = max(1, int(n_threads))
+        super().__init__(seed)
+        self.pool = ThreadPoolExecutor(self.n_threads)
+
+    def set_seed(self, seed):
+        super().set_seed(seed)
+        ss = np.random.SeedSequence(seed)
+        kids = ss.spawn(2 * self.n_threads)
+        self.pg_streams = [PCG64(k) for k in kids[:self.n_threads]]
+        self.ts_streams = [PCG64(k) for k in kids[self.n_threads:]]
+
+    def _blocks(self, size):
+        step = -(-size // self.n_threads)
+        return [(b, min(size, b + step)) for b in range(0, size, step)]
+
+    def polya_gamma(self, shape, tilt):
+        shape = np.ascontiguousarray(shape, dtype=np.int32)
+        tilt = np.ascontiguousarray(tilt, dtype=np.float64)
+        out = np.zeros(tilt.size)
+
+        def work(args):
+            k, (b, e) = args
+            self.lib.oracle_polya_gamma(_addr(self.pg_streams[k]), e - b,
+                                        _p(shape[b:e]), _p(tilt[b:e]),
+                                        _p(out[b:e]))
+        list(self.pool.map(work, enumerate(self._blocks(tilt.size))))
+        return out
+
+    def tilted_stable(self, char_exponent, tilt):
+        tilt = np.ascontiguousarray(tilt, dtype=np.float64)
+        out = np.zeros(tilt.size)
+
+        def work(args):
+            k, (b, e) = args
+            self.lib.oracle_tilted_stable(_addr(self.ts_streams[k]), e - b,
+                                          float(char_exponent), _p(tilt[b:e]),
+                                          _p(out[b:e]))
+        list(self.pool.map(work, enumerate(self._blocks(tilt.size))))
+        return out
+
+
 def csr_matvec(X, v):
     """y = X v with the C loop (cross-check of the NumPy/SciPy path)."""
     y = np.zeros(X.shape[0])

@@ -33,15 +33,16 @@ def cg_inputs(n, P, n_unshrunk=1, seed=0, flat_intercept=True,
                 n_unshrunk=n_unshrunk)
 
 
-def config2_small_problem(golden_dir):
-    """The scaled-down BASELINE config 2 problem of
-    tests/golden/chain_logit_binary_20000x1000_summary.npz, regenerated without
-    the reference (bayesbridge_amd.simulate replays the reference's RNG calls)
-    and checked against the checksums stored in the fixture."""
+def config2_small_problem(golden_dir,
+                          name='chain_logit_binary_20000x1000_summary.npz'):
+    """The BASELINE config 2 problem of a fixture under tests/golden/ (scaled
+    down: chain_logit_binary_20000x1000_summary.npz; full size:
+    chain_logit_binary_100000x10000_first10.npz), regenerated without the
+    reference (bayesbridge_amd.simulate replays the reference's RNG calls) and
+    checked against the checksums stored in the fixture."""
     import os
     from bayesbridge_amd import simulate
-    g = np.load(os.path.join(golden_dir,
-                             'chain_logit_binary_20000x1000_summary.npz'))
+    g = np.load(os.path.join(golden_dir, name))
     n, p = (int(v) for v in g['shape'])
     X = simulate.simulate_design_csr(n, p, binary_frac=1.,
                                      binary_pred_freq=float(g['freq']),

@@ -214,7 +214,7 @@ def test_dense_linear_chain_config1_summary(golden_dir):
                   - g['n_cg_iter']).max() <= 8
 
 
-def _variant_chain(tmp_path, env, family='logit', iters=6):
+def _variant_chain(tmp_path, env, family='logit', iters=6, n=4000, p=300):
     import os
     import subprocess
     import sys
@@ -223,7 +223,7 @@ def _variant_chain(tmp_path, env, family='logit', iters=6):
     out = os.path.join(str(tmp_path), "chain_%s_%s.npz" % (family, tag))
     run = subprocess.run(
         [sys.executable, os.path.join(ROOT, "scripts", "chain_variant_run.py"),
-         out, family, "4000", "300", str(iters)],
+         out, family, str(n), str(p), str(iters)],
         env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     return np.load(out)
@@ -242,3 +242,15 @@ def test_two_stream_iteration_is_bitwise_the_one_stream_iteration(tmp_path, fami
                 'n_cg_iter'):
         assert np.array_equal(a[key], b[key]), key
     assert np.all(np.isfinite(a['logp'])) and a['coef'].shape[0] == 6
+
+
+def test_automatic_two_stream_choice_matches_one_stream(tmp_path):
+    """BBX_CHAIN_FORK unset on a design past the automatic threshold (60 000
+    rows, 2 500 shrunk coefficients): the chain forks by itself, and its
+    samples are bit for bit those of the forced one-stream run."""
+    auto = _variant_chain(tmp_path, {}, n=60000, p=2500, iters=4)
+    one = _variant_chain(tmp_path, {'BBX_CHAIN_FORK': '0'}, n=60000, p=2500,
+                         iters=4)
+    for key in ('coef', 'local_scale', 'obs_prec', 'global_scale', 'logp',
+                'n_cg_iter'):
+        assert np.array_equal(auto[key], one[key]), key

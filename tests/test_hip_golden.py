@@ -236,3 +236,36 @@ def test_config2_scaled_exact_seed_and_device_rng(golden_dir):
     assert abs(lg.mean() - np.log(g['global_scale_mean'])) < ref_lg_sd + .1
     m_cg = dinfo['_reg_coef_sampling_info']['n_cg_iter'].mean()
     assert abs(m_cg - g['n_cg_iter'][int(g['n_burnin']):].mean()) < 5
+
+
+def test_config2_full_size_exact_seed_chain(golden_dir):
+    """BASELINE config 2 at FULL size under test (100 000 x 10 000 value-free
+    binary CSR, nnz 10 221 685, logit, demo prior): on the reference's random
+    streams the HIP chain reproduces the reference's first 10 samples (fixture
+    tests/golden/chain_logit_binary_100000x10000_first10.npz: 256 coefficients,
+    sum |coef|, tau, log posterior, n_cg_iter +- 2) AND every coefficient of the
+    oracle chain run here on the same design -- atol 1e-5, the reference's own
+    CPU-vs-GPU bound (tests/gpu_tests/test_gibbs.py:44)."""
+    from helpers import config2_small_problem
+    from oracle.gibbs import OracleGibbs
+    g, X, outcome = config2_small_problem(
+        golden_dir, 'chain_logit_binary_100000x10000_first10.npz')
+    kw = dict(bridge_exponent=.5, regularizing_slab_size=2.)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bridge = _bridge(outcome, X, 'logit', **kw)
+        assert bridge.model.design.storage_format == 'tiled'
+        s, info = bridge.gibbs(10, 0, init={'global_scale': .01},
+                               coef_sampler_type='cg', seed=111,
+                               options={'rng': 'reference'})
+    assert np.allclose(s['coef'][g['picked']], g['coef_first10'], atol=1e-5)
+    assert np.allclose(np.abs(s['coef']).sum(axis=0),
+                       g['coef_abs_sum_first10'], rtol=1e-5)
+    assert np.allclose(s['global_scale'], g['global_scale_first10'], rtol=1e-5)
+    assert np.allclose(s['logp'], g['logp_first10'], rtol=1e-6)
+    n_cg = info['_reg_coef_sampling_info']['n_cg_iter']
+    assert np.abs(n_cg - g['n_cg_iter']).max() <= 2
+    ora = OracleGibbs(outcome, X, 'logit', **kw).gibbs(
+        10, seed=111, init={'global_scale': .01})
+    assert np.allclose(s['coef'], ora['coef'], atol=1e-5)
+    assert np.abs(n_cg - ora['n_cg_iter']).max() <= 2

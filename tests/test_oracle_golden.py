@@ -167,3 +167,25 @@ def test_config4_scaled_chain_through_the_oracle(golden_dir):
     assert np.allclose(res['global_scale'], g['global_scale_samples'],
                        rtol=1e-5)
     assert np.allclose(res['logp'], g['logp_samples'], rtol=1e-6)
+
+
+def test_chain_config2_full_size_first10(golden_dir):
+    """BASELINE config 2 at FULL size (100 000 x 10 000 binary CSR, nnz
+    10 221 685, logit, demo prior; tests/golden/make_config2_full.py): the
+    design replayed by bayesbridge_amd.simulate carries the reference's
+    checksums, and the oracle chain reproduces the reference's first 10 samples
+    (256 stored coefficients, sum |coef| over all of them, tau, log posterior,
+    n_cg_iter) -- the same code path the GPU test compares the HIP chain with."""
+    from helpers import config2_small_problem
+    g, X, outcome = config2_small_problem(
+        golden_dir, 'chain_logit_binary_100000x10000_first10.npz')
+    chain = OracleGibbs(outcome, X, 'logit', bridge_exponent=.5,
+                        regularizing_slab_size=2.)
+    out = chain.gibbs(10, seed=111, init={'global_scale': .01})
+    assert np.allclose(out['coef'][g['picked']], g['coef_first10'], atol=1e-6)
+    assert np.allclose(np.abs(out['coef']).sum(axis=0),
+                       g['coef_abs_sum_first10'], rtol=1e-7)
+    assert np.allclose(out['global_scale'], g['global_scale_first10'],
+                       rtol=1e-6)
+    assert np.allclose(out['logp'], g['logp_first10'], rtol=1e-8)
+    assert np.array_equal(out['n_cg_iter'], g['n_cg_iter'])
