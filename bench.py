@@ -206,16 +206,21 @@ def iteration_bytes(mean_ncg, op_bytes, dot_bytes, tdot_bytes, n, P,
     n_cg operator applications; for the warm start one more application (dense
     single-pass kernel) or one product with X~ plus ONE with X~^T for the
     initial residual (cg_sampler.hip TD_RESID); the linear predictor of the
-    Omega update; 10 P-vector passes per CG iteration (direction 6, update in
-    the Tdot epilogue 4), ~64 bytes per row and ~30 P-vector passes for the
-    eta draws and the chain kernels.  Only bytes that are moved are credited.
-    Pinned against the PMC counters of a profiled chain
-    (profiles/r03_iteration_traffic.json, tests/test_bench_byte_model.py)."""
+    Omega update; the Omega vector every operator application scales by (8 n
+    bytes: the product byte counts hold the vector in and out only); 15
+    P-vector passes per CG iteration (direction kernel: r, p, s, offset, d in,
+    p, s.*p out; Tdot epilogue: offset, p, d, s, x, r in, x, r out -- its slab
+    read is part of tdot_bytes), ~64 bytes per row and ~30 P-vector passes
+    for the eta draws and the chain kernels.  Only bytes that are moved are
+    credited.  Pinned against the PMC counters of a profiled chain: 0.986 of
+    the measured HBM traffic (profiles/r03_iteration_traffic.json,
+    tests/test_bench_byte_model.py)."""
     if dense_single_pass:
         total = (mean_ncg + 1) * op_bytes + dot_bytes
     else:
         total = mean_ncg * op_bytes + 2 * dot_bytes + tdot_bytes
-    return total + mean_ncg * 10 * 8 * P + 64 * n + 30 * 8 * P
+    total += (mean_ncg + 1) * 8 * n
+    return total + mean_ncg * 15 * 8 * P + 64 * n + 30 * 8 * P
 
 
 def multi_chain_block(design, make_chain, state, widths, steps, warmup,

@@ -1,0 +1,28 @@
+"""CPU: bench.py's byte model of a whole Gibbs iteration (`roofline.iteration`,
+`iteration_frac`) against the HBM traffic MEASURED on an MI355X: two rocprofv3
+--pmc passes (FETCH_SIZE, WRITE_SIZE) over the last five iterations of a
+305-iteration config-3 chain, committed as profiles/r03_iteration_traffic.json
+(scripts/iteration_traffic.py, scripts/summarize_iteration_traffic.py)."""
+import json
+import os
+
+from conftest import ROOT
+
+
+def test_iteration_byte_model_is_within_3_percent_of_the_pmc_counters():
+    import bench
+    with open(os.path.join(ROOT, "profiles",
+                           "r03_iteration_traffic.json")) as fh:
+        prof = json.load(fh)
+    assert prof["iters"] == len(prof["n_cg_iter"]) >= 5
+    ncg = sum(prof["n_cg_iter"]) / len(prof["n_cg_iter"])
+    model = bench.iteration_bytes(
+        ncg, prof["dot_bytes"] + prof["tdot_bytes"], prof["dot_bytes"],
+        prof["tdot_bytes"], prof["n"], prof["P"])
+    # gfx950: FETCH_SIZE counts half the bytes of a 16-byte-per-lane stream
+    measured = (2. * prof["fetch_size_kb"] + prof["write_size_kb"]) * 1024. \
+        / prof["iters"]
+    assert abs(measured - prof["hbm_bytes_per_iteration"]) < 1e-6 * measured
+    assert abs(model / measured - 1.) <= .03, (model, measured)
+    # the operator's two products are what moves: > 95 % of an iteration
+    assert ncg * (prof["dot_bytes"] + prof["tdot_bytes"]) > .9 * measured
