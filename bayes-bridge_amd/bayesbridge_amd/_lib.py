@@ -58,6 +58,9 @@ def _declare(lib):
         "bbx_design_timed_bytes": (
             [hp, POINTER(c_int64), POINTER(c_int64)], c_int),
         "bbx_design_fused_operator_bytes": ([hp, POINTER(c_int64)], c_int),
+        "bbx_design_hybrid_info": (
+            [hp, POINTER(c_int), POINTER(c_int64), POINTER(c_int64),
+             POINTER(c_int64), POINTER(c_int)], c_int),
         "bbx_design_tiled_info": (
             [hp, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int),
              POINTER(c_int), POINTER(c_int64), POINTER(c_int64)], c_int),

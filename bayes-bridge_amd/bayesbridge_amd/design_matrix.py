@@ -141,6 +141,22 @@ class HipDesignMatrix():
                              G=G.value, n_quad=nq.value, n_slice=ns.value)
         return out
 
+    @property
+    def hybrid_info(self):
+        """None, or how a mixed design was split by value in the tiled format:
+        {'ones_nnz', 'rest_nnz', 'dense_nnz', 'dense_cols'} (entries equal to
+        1.0 in the value-free layout, a dense block for columns full of other
+        values, the rest in the valued layout)."""
+        from ctypes import c_int
+        hy, kd = c_int(), c_int()
+        a, b, c = c_int64(), c_int64(), c_int64()
+        _lib.check(self._lib.bbx_design_hybrid_info(
+            self._h, byref(hy), byref(a), byref(b), byref(c), byref(kd)))
+        if not hy.value:
+            return None
+        return dict(ones_nnz=a.value, rest_nnz=b.value, dense_nnz=c.value,
+                    dense_cols=kd.value)
+
     # -- the operator -------------------------------------------------------
     def dot(self, v):
         """X~ v (sparse_matrix.py:68-101, dense_matrix.py:37-48)."""

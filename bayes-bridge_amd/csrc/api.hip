@@ -833,6 +833,24 @@ int bbx_design_tiled_info(const bbx_design* h, int which, int* W,
   return tiled_describe(h, which, W, n_block, PR, G, n_quad, n_slice);
 }
 
+int bbx_design_hybrid_info(const bbx_design* h, int* is_hybrid,
+                           int64_t* ones_nnz, int64_t* rest_nnz,
+                           int64_t* dense_nnz, int* dense_cols) {
+  BBX_TRY(check_handle(h));
+  const int hy = (h->sparse && h->format == BBX_FORMAT_TILED)
+                     ? tiled_hybrid_info(h, ones_nnz, rest_nnz, dense_nnz,
+                                         dense_cols)
+                     : 0;
+  if (!hy) {
+    if (ones_nnz) *ones_nnz = 0;
+    if (rest_nnz) *rest_nnz = 0;
+    if (dense_nnz) *dense_nnz = 0;
+    if (dense_cols) *dense_cols = 0;
+  }
+  if (is_hybrid) *is_hybrid = hy;
+  return BBX_OK;
+}
+
 static int matvec_bytes_impl(const bbx_design* h, bool timed_only,
                              int64_t* dot_bytes, int64_t* tdot_bytes) {
   BBX_TRY(check_handle(h));

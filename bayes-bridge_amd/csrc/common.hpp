@@ -203,6 +203,7 @@ struct bbx_design {
 
   // --- LDS-tiled layout (BBX_FORMAT_TILED): see spmv_tiled.hip
   void* tiled = nullptr;           // bbx::TiledPair*
+  void* hybrid = nullptr;          // bbx::HybridParts*: mixed designs (instead of `tiled`)
   // layouts sized for 2 and 4 right-hand sides (batched chains), built on
   // first use from the CSR arrays above
   void* tiled_k[2] = {nullptr, nullptr};
@@ -373,6 +374,9 @@ int dense_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
                        int64_t* tdot_bytes, bool timed_only = false);
 int64_t tiled_storage_bytes(const bbx_design* h);
+// 1 when the design is stored split by value (HybridParts), else 0
+int tiled_hybrid_info(const bbx_design* h, int64_t* ones_nnz,
+                      int64_t* rest_nnz, int64_t* dense_nnz, int* kd);
 int tiled_describe(const bbx_design* h, int which, int* W, int* n_block,
                    int* PR, int* G, int64_t* n_quad, int64_t* n_slice);
 int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,

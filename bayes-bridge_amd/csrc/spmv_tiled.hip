@@ -97,6 +97,37 @@ struct TiledPair {
   TiledMatrix x, xt;
 };
 
+// Mixed designs: X = B + D + S.
+//
+// OHDSI-style designs are binary covariates plus a few continuous ones, and the
+// reference's own test helper builds simulate_design(n, p, binary_frac=.9)
+// (tests/helper.py:13).  One stored value that is not 1.0 used to move the
+// WHOLE matrix to the valued layout (10 bytes per entry instead of 2.4: 4x the
+// time per product).  Instead the entries are split by value at construction:
+//   B  every entry equal to 1.0            value-free tiled layout
+//   D  the other entries of columns that hold many of them (>= n / 16): a
+//      dense column-major block n x kd in f64 (a continuous covariate is a
+//      dense column)
+//   S  what is left                        valued tiled layout (often empty)
+// All three keep the row and column numbering of X, so no vector is permuted:
+//   X~ v   = epilogue(c + B v + [D v + S v])   the bracket is an n-vector the
+//            value-free kernel's epilogue adds (`addend`),
+//   X~^T w = the slabs of B^T w and S^T w and one more slab row holding D^T w,
+//            added in this order by the common epilogue kernel.
+struct HybridParts {
+  TiledPair ones;        // B
+  TiledPair rest;        // S (rest_nnz == 0: not built)
+  int64_t ones_nnz = 0, rest_nnz = 0, dense_nnz = 0;
+  int kd = 0;            // columns of D
+  DevMem dense_cols;     // int32[kd]: column of X (0-based, without intercept)
+  DevMem D;              // double[kd][n], column-major
+  DevMem addend;         // double[n]
+  DevMem v_dense;        // double[kd]
+  DevMem d_part;         // double[NPART][kd]: partial sums of D^T w
+  DevMem slab;           // double[(G_B + G_S + 1)][p]
+  int n_slab = 0;
+};
+
 // ------------------------------------------------------------------ kernel
 
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -223,7 +254,8 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     const int32_t* __restrict__ panel_fold, const FoldDesc* __restrict__ folds,
     double* __restrict__ out_sum_part, int twt_off, int ablate,
     unsigned long long* dbg, const int* __restrict__ skip_flag,
-    ChainPtrs rowscale_k, ChainOut out_k, int out_stride, int part_stride) {
+    ChainPtrs rowscale_k, ChainOut out_k, int out_stride, int part_stride,
+    const double* __restrict__ addend) {
   constexpr int K = KP > 0 ? 2 * KP : 1;
   // (scalar load, issued first; checked below once the descriptor loads that
   // every launch needs anyway have been issued, so it adds no round trip)
@@ -701,7 +733,8 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
       for (int u = 0; u < EPI_UNROLL; ++u) {
         const int r = tid + u * TILE_THREADS;
         if (r < rows_here) {
-          const double t = c + acc[r];
+          double t = c + acc[r];
+          if (addend) t += addend[row0 + r];
           double v = t;
           if (rowscale) v *= rs_pre[u];
           out[row0 + r] = v;
@@ -833,55 +866,197 @@ static size_t lds_bytes(const TiledMatrix& m) {
 void destroy_tiled(bbx_design* h) {
   delete static_cast<TiledPair*>(h->tiled);
   h->tiled = nullptr;
+  delete static_cast<HybridParts*>(h->hybrid);
+  h->hybrid = nullptr;
   for (void*& t : h->tiled_k) {
     delete static_cast<TiledPair*>(t);
     t = nullptr;
   }
 }
 
-// Builds both orientations from the device CSR arrays in the handle (CSR of X
-// and CSR of X^T) through a host pass, sized for K right-hand sides.
-static int build_tiled_pair(bbx_design* h, int K, void** slot) {
-  const int64_t n = h->n, p = h->p, nnz = h->nnz;
-  std::vector<int32_t> rowptr((size_t)n + 1), colidx((size_t)std::max<int64_t>(nnz, 1));
-  std::vector<double> vals;
-  BBX_HIP(hipMemcpy(rowptr.data(), h->indptr.ptr, sizeof(int32_t) * (size_t)(n + 1),
+struct HostCsr {
+  std::vector<int32_t> rowptr, colidx;
+  std::vector<double> vals;  // empty: every stored value is 1.0
+};
+
+static int fetch_host_csr(const bbx_design* h, bool transpose, HostCsr* out) {
+  const int64_t R = transpose ? h->p : h->n, nnz = h->nnz;
+  const DevMem& ip = transpose ? h->t_indptr : h->indptr;
+  const DevMem& ix = transpose ? h->t_indices : h->indices;
+  const DevMem& da = transpose ? h->t_data : h->data;
+  out->rowptr.resize((size_t)R + 1);
+  out->colidx.resize((size_t)std::max<int64_t>(nnz, 1));
+  BBX_HIP(hipMemcpy(out->rowptr.data(), ip.ptr, sizeof(int32_t) * (size_t)(R + 1),
                     hipMemcpyDeviceToHost));
   if (nnz > 0)
-    BBX_HIP(hipMemcpy(colidx.data(), h->indices.ptr, sizeof(int32_t) * (size_t)nnz,
+    BBX_HIP(hipMemcpy(out->colidx.data(), ix.ptr, sizeof(int32_t) * (size_t)nnz,
                       hipMemcpyDeviceToHost));
+  out->vals.clear();
   if (!h->binary) {
-    vals.resize((size_t)std::max<int64_t>(nnz, 1));
-    BBX_HIP(hipMemcpy(vals.data(), h->data.ptr, sizeof(double) * (size_t)nnz,
+    out->vals.resize((size_t)std::max<int64_t>(nnz, 1));
+    BBX_HIP(hipMemcpy(out->vals.data(), da.ptr, sizeof(double) * (size_t)nnz,
                       hipMemcpyDeviceToHost));
-  }
-  TiledPair* tp = new (std::nothrow) TiledPair();
-  if (!tp) return fail(BBX_ERR_INVALID, "out of host memory");
-  *slot = tp;  // owned by the handle from here on (destroy_tiled)
-  BBX_TRY(build_one(tp->x, n, p, nnz, rowptr.data(), colidx.data(),
-                    h->binary ? nullptr : vals.data(), false, K));
-  // transpose orientation from the CSR of X^T built on the device
-  rowptr.assign((size_t)p + 1, 0);
-  BBX_HIP(hipMemcpy(rowptr.data(), h->t_indptr.ptr, sizeof(int32_t) * (size_t)(p + 1),
-                    hipMemcpyDeviceToHost));
-  if (nnz > 0)
-    BBX_HIP(hipMemcpy(colidx.data(), h->t_indices.ptr,
-                      sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
-  if (!h->binary)
-    BBX_HIP(hipMemcpy(vals.data(), h->t_data.ptr, sizeof(double) * (size_t)nnz,
-                      hipMemcpyDeviceToHost));
-  BBX_TRY(build_one(tp->xt, p, n, nnz, rowptr.data(), colidx.data(),
-                    h->binary ? nullptr : vals.data(), true, K));
-  for (const TiledMatrix* m : {&tp->x, &tp->xt}) {
-    const size_t lb = lds_bytes(*m);
-    if (lb > (size_t)TILE_LDS_BYTES)
-      return fail(BBX_ERR_INVALID, "tile does not fit in LDS");
   }
   return BBX_OK;
 }
 
+static int check_lds(const TiledPair* tp) {
+  for (const TiledMatrix* m : {&tp->x, &tp->xt})
+    if (lds_bytes(*m) > (size_t)TILE_LDS_BYTES)
+      return fail(BBX_ERR_INVALID, "tile does not fit in LDS");
+  return BBX_OK;
+}
+
+// Builds both orientations from the device CSR arrays in the handle (CSR of X
+// and CSR of X^T) through a host pass, sized for K right-hand sides.
+static int build_tiled_pair(bbx_design* h, int K, void** slot) {
+  const int64_t n = h->n, p = h->p, nnz = h->nnz;
+  TiledPair* tp = new (std::nothrow) TiledPair();
+  if (!tp) return fail(BBX_ERR_INVALID, "out of host memory");
+  *slot = tp;  // owned by the handle from here on (destroy_tiled)
+  HostCsr c;
+  BBX_TRY(fetch_host_csr(h, false, &c));
+  BBX_TRY(build_one(tp->x, n, p, nnz, c.rowptr.data(), c.colidx.data(),
+                    h->binary ? nullptr : c.vals.data(), false, K));
+  // transpose orientation from the CSR of X^T built on the device
+  BBX_TRY(fetch_host_csr(h, true, &c));
+  BBX_TRY(build_one(tp->xt, p, n, nnz, c.rowptr.data(), c.colidx.data(),
+                    h->binary ? nullptr : c.vals.data(), true, K));
+  return check_lds(tp);
+}
+
+// Rows of one orientation split by value (see HybridParts): the entries equal
+// to 1.0, and the others outside the dense columns.  `col_is_dense` is indexed
+// by the ORIGINAL column id: the row id for the transposed orientation.
+static void split_rows(int64_t R, const HostCsr& c, bool transpose,
+                       const std::vector<uint8_t>& col_is_dense, HostCsr* ones,
+                       HostCsr* rest) {
+  ones->rowptr.assign((size_t)R + 1, 0);
+  rest->rowptr.assign((size_t)R + 1, 0);
+  ones->colidx.clear();
+  rest->colidx.clear();
+  ones->vals.clear();
+  rest->vals.clear();
+  for (int64_t r = 0; r < R; ++r) {
+    for (int32_t k = c.rowptr[(size_t)r]; k < c.rowptr[(size_t)r + 1]; ++k) {
+      const double v = c.vals[(size_t)k];
+      const int32_t j = c.colidx[(size_t)k];
+      if (v == 1.0) {
+        ones->colidx.push_back(j);
+      } else if (!col_is_dense[(size_t)(transpose ? r : j)]) {
+        rest->colidx.push_back(j);
+        rest->vals.push_back(v);
+      }
+    }
+    ones->rowptr[(size_t)r + 1] = (int32_t)ones->colidx.size();
+    rest->rowptr[(size_t)r + 1] = (int32_t)rest->colidx.size();
+  }
+  if (ones->colidx.empty()) ones->colidx.push_back(0);
+  if (rest->colidx.empty()) {
+    rest->colidx.push_back(0);
+    rest->vals.push_back(0.);
+  }
+}
+
+// Decides whether the design is worth splitting and builds the parts.
+// Returns BBX_OK with h->hybrid set, or 1 when the plain valued layout is the
+// right one (nothing built).
+static int build_hybrid(bbx_design* h) {
+  const int64_t n = h->n, p = h->p, nnz = h->nnz;
+  if (h->binary || nnz == 0) return 1;
+  HostCsr cx;
+  BBX_TRY(fetch_host_csr(h, false, &cx));
+  // per column: entries equal to 1.0 and other entries
+  std::vector<int64_t> c_one((size_t)p, 0), c_val((size_t)p, 0);
+  for (int64_t k = 0; k < nnz; ++k)
+    (cx.vals[(size_t)k] == 1.0 ? c_one : c_val)[(size_t)cx.colidx[(size_t)k]] += 1;
+  const int64_t dense_min = std::max<int64_t>(n / 16, 1);
+  std::vector<uint8_t> is_dense((size_t)p, 0);
+  std::vector<int32_t> dense_cols;
+  int64_t ones_nnz = 0, dense_nnz = 0;
+  for (int64_t j = 0; j < p; ++j) {
+    ones_nnz += c_one[(size_t)j];
+    if (c_val[(size_t)j] >= dense_min) {
+      is_dense[(size_t)j] = 1;
+      dense_cols.push_back((int32_t)j);
+      dense_nnz += c_val[(size_t)j];
+    }
+  }
+  // a dense block beyond 8 GB or 4096 columns is not a "few continuous
+  // covariates" design: those entries stay in the valued tiled part
+  if ((double)dense_cols.size() * (double)n * 8. > 8e9 ||
+      dense_cols.size() > 4096) {
+    std::fill(is_dense.begin(), is_dense.end(), 0);
+    dense_cols.clear();
+    dense_nnz = 0;
+  }
+  const int64_t rest_nnz = nnz - ones_nnz - dense_nnz;
+  // worth it when the value-free part and the dense block carry most entries
+  if (4 * ones_nnz < nnz || 2 * (ones_nnz + dense_nnz) < nnz) return 1;
+  HybridParts* hp = new (std::nothrow) HybridParts();
+  if (!hp) return fail(BBX_ERR_INVALID, "out of host memory");
+  h->hybrid = hp;  // owned by the handle (destroy_tiled)
+  hp->ones_nnz = ones_nnz;
+  hp->rest_nnz = rest_nnz;
+  hp->dense_nnz = dense_nnz;
+  hp->kd = (int)dense_cols.size();
+  HostCsr ones, rest;
+  split_rows(n, cx, false, is_dense, &ones, &rest);
+  BBX_TRY(build_one(hp->ones.x, n, p, ones_nnz, ones.rowptr.data(),
+                    ones.colidx.data(), nullptr, false, 1));
+  if (rest_nnz > 0)
+    BBX_TRY(build_one(hp->rest.x, n, p, rest_nnz, rest.rowptr.data(),
+                      rest.colidx.data(), rest.vals.data(), false, 1));
+  // the direct epilogue of the value-free kernel carries the other parts:
+  // it exists for one column group and <= NPART panels only
+  if (hp->ones.x.G != 1 || hp->ones.x.n_panel > NPART) {
+    delete hp;
+    h->hybrid = nullptr;
+    return 1;
+  }
+  if (hp->kd > 0) {
+    // D column-major: D[slot][i] = the non-one entry of row i in that column
+    std::vector<int32_t> slot_of((size_t)p, -1);
+    for (int s_ = 0; s_ < hp->kd; ++s_) slot_of[(size_t)dense_cols[(size_t)s_]] = s_;
+    std::vector<double> D((size_t)hp->kd * (size_t)n, 0.);
+    for (int64_t r = 0; r < n; ++r)
+      for (int32_t k = cx.rowptr[(size_t)r]; k < cx.rowptr[(size_t)r + 1]; ++k) {
+        const int32_t s_ = slot_of[(size_t)cx.colidx[(size_t)k]];
+        // (duplicates of one (row, column) add up, like everywhere else)
+        if (s_ >= 0 && cx.vals[(size_t)k] != 1.0)
+          D[(size_t)s_ * (size_t)n + (size_t)r] += cx.vals[(size_t)k];
+      }
+    BBX_TRY(upload(hp->D, D.data(), D.size() * sizeof(double)));
+    BBX_TRY(upload(hp->dense_cols, dense_cols.data(),
+                   dense_cols.size() * sizeof(int32_t)));
+    BBX_TRY(hp->v_dense.alloc(sizeof(double) * (size_t)hp->kd));
+    BBX_TRY(hp->d_part.alloc(sizeof(double) * NPART * (size_t)hp->kd));
+  }
+  {  // transposed orientation of B and S
+    HostCsr ct;
+    BBX_TRY(fetch_host_csr(h, true, &ct));
+    split_rows(p, ct, true, is_dense, &ones, &rest);
+    BBX_TRY(build_one(hp->ones.xt, p, n, ones_nnz, ones.rowptr.data(),
+                      ones.colidx.data(), nullptr, true, 1));
+    if (rest_nnz > 0)
+      BBX_TRY(build_one(hp->rest.xt, p, n, rest_nnz, rest.rowptr.data(),
+                        rest.colidx.data(), rest.vals.data(), true, 1));
+  }
+  BBX_TRY(check_lds(&hp->ones));
+  if (rest_nnz > 0) BBX_TRY(check_lds(&hp->rest));
+  hp->n_slab = hp->ones.xt.G + (rest_nnz > 0 ? hp->rest.xt.G : 0) +
+               (hp->kd > 0 ? 1 : 0);
+  BBX_TRY(hp->slab.alloc(sizeof(double) * (size_t)hp->n_slab * (size_t)p));
+  BBX_HIP(hipMemset(hp->slab.ptr, 0, sizeof(double) * (size_t)hp->n_slab * (size_t)p));
+  BBX_TRY(hp->addend.alloc(sizeof(double) * (size_t)n));
+  return BBX_OK;
+}
+
 int build_tiled(bbx_design* h) {
-  BBX_TRY(build_tiled_pair(h, 1, &h->tiled));
+  // mixed designs: value-free part + dense block + valued rest (HybridParts)
+  const int st_h = no_throw([&]() -> int { return build_hybrid(h); });
+  if (st_h < 0) return st_h;
+  if (st_h != BBX_OK) BBX_TRY(build_tiled_pair(h, 1, &h->tiled));
 #define BBX_TILED_ATTR(VV, WW, KK)                                             \
   BBX_HIP(hipFuncSetAttribute(                                                 \
       reinterpret_cast<const void*>(&tiled_spmv_kernel<VV, WW, KK>),           \
@@ -902,7 +1077,8 @@ int build_tiled(bbx_design* h) {
 
 // The layout sized for K right-hand sides (K = 2, 4), built on first use.
 int ensure_tiled_k(bbx_design* h, int K) {
-  if (!h->sparse || h->format != BBX_FORMAT_TILED || !h->tiled)
+  // (a mixed design's K-layout is the plain valued one of the whole matrix)
+  if (!h->sparse || h->format != BBX_FORMAT_TILED || (!h->tiled && !h->hybrid))
     return fail(BBX_ERR_STATE, "batched chains need the tiled format");
   if (K == 1) return BBX_OK;
   if (K != 2 && K != 4) return fail(BBX_ERR_INVALID, "K must be 1, 2 or 4");
@@ -926,7 +1102,8 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                         const double* rowscale, double* out, double* slab,
                         double* out_sum_part, hipEvent_t ev_begin = nullptr,
                         hipEvent_t ev_end = nullptr, int twt_off = 0,
-                        const TiledBatchArgs* ba = nullptr) {
+                        const TiledBatchArgs* ba = nullptr,
+                        const double* addend = nullptr) {
   const unsigned grid = (unsigned)(m.n_panel * m.G);
   const size_t lb = lds_bytes(m);
   // Instrumented builds only (-DBBX_TILED_INSTRUMENT=1; the product library
@@ -964,7 +1141,8 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                      out, slab, m.PR + m.n_extra,                              \
                      m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),       \
                      out_sum_part, twt_off, ablate, dbg, h->skip_flag,         \
-                     bb.rowscale, bb.out, bb.out_stride, bb.part_stride)
+                     bb.rowscale, bb.out, bb.out_stride, bb.part_stride,       \
+                     addend)
 #define BBX_TILED_LAUNCH(VV, VALPTR)                                           \
   do {                                                                         \
     if (m.K == 2) BBX_TILED_LAUNCH_W(VV, true, 1, VALPTR);                \
@@ -1013,18 +1191,182 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
   return BBX_OK;
 }
 
+// ---- mixed designs (HybridParts): the small kernels around the tiled ones
+
+// v_dense[j] = v[intercept + dense_cols[j]]
+__global__ void hyb_gather_kernel(int kd, int intercept,
+                                  const int32_t* __restrict__ dense_cols,
+                                  const double* __restrict__ v,
+                                  double* __restrict__ v_dense) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < kd) v_dense[j] = v[intercept + dense_cols[j]];
+}
+
+// addend[i] = sum_g rest_slab[g][i] + sum_j D[j][i] v_dense[j]   (fixed order)
+__global__ __launch_bounds__(256) void hyb_addend_kernel(
+    int64_t n, int kd, const double* __restrict__ D,
+    const double* __restrict__ v_dense, const double* __restrict__ rest_slab,
+    int G_rest, double* __restrict__ addend, const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  extern __shared__ double s_v[];
+  for (int j = threadIdx.x; j < kd; j += 256) s_v[j] = v_dense[j];
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256) {
+    double a = 0.;
+    for (int g = 0; g < G_rest; ++g) a += rest_slab[(int64_t)g * n + i];
+    int j = 0;
+    for (; j + 4 <= kd; j += 4) {
+      const double d0 = D[(int64_t)j * n + i], d1 = D[(int64_t)(j + 1) * n + i],
+                   d2 = D[(int64_t)(j + 2) * n + i], d3 = D[(int64_t)(j + 3) * n + i];
+      a += d0 * s_v[j];
+      a += d1 * s_v[j + 1];
+      a += d2 * s_v[j + 2];
+      a += d3 * s_v[j + 3];
+    }
+    for (; j < kd; ++j) a += D[(int64_t)j * n + i] * s_v[j];
+    addend[i] = a;
+  }
+}
+
+// part[b][j] = sum over block b's rows of D[j][i] w[i]; four columns per round
+__global__ __launch_bounds__(256) void hyb_dense_tdot_kernel(
+    int64_t n, int kd, const double* __restrict__ D,
+    const double* __restrict__ w, double* __restrict__ part,
+    const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  __shared__ double s_w[4][256 / WAVE];
+  const int64_t rows = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows;
+  const int64_t r1 = (r0 + rows < n) ? r0 + rows : n;
+  for (int j0 = 0; j0 < kd; j0 += 4) {
+    double a[4] = {0., 0., 0., 0.};
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
+      const double wi = w[i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + u < kd) a[u] += D[(int64_t)(j0 + u) * n + i] * wi;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double t = wave_allsum(a[u]);
+      if ((threadIdx.x & (WAVE - 1)) == 0) s_w[u][threadIdx.x / WAVE] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && j0 + (int)threadIdx.x < kd) {
+      double t = 0.;
+      for (int k = 0; k < 256 / WAVE; ++k) t += s_w[threadIdx.x][k];
+      part[(int64_t)blockIdx.x * kd + j0 + threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+}
+
+// slab_row[dense_cols[j]] = sum_b part[b][j], blocks in order
+__global__ void hyb_dense_scatter_kernel(int kd, int n_block,
+                                         const int32_t* __restrict__ dense_cols,
+                                         const double* __restrict__ part,
+                                         double* __restrict__ slab_row,
+                                         const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= kd) return;
+  double t = 0.;
+  for (int b = 0; b < n_block; ++b) t += part[(int64_t)b * kd + j];
+  slab_row[dense_cols[j]] = t;
+}
+
+static int launch_dot_hybrid(bbx_design* h, const double* d_v,
+                             const double* d_rowscale, double* d_t,
+                             double* d_sum_part, int* sum_done,
+                             double* d_twt_part, int* twt_done) {
+  HybridParts* hp = static_cast<HybridParts*>(h->hybrid);
+  const double* x = d_v + h->intercept;
+  const double* x0 = h->intercept ? d_v : nullptr;
+  BBX_TRY(timer_begin(h, 0));
+  const double* rest_slab = nullptr;
+  int G_rest = 0;
+  if (hp->rest_nnz > 0) {
+    const TiledMatrix& ms = hp->rest.x;
+    BBX_TRY(launch_tiled(h, ms, x, nullptr, nullptr, nullptr, nullptr,
+                         ms.slab.as<double>(), nullptr));
+    rest_slab = ms.slab.as<double>();
+    G_rest = ms.G;
+  }
+  if (hp->kd > 0)
+    hipLaunchKernelGGL(hyb_gather_kernel, dim3((hp->kd + 255) / 256), dim3(256),
+                       0, h->stream, hp->kd, h->intercept,
+                       hp->dense_cols.as<int32_t>(), d_v,
+                       hp->v_dense.as<double>());
+  hipLaunchKernelGGL(hyb_addend_kernel, dim3(1024), dim3(256),
+                     sizeof(double) * (size_t)(hp->kd + 1), h->stream, h->n,
+                     hp->kd, hp->D.as<double>(), hp->v_dense.as<double>(),
+                     rest_slab, G_rest, hp->addend.as<double>(), h->skip_flag);
+  BBX_HIP(hipGetLastError());
+  const TiledMatrix& mb = hp->ones.x;  // G == 1, n_panel <= NPART (build_hybrid)
+  double* fused = nullptr;
+  int twt_off = 0;
+  if (d_sum_part) {
+    fused = d_sum_part;
+    if (sum_done) *sum_done = 1;
+    if (d_twt_part && twt_done && d_twt_part != d_sum_part) {
+      twt_off = (int)(d_twt_part - d_sum_part);
+      *twt_done = 1;
+    }
+  }
+  BBX_TRY(launch_tiled(h, mb, x, part_slot(h, PS_C), x0, d_rowscale, d_t,
+                       nullptr, fused, nullptr, nullptr, twt_off, nullptr,
+                       hp->addend.as<double>()));
+  return timer_end(h, 0);
+}
+
+static int launch_tdot_hybrid(bbx_design* h, const double* d_w,
+                              const double* d_sumw_part,
+                              const TdotEpilogue& ep, double* d_out) {
+  HybridParts* hp = static_cast<HybridParts*>(h->hybrid);
+  double* slab = hp->slab.as<double>();
+  BBX_TRY(timer_begin(h, 1));
+  const TiledMatrix& mb = hp->ones.xt;
+  BBX_TRY(launch_tiled(h, mb, d_w, nullptr, nullptr, nullptr, nullptr, slab,
+                       nullptr));
+  int at = mb.G;
+  if (hp->rest_nnz > 0) {
+    const TiledMatrix& ms = hp->rest.xt;
+    BBX_TRY(launch_tiled(h, ms, d_w, nullptr, nullptr, nullptr, nullptr,
+                         slab + (size_t)at * (size_t)h->p, nullptr));
+    at += ms.G;
+  }
+  if (hp->kd > 0) {
+    hipLaunchKernelGGL(hyb_dense_tdot_kernel, dim3(NPART), dim3(256), 0,
+                       h->stream, h->n, hp->kd, hp->D.as<double>(), d_w,
+                       hp->d_part.as<double>(), h->skip_flag);
+    hipLaunchKernelGGL(hyb_dense_scatter_kernel, dim3((hp->kd + 255) / 256),
+                       dim3(256), 0, h->stream, hp->kd, NPART,
+                       hp->dense_cols.as<int32_t>(), hp->d_part.as<double>(),
+                       slab + (size_t)at * (size_t)h->p, h->skip_flag);
+    BBX_HIP(hipGetLastError());
+    at += 1;
+  }
+  BBX_TRY(timer_end(h, 1));
+  // the epilogue kernel adds the slabs in this order: B, S, D
+  return launch_tdot_finalize(h, slab, at, d_sumw_part, ep, d_out);
+}
+
 // Returns 1 through *sum_done when the partial sums of the output were
 // produced by the kernel itself (no separate reduction pass needed).
 int launch_dot_tiled(bbx_design* h, const double* d_v,
                      const double* d_rowscale, double* d_t,
                      double* d_sum_part, int* sum_done, double* d_twt_part,
                      int* twt_done) {
+  if (sum_done) *sum_done = 0;
+  if (twt_done) *twt_done = 0;
+  if (h->hybrid)
+    return launch_dot_hybrid(h, d_v, d_rowscale, d_t, d_sum_part, sum_done,
+                             d_twt_part, twt_done);
   TiledPair* tp = static_cast<TiledPair*>(h->tiled);
   const TiledMatrix& m = tp->x;
   const double* x = d_v + h->intercept;
   const double* x0 = h->intercept ? d_v : nullptr;
-  if (sum_done) *sum_done = 0;
-  if (twt_done) *twt_done = 0;
   if (m.G == 1) {
     double* fused = nullptr;
     int twt_off = 0;
@@ -1057,6 +1399,7 @@ int launch_dot_tiled(bbx_design* h, const double* d_v,
 int launch_tdot_tiled(bbx_design* h, const double* d_w,
                       const double* d_sumw_part, const TdotEpilogue& ep,
                       double* d_out) {
+  if (h->hybrid) return launch_tdot_hybrid(h, d_w, d_sumw_part, ep, d_out);
   TiledPair* tp = static_cast<TiledPair*>(h->tiled);
   const TiledMatrix& m = tp->xt;
   hipEvent_t ea, eb;
@@ -1194,6 +1537,25 @@ int tiled_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
 
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
                        int64_t* tdot_bytes, bool timed_only) {
+  if (h->hybrid) {
+    // every part's stream once, the dense block once, the rest part's slabs
+    // and the addend written and read back, vectors in and out; the timers
+    // bracket everything but the final epilogue kernel of the Tdot
+    const HybridParts* hp = static_cast<const HybridParts*>(h->hybrid);
+    const int64_t dense = 8 * (int64_t)hp->kd * h->n;
+    int64_t db = hp->ones.x.stream_bytes() + dense + 8 * (h->P + h->n) +
+                 16 * h->n;
+    int64_t tb = hp->ones.xt.stream_bytes() + dense + 8 * h->n +
+                 8 * (int64_t)hp->n_slab * h->p;
+    if (hp->rest_nnz > 0) {
+      db += hp->rest.x.stream_bytes() + 16 * (int64_t)hp->rest.x.G * h->n + 8 * h->P;
+      tb += hp->rest.xt.stream_bytes() + 8 * h->n;
+    }
+    if (!timed_only) tb += 8 * (int64_t)hp->n_slab * h->p + 8 * h->P;
+    *dot_bytes = db;
+    *tdot_bytes = tb;
+    return BBX_OK;
+  }
   const TiledPair* tp = static_cast<const TiledPair*>(h->tiled);
   if (!tp) return fail(BBX_ERR_STATE, "tiled format not built");
   // Whole product: bytes of the format actually read + vector in + vector out
@@ -1213,7 +1575,25 @@ int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
   return BBX_OK;
 }
 
+int tiled_hybrid_info(const bbx_design* h, int64_t* ones_nnz,
+                      int64_t* rest_nnz, int64_t* dense_nnz, int* kd) {
+  const HybridParts* hp = static_cast<const HybridParts*>(h->hybrid);
+  if (ones_nnz) *ones_nnz = hp ? hp->ones_nnz : 0;
+  if (rest_nnz) *rest_nnz = hp ? hp->rest_nnz : 0;
+  if (dense_nnz) *dense_nnz = hp ? hp->dense_nnz : 0;
+  if (kd) *kd = hp ? hp->kd : 0;
+  return hp ? 1 : 0;
+}
+
 int64_t tiled_storage_bytes(const bbx_design* h) {
+  if (h->hybrid) {
+    const HybridParts* hp = static_cast<const HybridParts*>(h->hybrid);
+    int64_t b = hp->ones.x.stream_bytes() + hp->ones.xt.stream_bytes() +
+                8 * (int64_t)hp->kd * h->n;
+    if (hp->rest_nnz > 0)
+      b += hp->rest.x.stream_bytes() + hp->rest.xt.stream_bytes();
+    return b;
+  }
   const TiledPair* tp = static_cast<const TiledPair*>(h->tiled);
   if (!tp) return 0;
   return tp->x.stream_bytes() + tp->xt.stream_bytes();
@@ -1222,6 +1602,12 @@ int64_t tiled_storage_bytes(const bbx_design* h) {
 int tiled_describe(const bbx_design* h, int which, int* W, int* n_block,
                    int* PR, int* G, int64_t* n_quad, int64_t* n_slice) {
   const TiledPair* tp = static_cast<const TiledPair*>(h->tiled);
+  // mixed designs: the value-free part (0, 1) and the valued rest (6, 7)
+  if (h->hybrid) {
+    const HybridParts* hp = static_cast<const HybridParts*>(h->hybrid);
+    tp = (which >= 6) ? (hp->rest_nnz > 0 ? &hp->rest : nullptr) : &hp->ones;
+    if (which >= 6) which -= 6;
+  }
   if (!tp) return fail(BBX_ERR_STATE, "tiled format not built");
   if (which >= 2) {  // 2, 3: the K = 2 layout; 4, 5: the K = 4 layout
     tp = tiled_pair_for(h, which < 4 ? 2 : 4);

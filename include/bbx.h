@@ -157,6 +157,16 @@ int bbx_design_timed_bytes(const bbx_design* h, int64_t* dot_bytes,
  * matrix + v + Omega + the per-workgroup slabs it writes. */
 int bbx_design_fused_operator_bytes(const bbx_design* h, int64_t* bytes);
 
+/* Mixed designs (binary covariates plus a few continuous ones: the reference's
+ * tests build simulate_design(n, p, binary_frac=.9), tests/helper.py:13) are
+ * stored split by VALUE in the tiled format: the entries equal to 1.0 in the
+ * value-free layout, the other entries of columns that hold many of them in a
+ * dense column-major f64 block, what is left in the valued layout; the three
+ * products are added in a fixed order.  *is_hybrid says whether that happened,
+ * the counts how the entries were divided. */
+int bbx_design_hybrid_info(const bbx_design* h, int* is_hybrid,
+                           int64_t* ones_nnz, int64_t* rest_nnz,
+                           int64_t* dense_nnz, int* dense_cols);
 /* Geometry of the tiled format (BBX_FORMAT_TILED only): which = 0 for X, 1 for
  * X^T; W = column-block width, n_block = column blocks, PR = rows per panel,
  * G = column-block groups (partial-sum slabs), n_quad = 512-byte id groups

@@ -1,0 +1,58 @@
+"""Times the products of a MIXED design at the config-3 shape: the synthetic
+binary design of bench.py plus `n_cont` dense continuous columns (a fraction
+of the binary entries can also carry values), tiled format.
+Usage: python scripts/bench_mixed.py [n_cont] [reps] [valued_frac]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.environ.get("BBX_PACKAGE_DIR",
+                                  os.path.join(ROOT, "bayes-bridge_amd")))
+import numpy as np
+import scipy.sparse as sparse
+import torch
+
+from bayesbridge_amd import HipSparseDesignMatrix, simulate
+
+n_cont = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+valued_frac = float(sys.argv[3]) if len(sys.argv) > 3 else 0.
+n, p, f = 1000000, 50000, .002
+indptr, indices = simulate.simulate_binary_csr_device(n, p, f, seed=111)
+torch.cuda.synchronize()
+Xb = sparse.csr_matrix((np.ones(indices.numel()), indices.cpu().numpy(),
+                        indptr.cpu().numpy()), shape=(n, p))
+rng = np.random.default_rng(3)
+if valued_frac > 0:
+    m = rng.random(Xb.nnz) < valued_frac
+    Xb.data[m] = rng.standard_normal(int(m.sum()))
+for label, X in (("all-binary", Xb if valued_frac == 0 else None),
+                 ("mixed", sparse.hstack(
+                     [Xb, sparse.csr_matrix(rng.standard_normal((n, n_cont)))]
+                 ).tocsr() if n_cont else Xb)):
+    if X is None:
+        continue
+    t0 = time.time()
+    X.sort_indices()
+    d = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
+                              storage='tiled')
+    nn, P = d.shape
+    v, w = rng.standard_normal(P), rng.standard_normal(nn)
+    ref_v = v[0] + X @ v[1:] - np.asarray(X.mean(axis=0)).ravel() @ v[1:]
+    err = np.abs(d.dot(v) - ref_v).max() / np.abs(ref_v).max()
+    d.set_timing(True, every=1)
+    d.reset_timing()
+    for _ in range(reps):
+        d.dot(v)
+        d.Tdot(w)
+    t = d.get_timing()
+    db, tb = d.timed_bytes
+    print("%-10s nnz=%d hybrid=%s built in %.1fs: dot %.4f ms (%.0f GB/s), "
+          "tdot %.4f ms (%.0f GB/s), rel err %.1e"
+          % (label, X.nnz, d.hybrid_info, time.time() - t0,
+             t['dot'][1] / t['dot'][0], db / (t['dot'][1] / t['dot'][0]) / 1e6,
+             t['tdot'][1] / t['tdot'][0],
+             tb / (t['tdot'][1] / t['tdot'][0]) / 1e6, err))
+    d.close() if hasattr(d, 'close') else None
+    del d

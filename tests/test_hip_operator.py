@@ -242,6 +242,111 @@ def test_random_shapes_and_patterns(case):
         assert np.abs(hip.Tdot(w) - ref_w).max() <= tol_w, (storage, n, p)
 
 
+@pytest.mark.parametrize("case", range(24))
+def test_random_mixed_designs_split_by_value(case):
+    """The randomised cases again as MIXED designs -- most entries 1.0, some
+    columns with Gaussian values, up to three fully dense continuous columns
+    (tests/helper.py:13 builds simulate_design(..., binary_frac=.9)): the
+    tiled format stores them split by value (value-free part + dense block +
+    valued rest, spmv_tiled.hip HybridParts); products against SciPy, the two
+    storages against each other."""
+    from bayesbridge_amd import HipSparseDesignMatrix
+    from bayesbridge_amd.design_matrix import remove_intercept_indicator
+    from helpers import random_sparse_case
+    X, _, rng = random_sparse_case(case)
+    X = X.tocsr().astype(np.float64)
+    X.sum_duplicates()
+    n, p = X.shape
+    X.data[:] = 1.
+    valued_cols = rng.random(p) < .15
+    mask = valued_cols[X.indices]
+    X.data[mask] = rng.standard_normal(int(mask.sum()))
+    n_dense = int(case % 4) if n >= 130 else 0
+    if n_dense:
+        dense = sparse.csr_matrix(rng.standard_normal((n, n_dense)))
+        X = sparse.hstack([X, dense]).tocsr()
+    X.sort_indices()
+    center, intercept = bool(case & 4), bool(case & 8)
+    Xr = remove_intercept_indicator(X.copy())
+    if Xr.shape[1] == 0:
+        pytest.skip("all columns constant")
+    outs = {}
+    for storage in STORAGES:
+        hip = HipSparseDesignMatrix(X.copy(), center_predictor=center,
+                                    add_intercept=intercept, storage=storage)
+        nn, P = hip.shape
+        if storage == 'tiled':
+            info = hip.hybrid_info
+            ones = int((Xr.data == 1.).sum())
+            if n_dense and ones >= .3 * Xr.nnz:
+                assert info is not None and info['dense_cols'] >= 1, info
+            if info is not None:
+                assert info['ones_nnz'] == ones
+                assert info['ones_nnz'] + info['rest_nnz'] + \
+                    info['dense_nnz'] == Xr.nnz
+        rs = np.random.default_rng(case)
+        v, w = rs.standard_normal(P), rs.standard_normal(nn)
+        off = np.asarray(Xr.mean(axis=0)).ravel() if center \
+            else np.zeros(Xr.shape[1])
+        a = 1 if intercept else 0
+        ref_v = (v[0] if intercept else 0.) + Xr @ v[a:] - off @ v[a:]
+        ref_w = Xr.T @ w - w.sum() * off
+        if intercept:
+            ref_w = np.concatenate(([w.sum()], ref_w))
+        tol_v = 1e-11 * max(1., np.abs(ref_v).max())
+        tol_w = 1e-11 * max(1., np.abs(ref_w).max())
+        outs[storage] = (hip.dot(v), hip.Tdot(w))
+        assert np.abs(outs[storage][0] - ref_v).max() <= tol_v, (storage, n, p)
+        assert np.abs(outs[storage][1] - ref_w).max() <= tol_w, (storage, n, p)
+
+
+def test_mixed_design_of_the_reference_helper_is_stored_split():
+    """tests/helper.py:13 -- simulate_design(n, p, binary_frac=.9): 10 % of the
+    columns are dense Gaussian.  Split by value the products agree with the
+    reference layout's, a CG draw with the oracle's, and a device chain on it
+    runs (the golden chain_logit_mixed_initcoef test covers exact parity)."""
+    from bayesbridge_amd import HipCGSampler, HipSparseDesignMatrix
+    from helpers import cg_inputs, mixed_design
+    import oracle
+    X = mixed_design(20000, 600, binary_frac=.9, seed=5)
+    hip = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
+                                storage='tiled')
+    info = hip.hybrid_info
+    assert info is not None and info['dense_cols'] == 60, info
+    assert info['rest_nnz'] == 0
+    csr = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
+                                storage='csr')
+    assert csr.hybrid_info is None
+    n, P = hip.shape
+    rng = np.random.default_rng(2)
+    v, w = rng.standard_normal(P), rng.standard_normal(n)
+    assert np.abs(hip.dot(v) - csr.dot(v)).max() <= 1e-11 * np.abs(csr.dot(v)).max()
+    assert np.abs(hip.Tdot(w) - csr.Tdot(w)).max() <= 1e-11 * np.abs(csr.Tdot(w)).max()
+    inp = cg_inputs(n, P, seed=4, lam_log_sd=.3)
+    ora = oracle.OracleSparseDesign(X, center_predictor=True, add_intercept=True)
+    atol = 10e-6 * np.sqrt(P)
+    c_o, i_o = oracle.cg_sample(
+        ora, inp['obs_prec'], inp['prior_prec_sqrt'], inp['z'],
+        inp['coef_cg_init'], inp['coef_scaled_sd'], inp['n_unshrunk'],
+        inp['randn_n'], inp['randn_P'], 500, atol)
+
+    class _Replay:
+        def __init__(self, vecs): self.vecs = list(vecs)
+        def __call__(self, size): return self.vecs.pop(0)
+    orig = np.random.randn
+    np.random.randn = _Replay([inp['randn_n'], inp['randn_P']])
+    try:
+        c_h, i_h = HipCGSampler(inp['n_unshrunk']).sample(
+            hip, inp['obs_prec'], inp['prior_prec_sqrt'], inp['z'],
+            coef_cg_init=inp['coef_cg_init'], precond_by='prior',
+            coef_scaled_sd=inp['coef_scaled_sd'], maxiter=500, atol=atol)
+    finally:
+        np.random.randn = orig
+    assert i_h['converged'] and abs(i_h['n_iter'] - i_o['n_iter']) <= 2
+    tol = 1e-6 if i_h['n_iter'] == i_o['n_iter'] else 1e-5
+    assert np.abs(c_h - c_o).max() <= tol * max(1., np.abs(c_o).max())
+
+
 @pytest.mark.parametrize("shape", [(9000, 20000, .004), (700, 40000, .003),
                                    (20000, 1000, .02)])
 def test_kernel_equals_cpu_emulator_bitwise(shape):
