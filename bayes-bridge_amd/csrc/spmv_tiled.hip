@@ -97,6 +97,8 @@ struct TiledPair {
   TiledMatrix x, xt;
 };
 
+constexpr int HYB_TDOT_CHUNKS = 256;  // row chunks of the dense block's D^T w
+
 // Mixed designs: X = B + D + S.
 //
 // OHDSI-style designs are binary covariates plus a few continuous ones, and the
@@ -123,7 +125,7 @@ struct HybridParts {
   DevMem D;              // double[kd][n], column-major
   DevMem addend;         // double[n]
   DevMem v_dense;        // double[kd]
-  DevMem d_part;         // double[NPART][kd]: partial sums of D^T w
+  DevMem d_part;         // double[HYB_TDOT_CHUNKS][kd]: partial sums of D^T w
   DevMem slab;           // double[(G_B + G_S + 1)][p]
   int n_slab = 0;
 };
@@ -789,7 +791,8 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
 __global__ __launch_bounds__(256) void tiled_dot_finalize_kernel(
     int64_t R, int G, const double* __restrict__ slab,
     const double* __restrict__ c_part, const double* x0_ptr,
-    const double* __restrict__ rowscale, double* __restrict__ out) {
+    const double* __restrict__ rowscale, double* __restrict__ out,
+    const double* __restrict__ addend) {
   double c = x0_ptr ? *x0_ptr : 0.;
   if (c_part) {
     double cs = 0.;
@@ -801,6 +804,7 @@ __global__ __launch_bounds__(256) void tiled_dot_finalize_kernel(
     double a = 0.;
     for (int g = 0; g < G; ++g) a += slab[(int64_t)g * R + r];
     double v = c + a;
+    if (addend) v += addend[r];
     if (rowscale) v *= rowscale[r];
     out[r] = v;
   }
@@ -1007,13 +1011,6 @@ static int build_hybrid(bbx_design* h) {
   if (rest_nnz > 0)
     BBX_TRY(build_one(hp->rest.x, n, p, rest_nnz, rest.rowptr.data(),
                       rest.colidx.data(), rest.vals.data(), false, 1));
-  // the direct epilogue of the value-free kernel carries the other parts:
-  // it exists for one column group and <= NPART panels only
-  if (hp->ones.x.G != 1 || hp->ones.x.n_panel > NPART) {
-    delete hp;
-    h->hybrid = nullptr;
-    return 1;
-  }
   if (hp->kd > 0) {
     // D column-major: D[slot][i] = the non-one entry of row i in that column
     std::vector<int32_t> slot_of((size_t)p, -1);
@@ -1030,7 +1027,7 @@ static int build_hybrid(bbx_design* h) {
     BBX_TRY(upload(hp->dense_cols, dense_cols.data(),
                    dense_cols.size() * sizeof(int32_t)));
     BBX_TRY(hp->v_dense.alloc(sizeof(double) * (size_t)hp->kd));
-    BBX_TRY(hp->d_part.alloc(sizeof(double) * NPART * (size_t)hp->kd));
+    BBX_TRY(hp->d_part.alloc(sizeof(double) * HYB_TDOT_CHUNKS * (size_t)hp->kd));
   }
   {  // transposed orientation of B and S
     HostCsr ct;
@@ -1229,37 +1226,38 @@ __global__ __launch_bounds__(256) void hyb_addend_kernel(
   }
 }
 
-// part[b][j] = sum over block b's rows of D[j][i] w[i]; four columns per round
+// part[c][j] = sum over row chunk c of D[j][i] w[i]: one WAVE per (column,
+// chunk), contiguous 16-byte lane loads, no workgroup synchronisation
 __global__ __launch_bounds__(256) void hyb_dense_tdot_kernel(
-    int64_t n, int kd, const double* __restrict__ D,
+    int64_t n, int kd, int n_chunk, const double* __restrict__ D,
     const double* __restrict__ w, double* __restrict__ part,
     const int* __restrict__ skip_flag) {
   if (skip_flag && *skip_flag) return;
-  __shared__ double s_w[4][256 / WAVE];
-  const int64_t rows = (n + gridDim.x - 1) / gridDim.x;
-  const int64_t r0 = (int64_t)blockIdx.x * rows;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t task = (int64_t)blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+  if (task >= (int64_t)kd * n_chunk) return;
+  const int j = (int)(task / n_chunk), c = (int)(task - (int64_t)j * n_chunk);
+  int64_t rows = (n + n_chunk - 1) / n_chunk;
+  rows = (rows + 1) / 2 * 2;  // even: chunks start 16-byte aligned
+  const int64_t r0 = (int64_t)c * rows;
   const int64_t r1 = (r0 + rows < n) ? r0 + rows : n;
-  for (int j0 = 0; j0 < kd; j0 += 4) {
-    double a[4] = {0., 0., 0., 0.};
-    for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
-      const double wi = w[i];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (j0 + u < kd) a[u] += D[(int64_t)(j0 + u) * n + i] * wi;
+  const double* __restrict__ Dj = D + (int64_t)j * n;
+  double a0 = 0., a1 = 0.;
+  int64_t i = r0 + 2 * lane;
+  const bool aligned = (n & 1) == 0;  // column starts stay 16-byte aligned
+  if (aligned) {
+    for (; i + 1 < r1; i += 2 * WAVE) {
+      const v2d d = *reinterpret_cast<const v2d*>(Dj + i);
+      const v2d ww = *reinterpret_cast<const v2d*>(w + i);
+      a0 += d.x * ww.x;
+      a1 += d.y * ww.y;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double t = wave_allsum(a[u]);
-      if ((threadIdx.x & (WAVE - 1)) == 0) s_w[u][threadIdx.x / WAVE] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x < 4 && j0 + (int)threadIdx.x < kd) {
-      double t = 0.;
-      for (int k = 0; k < 256 / WAVE; ++k) t += s_w[threadIdx.x][k];
-      part[(int64_t)blockIdx.x * kd + j0 + threadIdx.x] = t;
-    }
-    __syncthreads();
+    if (i < r1) a0 += Dj[i] * w[i];
+  } else {
+    for (i = r0 + lane; i < r1; i += WAVE) a0 += Dj[i] * w[i];
   }
+  const double t = wave_allsum(a0 + a1);
+  if (lane == 0) part[(int64_t)c * kd + j] = t;
 }
 
 // slab_row[dense_cols[j]] = sum_b part[b][j], blocks in order
@@ -1303,7 +1301,18 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
                      hp->kd, hp->D.as<double>(), hp->v_dense.as<double>(),
                      rest_slab, G_rest, hp->addend.as<double>(), h->skip_flag);
   BBX_HIP(hipGetLastError());
-  const TiledMatrix& mb = hp->ones.x;  // G == 1, n_panel <= NPART (build_hybrid)
+  const TiledMatrix& mb = hp->ones.x;
+  if (mb.G > 1 || mb.n_panel > NPART) {
+    // several column groups: slabs, then the finalize kernel adds the addend
+    BBX_TRY(launch_tiled(h, mb, x, nullptr, nullptr, nullptr, nullptr,
+                         mb.slab.as<double>(), nullptr));
+    hipLaunchKernelGGL(tiled_dot_finalize_kernel, dim3(1024), dim3(256), 0,
+                       h->stream, mb.R, mb.G, mb.slab.as<double>(),
+                       part_slot(h, PS_C), x0, d_rowscale, d_t,
+                       hp->addend.as<double>());
+    BBX_HIP(hipGetLastError());
+    return timer_end(h, 0);
+  }
   double* fused = nullptr;
   int twt_off = 0;
   if (d_sum_part) {
@@ -1337,11 +1346,14 @@ static int launch_tdot_hybrid(bbx_design* h, const double* d_w,
     at += ms.G;
   }
   if (hp->kd > 0) {
-    hipLaunchKernelGGL(hyb_dense_tdot_kernel, dim3(NPART), dim3(256), 0,
-                       h->stream, h->n, hp->kd, hp->D.as<double>(), d_w,
-                       hp->d_part.as<double>(), h->skip_flag);
-    hipLaunchKernelGGL(hyb_dense_scatter_kernel, dim3((hp->kd + 255) / 256),
-                       dim3(256), 0, h->stream, hp->kd, NPART,
+    const int64_t n_task = (int64_t)hp->kd * HYB_TDOT_CHUNKS;
+    hipLaunchKernelGGL(hyb_dense_tdot_kernel,
+                       dim3((unsigned)((n_task + 3) / 4)), dim3(256), 0,
+                       h->stream, h->n, hp->kd, HYB_TDOT_CHUNKS,
+                       hp->D.as<double>(), d_w, hp->d_part.as<double>(),
+                       h->skip_flag);
+    hipLaunchKernelGGL(hyb_dense_scatter_kernel, dim3((hp->kd + 63) / 64),
+                       dim3(64), 0, h->stream, hp->kd, HYB_TDOT_CHUNKS,
                        hp->dense_cols.as<int32_t>(), hp->d_part.as<double>(),
                        slab + (size_t)at * (size_t)h->p, h->skip_flag);
     BBX_HIP(hipGetLastError());
@@ -1390,7 +1402,7 @@ int launch_dot_tiled(bbx_design* h, const double* d_v,
                        m.slab.as<double>(), nullptr));
   hipLaunchKernelGGL(tiled_dot_finalize_kernel, dim3(1024), dim3(256), 0,
                      h->stream, m.R, m.G, m.slab.as<double>(),
-                     part_slot(h, PS_C), x0, d_rowscale, d_t);
+                     part_slot(h, PS_C), x0, d_rowscale, d_t, nullptr);
   BBX_HIP(hipGetLastError());
   BBX_TRY(timer_end(h, 0));
   return BBX_OK;

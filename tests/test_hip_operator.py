@@ -312,7 +312,7 @@ def test_mixed_design_of_the_reference_helper_is_stored_split():
     hip = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
                                 storage='tiled')
     info = hip.hybrid_info
-    assert info is not None and info['dense_cols'] == 60, info
+    assert info is not None and 55 <= info['dense_cols'] <= 60, info
     assert info['rest_nnz'] == 0
     csr = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
                                 storage='csr')
