@@ -268,4 +268,10 @@ def test_config2_full_size_exact_seed_chain(golden_dir):
     ora = OracleGibbs(outcome, X, 'logit', **kw).gibbs(
         10, seed=111, init={'global_scale': .01})
     assert np.allclose(s['coef'], ora['coef'], atol=1e-5)
-    assert np.abs(n_cg - ora['n_cg_iter']).max() <= 2
+    # (the oracle's own stopping iterations move with the host: on the GPU
+    # box's CPU it stops up to 2 iterations away from where it stops in the
+    # build container, i.e. from the fixture -- ||r|| grazes atol, DESIGN.md
+    # "Tolerances"; the HIP chain is held to +-2 of the fixture above and to
+    # that plus the oracle's own drift here)
+    drift = np.abs(ora['n_cg_iter'] - g['n_cg_iter']).max()
+    assert np.abs(n_cg - ora['n_cg_iter']).max() <= 2 + drift
