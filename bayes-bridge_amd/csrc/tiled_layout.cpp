@@ -398,6 +398,15 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
           densest_rows = rows_cb;
         }
       }
+      // Balance: a slice of T-entry chunks takes T / 4 steps on ONE wave while
+      // the whole tile is densest_entries / 512 wave-steps for 16 waves; a
+      // chunk longer than the tile's fair share per wave is its critical path.
+      if (!t_env && opt.chains > 1) {
+        int t_bal = (int)(4 * ((densest_entries + 512 * TILE_WAVES - 1) /
+                               (512 * TILE_WAVES)));
+        if (t_bal < 8) t_bal = 8;
+        if (t_bal < t_min) t_min = t_bal;
+      }
       const int64_t want_rows = 2 * TILE_WAVES * SLICE_ROWS;
       if (densest_rows < (3 * TILE_WAVES * SLICE_ROWS) / 2 && !t_env) {
         int t_par = (int)((densest_entries + want_rows - 1) / want_rows);
@@ -614,7 +623,8 @@ static double shape_cost(int64_t R, int64_t nnz, int n_block, int pr, int g,
 }
 
 static void choose_shape(int64_t R, int64_t C, int64_t nnz, int n_block, int W,
-                         int K, int* PR_out, int* G_out, double* cost_out) {
+                         int K, bool heavy_rows, int* PR_out, int* G_out,
+                         double* cost_out) {
   double best = 1e300;
   int best_pr = 128, best_g = 1;
   const int lds_rows = lds_budget_per_chain(K) - (W + 8);
@@ -623,7 +633,16 @@ static void choose_shape(int64_t R, int64_t C, int64_t nnz, int n_block, int W,
   // the main kernel in 46.9 / 49.7 us against 48.5 us, with twice the slab
   // traffic for the epilogue kernel -- profiles/r02_ab_geometry.txt)
   int pr_cap = TILE_PR_MAX / K < 4096 ? TILE_PR_MAX / K : 4096;
-  if (lds_rows - 256 < pr_cap) pr_cap = lds_rows - 256;  // room for extras
+  // Room for the extra accumulators of split rows.  Batched layouts (K > 1)
+  // have small tiles -- a handful of steps per wave -- where ONE long slice is
+  // the tile's critical path: their rows must be cut short, which takes
+  // accumulators.  Measured on the 1M x 50k design, X^T, K = 2: 312 extras ->
+  // split threshold 53, busiest wave 128 batches against 57.6 ideal (X^T W
+  // 76 us); ~1400 extras -> threshold 9-21, busiest wave 70.
+  // (only where the row lengths are heavy-tailed: balanced rows -- X itself
+  // -- are not split and would only lose slice width)
+  int reserve = (K > 1 && heavy_rows) ? std::max(256, lds_rows / 3) : 256;
+  if (lds_rows - reserve < pr_cap) pr_cap = lds_rows - reserve;
   if (pr_cap < 128) pr_cap = 128;
   for (int pr = 128; pr <= pr_cap; pr += 128) {
     for (int g = 1; g <= n_block; ++g) {
@@ -667,13 +686,19 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
     if (opt.force_blocks > m.n_block) m.n_block = opt.force_blocks;
     if (m.n_block < 1) m.n_block = 1;
     m.W = width_for(m.n_block);
-    choose_shape(R, C, nnz, m.n_block, m.W, K, &m.PR, &m.G, nullptr);
+    choose_shape(R, C, nnz, m.n_block, m.W, K, false, &m.PR, &m.G, nullptr);
   } else {
     // K slices and K accumulator sets share the LDS: the slice width is part
     // of the search (a wide slice means few tile switches but short panels,
     // i.e. more workgroups than CUs).  Candidates: every block count from the
     // widest slice that leaves room for 128 rows + 256 extras down to slices
     // a quarter as wide.
+    // heavy-tailed row lengths (the columns of simulate_data.py designs as
+    // rows of X^T): longest row > 6x the mean, the test build_panel applies
+    int64_t longest = 0;
+    for (int64_t r = 0; r < R; ++r)
+      longest = std::max<int64_t>(longest, rowptr[r + 1] - rowptr[r]);
+    const bool heavy_rows = R > 0 && (double)longest > 6. * (double)nnz / (double)R;
     const int w_cap = (lds_budget_per_chain(K) - 8 - 128 - 256) / 64 * 64;
     int nb_min = (int)((C + w_cap - 1) / w_cap);
     if (nb_min < 1) nb_min = 1;
@@ -685,7 +710,7 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
       if (nb > nb_min && w == width_for(nb - 1)) continue;
       int pr, g;
       double cost;
-      choose_shape(R, C, nnz, nb, w, K, &pr, &g, &cost);
+      choose_shape(R, C, nnz, nb, w, K, heavy_rows, &pr, &g, &cost);
       if (cost < best) {
         best = cost;
         m.n_block = nb;
@@ -1048,12 +1073,15 @@ extern "C" {
 int bbx_layout_emulate(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
                        const int32_t* colidx, const double* vals,
                        int bank_aware, int force_PR, int force_G,
-                       int max_threads, int chains, const double* x, double* out,
+                       int force_blocks, int max_threads, int chains,
+                       const double* x, double* out,
                        int64_t* info, double* gather_cycles) {
   bbx::TiledOptions opt;
   opt.bank_aware = bank_aware != 0;
   opt.force_PR = force_PR;
   opt.force_G = force_G;
+  opt.force_blocks = force_blocks;
+  opt.stats = getenv("BBX_TILED_STATS") != nullptr;
   opt.chains = chains > 0 ? chains : 1;
   if (max_threads > 0) opt.max_threads = max_threads;
   bbx::TiledHost m;

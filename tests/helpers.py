@@ -108,11 +108,11 @@ class TiledLayoutCpu:
                  '../libbbx_layout.so'], stdout=subprocess.DEVNULL)
         self.lib = ctypes.CDLL(path)
         self.lib.bbx_layout_emulate.argtypes = (
-            [c_int64] * 3 + [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 2
+            [c_int64] * 3 + [c_void_p] * 3 + [c_int] * 6 + [c_void_p] * 2
             + [POINTER(c_int64), POINTER(c_double)])
 
     def matvec(self, A, x, bank_aware=True, force_PR=0,
-               force_G=0, threads=4, chains=1):
+               force_G=0, threads=4, chains=1, force_blocks=0):
         """(A x, info dict) through the layout + emulator; A is R x C CSR
         with ascending column indices inside each row."""
         import ctypes
@@ -131,8 +131,8 @@ class TiledLayoutCpu:
         st = self.lib.bbx_layout_emulate(
             R, C, A.nnz, indptr.ctypes.data, indices.ctypes.data,
             None if data is None else data.ctypes.data,
-            int(bank_aware), int(force_PR), int(force_G), int(threads),
-            int(chains),
+            int(bank_aware), int(force_PR), int(force_G), int(force_blocks),
+            int(threads), int(chains),
             x.ctypes.data, out.ctypes.data, info, ctypes.byref(cyc))
         if st != 0:
             raise RuntimeError("tiled layout could not be built")
