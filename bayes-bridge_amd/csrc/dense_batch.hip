@@ -41,12 +41,14 @@ namespace bbx {
 
 typedef double dk_d4 __attribute__((ext_vector_type(4)));
 
-// Stage geometry, measured at 200k x 8k, K = 16 (profiles/r03_dense_batch.txt):
-//   X V   : 64 rows x 4 waves 3.51 ms, 32 rows x 8 waves 2.09 ms, 16 x 16 4.14
-//   X^T W : 64 rows x 4 waves 2.08 ms, 32 rows x 8 waves 2.95 ms, 16 x 16 5.36
-// (128 KB of LDS per CU either way, two stages per wave)
+// Stage geometry, measured at 200k x 8k, K = 16 (profiles/r03_dense_batch.txt;
+// 128 KB of LDS per CU either way, two stages per wave):
+//   X V   : 64 rows x 4 waves 1.57 ms, 32 rows x 8 waves 1.72 ms
+//   X^T W : 64 rows x 4 waves 1.37 ms, 32 rows x 8 waves 2.29 ms
+// (before the stage's A fragments were all read up front and the operand loads
+// lost their conditions the same shapes took 3.5 / 2.1 and 2.1 / 2.9 ms)
 #ifndef DK_DOT_ROWS
-#define DK_DOT_ROWS 32
+#define DK_DOT_ROWS 64
 #endif
 #ifndef DK_TDOT_ROWS
 #define DK_TDOT_ROWS 64
@@ -151,16 +153,25 @@ __device__ __forceinline__ void dk_dot_group(int K,
     }
     const float4* st4 =
         reinterpret_cast<const float4*>(my_stage + slot * DkDot::stage_bytes);
+    // all A fragments of the stage first (one exposed LDS round trip per
+    // stage instead of one per 16-column step: with one or two waves per SIMD
+    // nothing else hides it), then the MFMAs back to back
+    float4 xa[4][NT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int rt = 0; rt < NT; ++rt)
+        xa[c][rt] = st4[(16 * rt + i) * 16 + ((4 * c + k) ^ i)];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       double a[NT][4];
 #pragma unroll
       for (int rt = 0; rt < NT; ++rt) {
-        const float4 x = st4[(16 * rt + i) * 16 + ((4 * c + k) ^ i)];
-        a[rt][0] = (double)x.x;
-        a[rt][1] = (double)x.y;
-        a[rt][2] = (double)x.z;
-        a[rt][3] = (double)x.w;
+        a[rt][0] = (double)xa[c][rt].x;
+        a[rt][1] = (double)xa[c][rt].y;
+        a[rt][2] = (double)xa[c][rt].z;
+        a[rt][3] = (double)xa[c][rt].w;
       }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -300,20 +311,27 @@ __global__ __launch_bounds__(DkTdot::waves * WAVE) void dense_tdot_k_kernel(
     }
     const float* st1 =
         reinterpret_cast<const float*>(my_stage + slot * DkTdot::stage_bytes);
-    // A[i][k] of (row group r, column tile ct) = X[4 r + k][16 ct + i]
+    // A[i][k] of (row group r, column tile ct) = X[4 r + k][16 ct + i]; the
+    // whole stage's fragments first, then the MFMAs back to back
+    float xa[DkTdot::rows / 4][4];
 #pragma unroll
     for (int r = 0; r < DkTdot::rows / 4; ++r) {
       const int row = 4 * r + k;
-      double a[4];
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
-        a[ct] = (double)st1[(row * 16 + ((4 * ct + (i >> 2)) ^ (row & 15))) * 4 +
-                            (i & 3)];
+        xa[r][ct] = st1[(row * 16 + ((4 * ct + (i >> 2)) ^ (row & 15))) * 4 +
+                        (i & 3)];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-        if (DK_ABLATE == 2) D[ct][0] += a[ct] * bc[r];
+    for (int r = 0; r < DkTdot::rows / 4; ++r) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        if (DK_ABLATE == 2) D[ct][0] += (double)xa[r][ct] * bc[r];
         else
-        D[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ct], bc[r], D[ct], 0, 0, 0);
+        D[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xa[r][ct], bc[r],
+                                                     D[ct], 0, 0, 0);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
