@@ -226,8 +226,10 @@ class BayesBridge():
         """How many of `n_chain` chains one batch can hold on this model's
         design (0: batching does not apply): sparse tiled designs 2 or 4 (2
         with stored values; pairs are what pays), dense f32
-        designs 2, 4, 8 or 16.  Batches keep 'coef', 'global_scale', 'logp'
-        and use the device RNG."""
+        designs 4, 8 or 16 (the batched dense products cost three single-chain
+        operator applications whatever the width: two chains run faster one
+        after the other).  Batches keep 'coef', 'global_scale', 'logp' and use
+        the device RNG."""
         design = self.model.design
         if options is not None and not isinstance(options, SamplerOptions):
             options = SamplerOptions.pick_default_and_create(
@@ -244,7 +246,7 @@ class BayesBridge():
         else:
             if design.storage_dtype != 'float32':
                 return 0
-            widths = (16, 8, 4, 2)
+            widths = (16, 8, 4)
         for w in widths:
             if w <= n_chain:
                 return w
