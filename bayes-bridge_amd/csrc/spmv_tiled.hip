@@ -1260,18 +1260,18 @@ __global__ __launch_bounds__(256) void hyb_dense_tdot_kernel(
   if (lane == 0) part[(int64_t)c * kd + j] = t;
 }
 
-// slab_row[dense_cols[j]] = sum_b part[b][j], blocks in order
-__global__ void hyb_dense_scatter_kernel(int kd, int n_block,
-                                         const int32_t* __restrict__ dense_cols,
-                                         const double* __restrict__ part,
-                                         double* __restrict__ slab_row,
-                                         const int* __restrict__ skip_flag) {
+// slab_row[dense_cols[j]] = sum_c part[c][j]: one wave per dense column, lanes
+// over the chunks, fixed order (a serial sum of 256 dependent loads took 33 us)
+__global__ __launch_bounds__(WAVE) void hyb_dense_scatter_kernel(
+    int kd, int n_chunk, const int32_t* __restrict__ dense_cols,
+    const double* __restrict__ part, double* __restrict__ slab_row,
+    const int* __restrict__ skip_flag) {
   if (skip_flag && *skip_flag) return;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= kd) return;
-  double t = 0.;
-  for (int b = 0; b < n_block; ++b) t += part[(int64_t)b * kd + j];
-  slab_row[dense_cols[j]] = t;
+  const int j = blockIdx.x;
+  double a = 0.;
+  for (int c = threadIdx.x; c < n_chunk; c += WAVE) a += part[(int64_t)c * kd + j];
+  a = wave_allsum(a);
+  if (threadIdx.x == 0) slab_row[dense_cols[j]] = a;
 }
 
 static int launch_dot_hybrid(bbx_design* h, const double* d_v,
@@ -1352,8 +1352,8 @@ static int launch_tdot_hybrid(bbx_design* h, const double* d_w,
                        h->stream, h->n, hp->kd, HYB_TDOT_CHUNKS,
                        hp->D.as<double>(), d_w, hp->d_part.as<double>(),
                        h->skip_flag);
-    hipLaunchKernelGGL(hyb_dense_scatter_kernel, dim3((hp->kd + 63) / 64),
-                       dim3(64), 0, h->stream, hp->kd, HYB_TDOT_CHUNKS,
+    hipLaunchKernelGGL(hyb_dense_scatter_kernel, dim3((unsigned)hp->kd),
+                       dim3(WAVE), 0, h->stream, hp->kd, HYB_TDOT_CHUNKS,
                        hp->dense_cols.as<int32_t>(), hp->d_part.as<double>(),
                        slab + (size_t)at * (size_t)h->p, h->skip_flag);
     BBX_HIP(hipGetLastError());

@@ -293,8 +293,10 @@ def committed_traffic(design, which, cfg):
     n, P = design.shape
     rows = n if which == "dot" else P - 1
     n_wg = -(-rows // info["PR"]) * info["G"]
-    for tag in ("r02", "r01"):
-        path = os.path.join(ROOT, "profiles", "%s_spmv_profile.json" % tag)
+    for name in ("r03_spmv_traffic.json", "r02_spmv_profile.json",
+                 "r01_spmv_profile.json"):
+        tag = name.split("_")[0]
+        path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
         with open(path) as fh:
@@ -302,9 +304,8 @@ def committed_traffic(design, which, cfg):
         entry = prof.get("hbm_traffic", {}).get("grid=%d" % n_wg)
         if entry:
             return int(entry["total_bytes"]), \
-                "profiles/%s_spmv_profile.json (separate rocprofv3 --pmc " \
-                "passes of the same kernel and matrix; not collected in " \
-                "this run)" % tag
+                "profiles/%s (separate rocprofv3 --pmc passes of the same " \
+                "kernel and matrix; not collected in this run)" % name
     return None, None
 
 
