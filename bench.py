@@ -132,10 +132,12 @@ def cpu_baselines(prob, state, n_iters, seed):
          prob["indptr"].cpu().numpy()), shape=(n, p))
     n_success = prob["n_success"].cpu().numpy()
     coef0, obs0, ls0, g0, mean, square, n_avg = state
-    from oracle.omp_baseline import usable_cores
+    from oracle.omp_baseline import cpu_quota, usable_cores
     from oracle.rng import ParallelOracleRandom
     host_cores = os.cpu_count()
-    omp_cores = usable_cores()      # the affinity mask, every core of it
+    # every core this container can keep busy: the affinity mask capped by the
+    # cgroup's CPU quota (threads beyond it are throttled, not run)
+    omp_cores = usable_cores()
 
     def run(kind, cores, **kw):
         chain = OracleGibbs((n_success, np.ones(n)), X, 'logit',
@@ -164,6 +166,7 @@ def cpu_baselines(prob, state, n_iters, seed):
             extra = dict(
                 dot_gbs=round(db * reps / (t1 - t0) / 1e9, 1),
                 tdot_gbs=round(tb * reps / (t2 - t1) / 1e9, 1),
+                cpu_quota=cpu_quota(),
                 product_format="value-free int32 CSR of X and of X^T, each "
                                "thread's rows first-touched by that thread")
         summ = CoefSummarizer(chain.P, chain.nu, chain.slab)
@@ -588,9 +591,14 @@ def main():
             "roofline": roofline,
         }
         if state is not None and widths:
-            line["multi_chain"] = multi_chain_block(
-                design, make_chain, state, widths, args.multi_chain_steps, 5,
-                line["value"], dense)
+            # (an extra block beside the headline: it must never cost the line)
+            try:
+                line["multi_chain"] = multi_chain_block(
+                    design, make_chain, state, widths, args.multi_chain_steps,
+                    5, line["value"], dense)
+            except Exception as exc:     # noqa: BLE001
+                line["multi_chain"] = {"error": "%s: %s" % (type(exc).__name__,
+                                                            exc)}
         if state is not None and args.cpu_baseline_iters > 0 and not dense:
             port, omp = cpu_baselines(prob, state, args.cpu_baseline_iters,
                                       args.seed)
