@@ -107,7 +107,8 @@ constexpr int BATCH_MAX = 16;  // (sparse designs: 4; dense f32 designs: 16)
 // columns (and the rows of padding the kernels' last stages read) stay zero,
 // so the operand loads of the product kernels carry no condition.
 constexpr int DENSE_BATCH_STRIDE = 16;
-constexpr int DENSE_BATCH_ROW_PAD = 64;
+constexpr int DENSE_BATCH_ROW_PAD = 320;  // zero rows past P / n of the 16-column operands
+constexpr int DENSE_PAD_ROWS = 256;       // zero rows past n of the stored dense matrix
 struct ChainPtrs {
   const double* p[BATCH_MAX];
 };
@@ -197,6 +198,8 @@ struct bbx_design {
   bbx::DevMem dense_slab;  // Tdot partial sums [dense_chunks][dense_ld]
   bbx::DevMem dense_fused_slab;  // fused operator: [workgroups][dense_ld]
   bbx::DevMem dense_batch_slab;  // batched Tdot: [row chunks][dense_ld][K]
+  bbx::DevMem dense_xt;          // batched dot: X^T, row-major [dense_ld + pad][dense_xt_ld] f32
+  int64_t dense_xt_ld = 0;
   int dense_fused_wgs = 0;
   int64_t dense_ld = 0;
   int dense_chunks = 1;

@@ -738,7 +738,13 @@ static int create_dense_common(int64_t n, int64_t p, const void* X,
     BBX_TRY(design_alloc_work(h));
     const size_t el_out = storage_dtype == BBX_F32 ? 4 : 8;
     const size_t el_in = in_dtype == BBX_F32 ? 4 : 8;
-    BBX_TRY(h->dense.alloc(el_out * (size_t)n * (size_t)h->dense_ld));
+    // DENSE_PAD_ROWS zero rows behind the matrix: the batched products' register
+    // rings read ahead of the rows and columns they use (dense_batch.hip)
+    BBX_TRY(h->dense.alloc(el_out * (size_t)(n + DENSE_PAD_ROWS) *
+                           (size_t)h->dense_ld));
+    BBX_HIP(hipMemset(static_cast<char*>(h->dense.ptr) +
+                          el_out * (size_t)n * (size_t)h->dense_ld,
+                      0, el_out * (size_t)DENSE_PAD_ROWS * (size_t)h->dense_ld));
     BBX_TRY(h->dense_slab.alloc(sizeof(double) * (size_t)h->dense_chunks *
                                 (size_t)h->dense_ld));
     // zeros for the epilogue's offset (length P) and sum(w) partials

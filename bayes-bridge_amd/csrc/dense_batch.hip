@@ -347,6 +347,355 @@ __global__ __launch_bounds__(DkTdot::waves * WAVE) void dense_tdot_k_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Direct forms: the matrix goes from HBM straight into the A-operand registers.
+//
+// The LDS stages above keep ONE stage in flight per wave while the previous one
+// feeds the matrix cores (a second would need 256 KB), and every stage pays an
+// LDS round trip before its first MFMA: 1.57 / 1.37 ms per product where the
+// HBM pass is 0.9-1.0 ms and the MFMAs 0.66 ms.  A wave's registers (512 per
+// lane at one wave per SIMD) hold three times what its LDS share does, and one
+// orientation needs no staging at all:
+//
+//   G = M^T B for a row-major M: lane (i, k) loads 16 bytes M[r + k][c0 + 4 i
+//   .. + 3].  A wave's load is 4 rows x 256 contiguous bytes (the DMA's shape)
+//   and already IS the A operand of four MFMAs -- MFMA e takes element e of
+//   every lane, i.e. the column set {c0 + 4 i + e}; which columns share a tile
+//   is bookkeeping at the store.  B[k][chain] = one 512-byte load per four
+//   rows, used by all 16 MFMAs of the wave's 256 columns.
+//
+// X^T W is that product with M = X.  X V contracts along X's CONTIGUOUS
+// direction: its A operand would be 16 rows x 64 bytes per load, and at 13 row
+// tiles per wave every 128-byte line is fetched twice, a slot apart (2.3 ms per
+// pass, the same with the MFMAs removed; scripts/probes/row_frag_stream.hip
+// shows the shape streaming well only while few lines are open).  So a batch
+// keeps a TRANSPOSED copy of the matrix (dense_xt: P x n, built on first use,
+// 6.4 GB at 200k x 8k -- the batch's working set is then 13 of the 288 GB) and
+// computes X V = (X^T)^T V with the same sweep: both products read 4-row x
+// 256-byte pieces.
+//
+// The sweep keeps a ring of D slots in registers (a slot = 4 rows: four A loads
+// and one B load, 16 MFMAs), issued through inline asm and retired with counted
+// waits (the idiom of spmv_tiled.hip): D - 1 slots -- 44 KB per wave -- are in
+// flight while one is consumed.  Reads may run past a wave's rows or the end of
+// the matrix (the allocations are padded with zero rows); what they fetch meets
+// a zero B operand or a column that is never stored.
+#ifndef DK_DIRECT
+#define DK_DIRECT 1
+#endif
+#ifndef DKT_D
+#define DKT_D 12     // ring depth (slots of 4 rows)
+#endif
+
+typedef float dk_f4 __attribute__((ext_vector_type(4)));
+
+template <int IMM>
+__device__ __forceinline__ void dk_ld_x4(dk_f4& dst, unsigned voff,
+                                         const void* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt"
+               : "=v"(dst)
+               : "v"(voff), "s"(sbase), "n"(IMM)
+               : "memory");
+}
+__device__ __forceinline__ void dk_ld_d(double& dst, unsigned voff,
+                                        const void* sbase) {
+  asm volatile("global_load_dwordx2 %0, %1, %2"
+               : "=v"(dst)
+               : "v"(voff), "s"(sbase)
+               : "memory");
+}
+
+// The MFMA of the direct kernels: f32 -> f64 conversion of the A operand, the
+// wait states between a VALU result and the matrix core's read of it, and the
+// MFMA with its accumulator pinned to the accumulation half of the register
+// file, as ONE asm statement.
+//  * Through the builtin the compiler carries the accumulators across the loop
+//    boundary in architectural VGPRs -- which the asm loads' ring already
+//    fills -- and copies every one of them in and out once per period
+//    (v_accvgpr_write/read x 8 per tile, each waiting for its MFMA; seen in
+//    the .s).
+//  * An MFMA written in asm is invisible to the compiler's hazard recogniser:
+//    with the conversion left outside, `v_cvt_f64_f32 v[a:b], ..` directly in
+//    front of `v_mfma .., v[a:b], ..` read the register's OLD contents (there
+//    is no interlock; every column but one of the first version was wrong).
+//    The s_nop below is that spacing; it also covers a B operand produced by
+//    the VALU just before the statement.  The rest holds by construction: an
+//    accumulator is touched again only after >= 3 other MFMAs (the statements
+//    are volatile and keep their source order), and the epilogue's reads are
+//    preceded by explicit s_nops.
+//  The ~12 cycles of issue per statement sit in the shadow of the previous
+//  MFMA's 64.
+__device__ __forceinline__ void dk_mfma(dk_d4& acc, float x, double b) {
+  double t;
+  asm volatile(
+      "v_cvt_f64_f32 %1, %2\n\ts_nop 3\n\t"
+      "v_mfma_f64_16x16x4_f64 %0, %1, %3, %0"
+      : "+a"(acc), "=&v"(t)
+      : "v"(x), "v"(b));
+}
+
+constexpr int DKD_WAVES = 4;        // one per SIMD: 512 registers per lane
+constexpr int DKD_C = 4;            // 64-column units a sweep carries
+constexpr int DKD_IMG = DKD_WAVES * DKD_C * 16 * WAVE * 8;  // 128 KB of LDS
+
+// One wave's sweep: acc[c][e] += sum over rows [r_begin, r_begin + 4 n_slot) of
+// M[r][col0 + 64 c + 4 i' + e] * B[r][chain], i' the MFMA's row index.
+// m_rows = rows of M that exist including its padding (addresses are clamped
+// for waves without work only; the ring's read-ahead relies on the padding).
+template <int C, int D>
+__device__ __forceinline__ void dkd_sweep(const float* __restrict__ M,
+                                          int64_t ldm, int64_t col0,
+                                          int64_t r_begin, int n_slot,
+                                          const double* __restrict__ Bop,
+                                          int lane, dk_d4 (&acc)[DKD_C][4]) {
+  static_assert(C >= 1 && C <= DKD_C, "units per sweep");
+  constexpr int LPS = C + 1;
+  constexpr int WAITC = (D - 1) * LPS;
+  static_assert(WAITC < 64, "vmcnt is a 6-bit field");
+  const int i = lane & 15, k = lane >> 4;
+  const int n_period = (n_slot + D - 1) / D;
+  const unsigned voff_a = (unsigned)(((int64_t)k * ldm + 4 * i) * 4);
+  const unsigned voff_b = (unsigned)((k * DK_KS + i) * 8);
+  // (a wave without rows primes its ring on the first rows and computes nothing)
+  const int64_t r_ring = n_slot > 0 ? r_begin : 0;
+  const float* sa = M + r_ring * ldm + col0;     // wave-uniform, 4 rows per slot
+  const double* sb = Bop + r_ring * DK_KS;
+  dk_f4 xa[D][C];
+  double bw[D];
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing of the compiler's in the queue
+#define DKD_ISSUE(KK)                                                         \
+  do {                                                                        \
+    dk_ld_x4<0>(xa[KK][0], voff_a, sa);                                       \
+    if (C > 1) dk_ld_x4<256>(xa[KK][C > 1 ? 1 : 0], voff_a, sa);              \
+    if (C > 2) dk_ld_x4<512>(xa[KK][C > 2 ? 2 : 0], voff_a, sa);              \
+    if (C > 3) dk_ld_x4<768>(xa[KK][C > 3 ? 3 : 0], voff_a, sa);              \
+    dk_ld_d(bw[KK], voff_b, sb);                                              \
+    sa += 4 * ldm;                                                            \
+    sb += 4 * DK_KS;                                                          \
+  } while (0)
+#define DKD_TIE(KK)                                                           \
+  do {                                                                        \
+    _Pragma("unroll") for (int c = 0; c < C; ++c)                             \
+        asm volatile("" : "+v"(xa[KK][c]));                                   \
+    asm volatile("" : "+v"(bw[KK]));                                          \
+  } while (0)
+#pragma unroll
+  for (int kk = 0; kk < D; ++kk) DKD_ISSUE(kk);
+  for (int p = 0; p < n_period; ++p) {
+#pragma unroll
+    for (int kk = 0; kk < D; ++kk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITC) : "memory");
+      DKD_TIE(kk);
+      // a slot past this wave's rows belongs to the next wave (or is
+      // padding): it meets a zero B operand, no branch between the MFMAs
+      const double b_ = (p * D + kk < n_slot) ? bw[kk] : 0.;
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (DK_ABLATE == 2) acc[c][e][0] += (double)xa[kk][c][e] * b_;
+          else dk_mfma(acc[c][e], xa[kk][c][e], b_);
+        }
+      DKD_ISSUE(kk);
+    }
+  }
+  // the D slots issued past the end: landed before their registers are free
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int kk = 0; kk < D; ++kk) DKD_TIE(kk);
+#undef DKD_ISSUE
+#undef DKD_TIE
+  // 18 wait states between the last MFMA and a read of its result
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][0]));
+#pragma unroll
+  for (int c = 0; c < DKD_C; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e > 0) asm volatile("" : "+a"(acc[c][e]));
+}
+
+// The four waves' accumulators through LDS, added in the fixed order
+// (w0 + w1) + (w2 + w3); wave c' returns sub-block c' in g[e][reg]:
+// g[e][reg] = G[col0 + 64 c' + 4 ((lane >> 4) + 4 reg) + e][chain lane & 15].
+__device__ __forceinline__ void dkd_fold(const dk_d4 (&acc)[DKD_C][4],
+                                         double* img, int wave, int lane,
+                                         double (&g)[4][4]) {
+#pragma unroll
+  for (int c = 0; c < DKD_C; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        img[((((wave * DKD_C + c) * 4 + e) * 4 + reg) << 6) + lane] = acc[c][e][reg];
+  __syncthreads();
+  constexpr int WS = DKD_C * 16 * WAVE;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int o = (((wave * 4 + e) * 4 + reg) << 6) + lane;
+      g[e][reg] = (img[o] + img[WS + o]) + (img[2 * WS + o] + img[3 * WS + o]);
+    }
+}
+
+// X^T W: a workgroup = (block of 256 columns, one of DK_TDOT_CHUNKS row chunks);
+// its four waves take quarters of the chunk's rows.  blockIdx.x % 8 = the
+// chunk: under round-robin placement the workgroups of an XCD share a row
+// chunk, and its slice of W streams through that XCD's L2 once.
+__global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_tdot_kd_kernel(
+    int K, int64_t n, int64_t ld, int64_t rows_per_wave,
+    const float* __restrict__ X, const double* __restrict__ w,
+    double* __restrict__ slab, const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dk_smem[];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+  const int chunk = (int)(blockIdx.x % DK_TDOT_CHUNKS);
+  const int colblk = (int)(blockIdx.x / DK_TDOT_CHUNKS);
+  const int64_t col0 = (int64_t)colblk * (64 * DKD_C);
+  const int64_t r_begin =
+      ((int64_t)chunk * DKD_WAVES + wave) * rows_per_wave;  // multiple of 4
+  int64_t r_end = r_begin + rows_per_wave;
+  if (r_end > n) r_end = n;
+  const int n_slot = r_end > r_begin ? (int)((r_end - r_begin + 3) / 4) : 0;
+  dk_d4 acc[DKD_C][4];
+#pragma unroll
+  for (int c = 0; c < DKD_C; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[c][e] = dk_d4{0., 0., 0., 0.};
+  dkd_sweep<DKD_C, DKT_D>(X, ld, col0, r_begin, n_slot, w, lane, acc);
+  double g[4][4];
+  dkd_fold(acc, reinterpret_cast<double*>(dk_smem), wave, lane, g);
+  const int i = lane & 15, k = lane >> 4;
+  if (i < K) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t col = col0 + 64 * wave + 4 * (k + 4 * reg) + e;
+        if (col < ld) slab[((int64_t)chunk * ld + col) * DK_KS + i] = g[e][reg];
+      }
+  }
+}
+
+// X V through the transposed copy: T = (X^T)^T V, XT row-major [P + pad][ldn].
+// 256 persistent workgroups; workgroup b owns the 64-row units [u0, u1) of T
+// (12 or 13 of them at 200 000 rows) and sweeps all P rows of XT once per four
+// units, its waves taking quarters of P; the tail of fewer than four units is
+// a narrower sweep.  Epilogue per unit: rowscale, the store, <t, Omega t>.
+template <int C>
+__device__ __forceinline__ void dkd_dot_units(
+    int K, int64_t n, int64_t P, int64_t ldn, const float* __restrict__ XT,
+    const double* __restrict__ v, const ChainPtrs& rowscale, const ChainOut& out,
+    int out_stride, int64_t unit0, double* img, int wave, int lane, double& twt) {
+  const int64_t rows_per_wave = ((P + DKD_WAVES - 1) / DKD_WAVES + 3) / 4 * 4;
+  const int64_t r_begin = (int64_t)wave * rows_per_wave;
+  int64_t r_end = r_begin + rows_per_wave;
+  if (r_end > P) r_end = P;
+  const int n_slot = r_end > r_begin ? (int)((r_end - r_begin + 3) / 4) : 0;
+  dk_d4 acc[DKD_C][4];
+#pragma unroll
+  for (int c = 0; c < DKD_C; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[c][e] = dk_d4{0., 0., 0., 0.};
+  dkd_sweep<C, DKT_D>(XT, ldn, unit0 * 64, r_begin, n_slot, v, lane, acc);
+  double g[4][4];
+  dkd_fold(acc, img, wave, lane, g);
+  const int i = lane & 15, k = lane >> 4;
+  if (wave < C && i < K) {
+    const double* rs = rowscale.p[i];
+    double* o = out.p[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int64_t row = (unit0 + wave) * 64 + 4 * (k + 4 * reg) + e;
+        if (row < n) {
+          const double t = g[e][reg];
+          double w = t;
+          if (rs) w *= rs[row];
+          o[row * out_stride] = w;
+          twt = fma(w, t, twt);
+        }
+      }
+  }
+  __syncthreads();   // the image is reused by the next sweep
+}
+
+__global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_dot_kd_kernel(
+    int K, int64_t n, int64_t P, int64_t ldn, const float* __restrict__ XT,
+    const double* __restrict__ v, ChainPtrs rowscale, ChainOut out,
+    int out_stride, double* __restrict__ twt_part,
+    const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dk_smem[];
+  __shared__ double s_twt[DKD_WAVES][16];
+  double* img = reinterpret_cast<double*>(dk_smem);
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+  const int64_t n_unit = ldn / 64;
+  const int64_t base = n_unit / gridDim.x, extra = n_unit % gridDim.x;
+  const int64_t b = blockIdx.x;
+  int64_t u = b * base + (b < extra ? b : extra);
+  const int64_t u1 = u + base + (b < extra ? 1 : 0);
+  double twt = 0.;  // this lane's part of <t_c, Omega_c t_c>, c = lane & 15
+  for (; u + 4 <= u1; u += 4)
+    dkd_dot_units<4>(K, n, P, ldn, XT, v, rowscale, out, out_stride, u, img, wave, lane, twt);
+  if (u1 - u == 3)
+    dkd_dot_units<3>(K, n, P, ldn, XT, v, rowscale, out, out_stride, u, img, wave, lane, twt);
+  else if (u1 - u == 2)
+    dkd_dot_units<2>(K, n, P, ldn, XT, v, rowscale, out, out_stride, u, img, wave, lane, twt);
+  else if (u1 - u == 1)
+    dkd_dot_units<1>(K, n, P, ldn, XT, v, rowscale, out, out_stride, u, img, wave, lane, twt);
+  if (twt_part) {
+    // lanes i, i + 16, i + 32, i + 48 hold chain i's parts: fixed order
+    double a = twt + __shfl_xor(twt, 16);
+    a = a + __shfl_xor(a, 32);
+    if (lane < 16) s_twt[wave][lane] = a;
+    __syncthreads();
+    if (tid < K) {
+      double tot = 0.;
+      for (int wv = 0; wv < DKD_WAVES; ++wv) tot += s_twt[wv][tid];
+      twt_part[tid * NPART + blockIdx.x] = tot;
+    }
+  }
+}
+
+// XT[c][r] = X[r][c] for c < ld (rows of XT past P: X's zero padding columns;
+// past ld and columns past n: zero)
+__global__ __launch_bounds__(256) void dense_transpose_kernel(
+    int64_t n, int64_t ld, int64_t ldn, int64_t xt_rows,
+    const float* __restrict__ X, float* __restrict__ XT) {
+  __shared__ float tile[64][65];
+  const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int j = ty; j < 64; j += 4) {
+    const int64_t r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < n && c < ld) ? X[r * ld + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 64; j += 4) {
+    const int64_t c = c0 + j, r = r0 + tx;
+    if (c < xt_rows && r < ldn) XT[c * ldn + r] = tile[tx][j];
+  }
+}
+
+static int ensure_dense_transpose(bbx_design* h) {
+  if (h->dense_xt.ptr) return BBX_OK;
+  const int64_t ldn = (h->n + 63) / 64 * 64;
+  const int64_t rows = (h->dense_ld + 63) / 64 * 64 + DENSE_PAD_ROWS;
+  BBX_TRY(h->dense_xt.alloc(sizeof(float) * (size_t)rows * (size_t)ldn));
+  BBX_HIP(hipMemsetAsync(h->dense_xt.ptr, 0,
+                         sizeof(float) * (size_t)rows * (size_t)ldn, h->stream));
+  const dim3 grid((unsigned)(ldn / 64), (unsigned)((h->dense_ld + 63) / 64));
+  hipLaunchKernelGGL(dense_transpose_kernel, grid, dim3(256), 0, h->stream,
+                     h->n, h->dense_ld, ldn, rows, h->dense.as<float>(),
+                     h->dense_xt.as<float>());
+  BBX_HIP(hipGetLastError());
+  h->dense_xt_ld = ldn;
+  return BBX_OK;
+}
+
 bool dense_batch_applies(const bbx_design* h) {
   return !h->sparse && h->dense_dtype == BBX_F32 && h->dense_ld % 8 == 0;
 }
@@ -358,6 +707,12 @@ static int dk_set_attr() {
   BBX_HIP(hipFuncSetAttribute(
       reinterpret_cast<const void*>(&dense_tdot_k_kernel),
       hipFuncAttributeMaxDynamicSharedMemorySize, DkTdot::lds_bytes));
+  BBX_HIP(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&dense_tdot_kd_kernel),
+      hipFuncAttributeMaxDynamicSharedMemorySize, DKD_IMG));
+  BBX_HIP(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&dense_dot_kd_kernel),
+      hipFuncAttributeMaxDynamicSharedMemorySize, DKD_IMG));
   return BBX_OK;
 }
 
@@ -366,13 +721,22 @@ int launch_dot_dense_k(bbx_design* h, int K, const double* d_v,
   if (!dense_batch_applies(h))
     return fail(BBX_ERR_STATE, "batched dense products need f32 storage");
   BBX_TRY(dk_set_attr());
+  if (DK_DIRECT) BBX_TRY(ensure_dense_transpose(h));
   h->n_dot += 1;
   BBX_TRY(timer_begin(h, 0));
-  hipLaunchKernelGGL(dense_dot_k_kernel, dim3(DK_DOT_WGS),
-                     dim3(DkDot::waves * WAVE), DkDot::lds_bytes, h->stream, K,
-                     h->n, h->P, h->dense_ld, h->dense.as<float>(), d_v,
-                     ba.rowscale, ba.out, ba.out_stride, d_twt_part,
-                     h->skip_flag);
+  if (DK_DIRECT) {
+    hipLaunchKernelGGL(dense_dot_kd_kernel, dim3(DK_DOT_WGS),
+                       dim3(DKD_WAVES * WAVE), DKD_IMG, h->stream, K, h->n,
+                       h->P, h->dense_xt_ld, h->dense_xt.as<float>(), d_v,
+                       ba.rowscale, ba.out, ba.out_stride, d_twt_part,
+                       h->skip_flag);
+  } else {
+    hipLaunchKernelGGL(dense_dot_k_kernel, dim3(DK_DOT_WGS),
+                       dim3(DkDot::waves * WAVE), DkDot::lds_bytes, h->stream, K,
+                       h->n, h->P, h->dense_ld, h->dense.as<float>(), d_v,
+                       ba.rowscale, ba.out, ba.out_stride, d_twt_part,
+                       h->skip_flag);
+  }
   BBX_HIP(hipGetLastError());
   return timer_end(h, 0);
 }
@@ -389,19 +753,30 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
     // columns past the batch's chains are never written: keep them zero
     BBX_HIP(hipMemsetAsync(h->dense_batch_slab.ptr, 0, need, h->stream));
   }
-  const int n_colblk = (int)((h->dense_ld + DK_COLS - 1) / DK_COLS);
-  const int64_t rows_per_chunk =
-      ((h->n + DK_TDOT_CHUNKS - 1) / DK_TDOT_CHUNKS + DkTdot::rows - 1) /
-      DkTdot::rows * DkTdot::rows;
-  const int n_wave = n_colblk * DK_TDOT_CHUNKS;
-  const unsigned grid = (unsigned)((n_wave + DkTdot::waves - 1) / DkTdot::waves);
   h->n_tdot += 1;
   BBX_TRY(timer_begin(h, 1));
-  hipLaunchKernelGGL(dense_tdot_k_kernel, dim3(grid),
-                     dim3(DkTdot::waves * WAVE), DkTdot::lds_bytes, h->stream,
-                     K, h->n, h->dense_ld, rows_per_chunk, n_colblk,
-                     h->dense.as<float>(), d_w,
-                     h->dense_batch_slab.as<double>(), h->skip_flag);
+  if (DK_DIRECT) {
+    const int n_colblk = (int)((h->dense_ld + 64 * DKD_C - 1) / (64 * DKD_C));
+    const int64_t parts = (int64_t)DK_TDOT_CHUNKS * DKD_WAVES;
+    const int64_t rows_per_wave = ((h->n + parts - 1) / parts + 3) / 4 * 4;
+    hipLaunchKernelGGL(dense_tdot_kd_kernel,
+                       dim3((unsigned)(n_colblk * DK_TDOT_CHUNKS)),
+                       dim3(DKD_WAVES * WAVE), DKD_IMG, h->stream, K, h->n,
+                       h->dense_ld, rows_per_wave, h->dense.as<float>(), d_w,
+                       h->dense_batch_slab.as<double>(), h->skip_flag);
+  } else {
+    const int n_colblk = (int)((h->dense_ld + DK_COLS - 1) / DK_COLS);
+    const int64_t rows_per_chunk =
+        ((h->n + DK_TDOT_CHUNKS - 1) / DK_TDOT_CHUNKS + DkTdot::rows - 1) /
+        DkTdot::rows * DkTdot::rows;
+    const int n_wave = n_colblk * DK_TDOT_CHUNKS;
+    const unsigned grid = (unsigned)((n_wave + DkTdot::waves - 1) / DkTdot::waves);
+    hipLaunchKernelGGL(dense_tdot_k_kernel, dim3(grid),
+                       dim3(DkTdot::waves * WAVE), DkTdot::lds_bytes, h->stream,
+                       K, h->n, h->dense_ld, rows_per_chunk, n_colblk,
+                       h->dense.as<float>(), d_w,
+                       h->dense_batch_slab.as<double>(), h->skip_flag);
+  }
   BBX_HIP(hipGetLastError());
   BBX_TRY(timer_end(h, 1));
   *slab = h->dense_batch_slab.as<double>();

@@ -181,14 +181,16 @@ def _dense_problem(n, p, seed=2):
 
 
 @pytest.mark.parametrize("K", [2, 4, 8, 16])
-@pytest.mark.parametrize("shape", [(5000, 700), (20000, 4500), (4097, 8190)])
+@pytest.mark.parametrize("shape", [(5000, 700), (20000, 4500), (4097, 8190),
+                                   (200003, 37), (140000, 21), (263000, 12)])
 def test_dense_batched_products_on_the_matrix_cores(K, shape):
     """K-column dense products (dense_batch.hip: v_mfma_f64_16x16x4_f64, the
     chains in the 16 columns of the B operand) against NumPy in f64 on the
     stored f32 entries: <= 1e-11 of the result's scale (the reference's own
     bound against the explicit matrix is 1e-5, test_design_matrix.py:12-24),
     and a column never sees its neighbours (permuted inputs give the permuted
-    outputs bit for bit)."""
+    outputs bit for bit).  The tall shapes make a wave of X V carry 13, 9 and
+    (two sweeps) 9 row tiles -- the kernel is instantiated per tile count."""
     from bayesbridge_amd import HipChainBatch
     n, p = shape
     X, y, hip = _dense_problem(n, p)
