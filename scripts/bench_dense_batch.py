@@ -46,4 +46,16 @@ for name, nbytes in (("dot", db), ("tdot", tb)):
           % (K, name, ms / cnt, cnt, nbytes / (ms / cnt) / 1e6,
              nbytes / (ms / cnt) / 1e6 / 8000,
              2. * n * (p + 8) * 16 / (ms / cnt) / 1e9))
+# the same kernels inside the chains' CG loop (interleaved operands and results,
+# row scale and <t, Omega t> in the epilogue): two Gibbs iterations of the batch
+design.reset_timing()
+design.set_timing(True, every=4)
+samples, _ = batch.run(2, save_coef=False)
+t = design.get_timing()
+n_cg = samples['n_cg_iter'].max(axis=0).sum()
+for name, nbytes in (("dot", db), ("tdot", tb)):
+    cnt, ms = t[name]
+    print("K=%d %-4s in the CG loop: avg %.3f ms over %d sampled launches "
+          "(%.3f of 8 TB/s); %d lock-step CG iterations"
+          % (K, name, ms / cnt, cnt, nbytes / (ms / cnt) / 1e6 / 8000, n_cg))
 # single-chain reference on the same box: the one-pass operator
