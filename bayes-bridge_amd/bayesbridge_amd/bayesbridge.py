@@ -226,9 +226,10 @@ class BayesBridge():
         """How many of `n_chain` chains one batch can hold on this model's
         design (0: batching does not apply): sparse tiled designs 2 or 4 (2
         with stored values; pairs are what pays), dense f32
-        designs 4, 8 or 16 (the batched dense products cost three single-chain
-        operator applications whatever the width: two chains run faster one
-        after the other).  Batches keep 'coef', 'global_scale', 'logp' and use
+        designs 4, 8, 16 or 32 (the batched dense products read the matrix twice
+        per operator application whatever the width -- 2.3 single-chain
+        applications, 2.9 at 32 chains: two chains run faster one after the
+        other).  Batches keep 'coef', 'global_scale', 'logp' and use
         the device RNG."""
         design = self.model.design
         if options is not None and not isinstance(options, SamplerOptions):
@@ -246,7 +247,7 @@ class BayesBridge():
         else:
             if design.storage_dtype != 'float32':
                 return 0
-            widths = (16, 8, 4)
+            widths = (32, 16, 8, 4)
         for w in widths:
             if w <= n_chain:
                 return w

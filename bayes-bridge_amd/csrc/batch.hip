@@ -43,7 +43,7 @@ struct BatchState {
 struct bbx_batch {
   bbx_design* h = nullptr;
   int K = 0;   // chains
-  int KS = 0;  // interleave stride of the batch's vectors: K (sparse), 16 (dense)
+  int KS = 0;  // interleave stride of the batch's vectors: K (sparse), 16 or 32 (dense)
   bbx_chain* chain[bbx::BATCH_MAX] = {};
   bbx::DevMem s, d, x, r, p, sp;  // (P + 2) * KS doubles, interleaved [j][c]
   bbx::DevMem t, w;               // n * KS doubles (dense: zero-padded rows too)
@@ -638,8 +638,9 @@ int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,
   if (!out) return fail(BBX_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (!design || !chains) return fail(BBX_ERR_INVALID, "NULL argument");
-  if (n_chain != 2 && n_chain != 4 && n_chain != 8 && n_chain != 16)
-    return fail(BBX_ERR_INVALID, "a batch holds 2, 4, 8 or 16 chains");
+  if (n_chain != 2 && n_chain != 4 && n_chain != 8 && n_chain != 16 &&
+      n_chain != 32)
+    return fail(BBX_ERR_INVALID, "a batch holds 2, 4, 8, 16 or 32 chains");
   if (design->sparse && n_chain > 4)
     return fail(BBX_ERR_INVALID, "sparse designs batch 2 or 4 chains");
   for (int c = 0; c < n_chain; ++c) {
@@ -670,7 +671,7 @@ int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,
   b->h = h;
   b->K = n_chain;
   for (int c = 0; c < n_chain; ++c) b->chain[c] = chains[c];
-  b->KS = h->sparse ? n_chain : DENSE_BATCH_STRIDE;
+  b->KS = h->sparse ? n_chain : dense_batch_stride(n_chain);
   const size_t K = (size_t)n_chain, KS = (size_t)b->KS;
   // dense: the product kernels read whole 64-row / 64-column stages of their
   // 16-column operands; rows past P / n and columns past the chains stay zero

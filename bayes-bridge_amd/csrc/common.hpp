@@ -101,7 +101,7 @@ int no_throw(F&& f) noexcept {
 
 // Chains that may share one pass over a sparse design (batched chains); the
 // per-chain device pointers the batched kernels take by value.
-constexpr int BATCH_MAX = 16;  // (sparse designs: 4; dense f32 designs: 16)
+constexpr int BATCH_MAX = 32;  // (sparse designs: 4; dense f32 designs: 32)
 // Dense batches interleave their vectors with a FIXED stride of 16 -- the 16
 // columns of the MFMA's B operand -- whatever the number of chains; unused
 // columns (and the rows of padding the kernels' last stages read) stay zero,
@@ -366,6 +366,7 @@ int tiled_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
 // [G][ld][16] of X^T w_c.  d_v is [ld + 64][16] and d_w [n + 64][16], zero
 // outside the chains' columns and past P / n rows (DENSE_BATCH_STRIDE).
 bool dense_batch_applies(const bbx_design* h);
+int dense_batch_stride(int K);  // 16, or 32 for more than 16 chains
 int launch_dot_dense_k(bbx_design* h, int K, const double* d_v,
                        const TiledBatchArgs& ba, double* d_twt_part);
 int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,

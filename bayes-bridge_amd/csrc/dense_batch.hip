@@ -26,7 +26,8 @@
 namespace bbx {
 
 typedef double dk_d4 __attribute__((ext_vector_type(4)));
-constexpr int DK_KS = DENSE_BATCH_STRIDE;   // interleave stride: the 16 columns of B
+constexpr int DK_KS = DENSE_BATCH_STRIDE;   // 16: the columns of one B operand; a batch of
+                                            // 32 chains interleaves two of them (stride 32)
 constexpr int DK_DOT_WGS = 256;             // one persistent workgroup per CU
 constexpr int DK_TDOT_CHUNKS = 8;           // row chunks of the transposed product
 
@@ -67,6 +68,9 @@ constexpr int DK_TDOT_CHUNKS = 8;           // row chunks of the transposed prod
 #ifndef DKT_D
 #define DKT_D 12     // ring depth (slots of 4 rows)
 #endif
+#ifndef DKT_D2
+#define DKT_D2 6     // ... with two groups of chains: all 256 accumulation registers are taken
+#endif
 
 typedef float dk_f4 __attribute__((ext_vector_type(4)));
 
@@ -78,11 +82,12 @@ __device__ __forceinline__ void dk_ld_x4(dk_f4& dst, unsigned voff,
                : "v"(voff), "s"(sbase), "n"(IMM)
                : "memory");
 }
+template <int IMM>
 __device__ __forceinline__ void dk_ld_d(double& dst, unsigned voff,
                                         const void* sbase) {
-  asm volatile("global_load_dwordx2 %0, %1, %2"
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3"
                : "=v"(dst)
-               : "v"(voff), "s"(sbase)
+               : "v"(voff), "s"(sbase), "n"(IMM)
                : "memory");
 }
 
@@ -115,6 +120,18 @@ __device__ __forceinline__ void dk_mfma(dk_d4& acc, float x, double b) {
       : "v"(x), "v"(b));
 }
 
+// Two groups of 16 chains: one conversion of the A operand feeds both MFMAs
+__device__ __forceinline__ void dk_mfma2(dk_d4& acc0, dk_d4& acc1, float x,
+                                         double b0, double b1) {
+  double t;
+  asm volatile(
+      "v_cvt_f64_f32 %2, %3\n\ts_nop 3\n\t"
+      "v_mfma_f64_16x16x4_f64 %0, %2, %4, %0\n\t"
+      "v_mfma_f64_16x16x4_f64 %1, %2, %5, %1"
+      : "+a"(acc0), "+a"(acc1), "=&v"(t)
+      : "v"(x), "v"(b0), "v"(b1));
+}
+
 constexpr int DKD_WAVES = 4;        // one per SIMD: 512 registers per lane
 constexpr int DKD_C = 4;            // 64-column units a sweep carries
 constexpr int DKD_IMG = DKD_WAVES * DKD_C * 16 * WAVE * 8;  // 128 KB of LDS
@@ -123,26 +140,28 @@ constexpr int DKD_IMG = DKD_WAVES * DKD_C * 16 * WAVE * 8;  // 128 KB of LDS
 // M[r][col0 + 64 c + 4 i' + e] * B[r][chain], i' the MFMA's row index.
 // m_rows = rows of M that exist including its padding (addresses are clamped
 // for waves without work only; the ring's read-ahead relies on the padding).
-template <int C, int D>
+template <int C, int D, int NG>
 __device__ __forceinline__ void dkd_sweep(const float* __restrict__ M,
                                           int64_t ldm, int64_t col0,
                                           int64_t r_begin, int n_slot,
                                           const double* __restrict__ Bop,
-                                          int lane, dk_d4 (&acc)[DKD_C][4]) {
+                                          int lane, dk_d4 (&acc)[NG][DKD_C][4]) {
   static_assert(C >= 1 && C <= DKD_C, "units per sweep");
-  constexpr int LPS = C + 1;
+  static_assert(NG == 1 || NG == 2, "groups of 16 chains");
+  constexpr int KS = NG * DK_KS;
+  constexpr int LPS = C + NG;
   constexpr int WAITC = (D - 1) * LPS;
   static_assert(WAITC < 64, "vmcnt is a 6-bit field");
   const int i = lane & 15, k = lane >> 4;
   const int n_period = (n_slot + D - 1) / D;
   const unsigned voff_a = (unsigned)(((int64_t)k * ldm + 4 * i) * 4);
-  const unsigned voff_b = (unsigned)((k * DK_KS + i) * 8);
+  const unsigned voff_b = (unsigned)((k * KS + i) * 8);
   // (a wave without rows primes its ring on the first rows and computes nothing)
   const int64_t r_ring = n_slot > 0 ? r_begin : 0;
   const float* sa = M + r_ring * ldm + col0;     // wave-uniform, 4 rows per slot
-  const double* sb = Bop + r_ring * DK_KS;
+  const double* sb = Bop + r_ring * KS;
   dk_f4 xa[D][C];
-  double bw[D];
+  double bw[D][NG];
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing of the compiler's in the queue
 #define DKD_ISSUE(KK)                                                         \
   do {                                                                        \
@@ -150,15 +169,17 @@ __device__ __forceinline__ void dkd_sweep(const float* __restrict__ M,
     if (C > 1) dk_ld_x4<256>(xa[KK][C > 1 ? 1 : 0], voff_a, sa);              \
     if (C > 2) dk_ld_x4<512>(xa[KK][C > 2 ? 2 : 0], voff_a, sa);              \
     if (C > 3) dk_ld_x4<768>(xa[KK][C > 3 ? 3 : 0], voff_a, sa);              \
-    dk_ld_d(bw[KK], voff_b, sb);                                              \
+    dk_ld_d<0>(bw[KK][0], voff_b, sb);                                        \
+    if (NG > 1) dk_ld_d<DK_KS * 8>(bw[KK][NG - 1], voff_b, sb);               \
     sa += 4 * ldm;                                                            \
-    sb += 4 * DK_KS;                                                          \
+    sb += 4 * KS;                                                             \
   } while (0)
 #define DKD_TIE(KK)                                                           \
   do {                                                                        \
     _Pragma("unroll") for (int c = 0; c < C; ++c)                             \
         asm volatile("" : "+v"(xa[KK][c]));                                   \
-    asm volatile("" : "+v"(bw[KK]));                                          \
+    _Pragma("unroll") for (int g = 0; g < NG; ++g)                            \
+        asm volatile("" : "+v"(bw[KK][g]));                                   \
   } while (0)
 #pragma unroll
   for (int kk = 0; kk < D; ++kk) DKD_ISSUE(kk);
@@ -169,13 +190,16 @@ __device__ __forceinline__ void dkd_sweep(const float* __restrict__ M,
       DKD_TIE(kk);
       // a slot past this wave's rows belongs to the next wave (or is
       // padding): it meets a zero B operand, no branch between the MFMAs
-      const double b_ = (p * D + kk < n_slot) ? bw[kk] : 0.;
+      const bool live = p * D + kk < n_slot;
+      const double b0 = live ? bw[kk][0] : 0.;
+      const double b1 = live ? bw[kk][NG - 1] : 0.;
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (DK_ABLATE == 2) acc[c][e][0] += (double)xa[kk][c][e] * b_;
-          else dk_mfma(acc[c][e], xa[kk][c][e], b_);
+          if (DK_ABLATE == 2) acc[0][c][e][0] += (double)xa[kk][c][e] * (b0 + b1);
+          else if (NG == 1) dk_mfma(acc[0][c][e], xa[kk][c][e], b0);
+          else dk_mfma2(acc[0][c][e], acc[NG - 1][c][e], xa[kk][c][e], b0, b1);
         }
       DKD_ISSUE(kk);
     }
@@ -187,12 +211,14 @@ __device__ __forceinline__ void dkd_sweep(const float* __restrict__ M,
 #undef DKD_ISSUE
 #undef DKD_TIE
   // 18 wait states between the last MFMA and a read of its result
-  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][0]));
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][0][0]));
 #pragma unroll
-  for (int c = 0; c < DKD_C; ++c)
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (c + e > 0) asm volatile("" : "+a"(acc[c][e]));
+    for (int c = 0; c < DKD_C; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (g + c + e > 0) asm volatile("" : "+a"(acc[g][c][e]));
 }
 
 // The four waves' accumulators through LDS, added in the fixed order
@@ -217,12 +243,14 @@ __device__ __forceinline__ void dkd_fold(const dk_d4 (&acc)[DKD_C][4],
       const int o = (((wave * 4 + e) * 4 + reg) << 6) + lane;
       g[e][reg] = (img[o] + img[WS + o]) + (img[2 * WS + o] + img[3 * WS + o]);
     }
+  __syncthreads();   // the image is free again (next group of chains, next sweep)
 }
 
 // X^T W: a workgroup = (block of 256 columns, one of DK_TDOT_CHUNKS row chunks);
 // its four waves take quarters of the chunk's rows.  blockIdx.x % 8 = the
 // chunk: under round-robin placement the workgroups of an XCD share a row
 // chunk, and its slice of W streams through that XCD's L2 once.
+template <int NG>
 __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_tdot_kd_kernel(
     int K, int64_t n, int64_t ld, int64_t rows_per_wave,
     const float* __restrict__ X, const double* __restrict__ w,
@@ -239,23 +267,31 @@ __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_tdot_kd_kernel(
   int64_t r_end = r_begin + rows_per_wave;
   if (r_end > n) r_end = n;
   const int n_slot = r_end > r_begin ? (int)((r_end - r_begin + 3) / 4) : 0;
-  dk_d4 acc[DKD_C][4];
+  dk_d4 acc[NG][DKD_C][4];
 #pragma unroll
-  for (int c = 0; c < DKD_C; ++c)
+  for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[c][e] = dk_d4{0., 0., 0., 0.};
-  dkd_sweep<DKD_C, DKT_D>(X, ld, col0, r_begin, n_slot, w, lane, acc);
-  double g[4][4];
-  dkd_fold(acc, reinterpret_cast<double*>(dk_smem), wave, lane, g);
+    for (int c = 0; c < DKD_C; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[gq][c][e] = dk_d4{0., 0., 0., 0.};
+  dkd_sweep<DKD_C, (NG == 1 ? DKT_D : DKT_D2), NG>(X, ld, col0, r_begin, n_slot, w,
+                                                   lane, acc);
   const int i = lane & 15, k = lane >> 4;
-  if (i < K) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+  for (int gq = 0; gq < NG; ++gq) {
+    double g[4][4];
+    dkd_fold(acc[gq], reinterpret_cast<double*>(dk_smem), wave, lane, g);
+    const int chain = 16 * gq + i;
+    if (chain < K) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int64_t col = col0 + 64 * wave + 4 * (k + 4 * reg) + e;
-        if (col < ld) slab[((int64_t)chunk * ld + col) * DK_KS + i] = g[e][reg];
-      }
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int64_t col = col0 + 64 * wave + 4 * (k + 4 * reg) + e;
+          if (col < ld)
+            slab[((int64_t)chunk * ld + col) * (NG * DK_KS) + chain] = g[e][reg];
+        }
+    }
   }
 }
 
@@ -264,45 +300,53 @@ __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_tdot_kd_kernel(
 // (12 or 13 of them at 200 000 rows) and sweeps all P rows of XT once per four
 // units, its waves taking quarters of P; the tail of fewer than four units is
 // a narrower sweep.  Epilogue per unit: rowscale, the store, <t, Omega t>.
-template <int C>
+template <int C, int NG>
 __device__ __forceinline__ void dkd_dot_units(
     int K, int64_t n, int64_t P, int64_t ldn, const float* __restrict__ XT,
     const double* __restrict__ v, const ChainPtrs& rowscale, const ChainOut& out,
-    int out_stride, int64_t unit0, double* img, int wave, int lane, double& twt) {
+    int out_stride, int64_t unit0, double* img, int wave, int lane,
+    double (&twt)[NG]) {
   const int64_t rows_per_wave = ((P + DKD_WAVES - 1) / DKD_WAVES + 3) / 4 * 4;
   const int64_t r_begin = (int64_t)wave * rows_per_wave;
   int64_t r_end = r_begin + rows_per_wave;
   if (r_end > P) r_end = P;
   const int n_slot = r_end > r_begin ? (int)((r_end - r_begin + 3) / 4) : 0;
-  dk_d4 acc[DKD_C][4];
+  dk_d4 acc[NG][DKD_C][4];
 #pragma unroll
-  for (int c = 0; c < DKD_C; ++c)
+  for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[c][e] = dk_d4{0., 0., 0., 0.};
-  dkd_sweep<C, DKT_D>(XT, ldn, unit0 * 64, r_begin, n_slot, v, lane, acc);
-  double g[4][4];
-  dkd_fold(acc, img, wave, lane, g);
+    for (int c = 0; c < DKD_C; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[gq][c][e] = dk_d4{0., 0., 0., 0.};
+  dkd_sweep<C, (NG == 1 ? DKT_D : DKT_D2), NG>(XT, ldn, unit0 * 64, r_begin, n_slot,
+                                               v, lane, acc);
   const int i = lane & 15, k = lane >> 4;
-  if (wave < C && i < K) {
-    const double* rs = rowscale.p[i];
-    double* o = out.p[i];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+  for (int gq = 0; gq < NG; ++gq) {
+    double g[4][4];
+    dkd_fold(acc[gq], img, wave, lane, g);
+    const int chain = 16 * gq + i;
+    if (wave < C && chain < K) {
+      const double* rs = rowscale.p[chain];
+      double* o = out.p[chain];
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int64_t row = (unit0 + wave) * 64 + 4 * (k + 4 * reg) + e;
-        if (row < n) {
-          const double t = g[e][reg];
-          double w = t;
-          if (rs) w *= rs[row];
-          o[row * out_stride] = w;
-          twt = fma(w, t, twt);
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int64_t row = (unit0 + wave) * 64 + 4 * (k + 4 * reg) + e;
+          if (row < n) {
+            const double t = g[e][reg];
+            double w = t;
+            if (rs) w *= rs[row];
+            o[row * out_stride] = w;
+            twt[gq] = fma(w, t, twt[gq]);
+          }
         }
-      }
+    }
   }
-  __syncthreads();   // the image is reused by the next sweep
 }
 
+template <int NG>
 __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_dot_kd_kernel(
     int K, int64_t n, int64_t P, int64_t ldn, const float* __restrict__ XT,
     const double* __restrict__ v, ChainPtrs rowscale, ChainOut out,
@@ -310,7 +354,7 @@ __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_dot_kd_kernel(
     const int* __restrict__ skip_flag) {
   if (skip_flag && *skip_flag) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char dk_smem[];
-  __shared__ double s_twt[DKD_WAVES][16];
+  __shared__ double s_twt[DKD_WAVES][NG * 16];
   double* img = reinterpret_cast<double*>(dk_smem);
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
@@ -319,20 +363,26 @@ __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_dot_kd_kernel(
   const int64_t b = blockIdx.x;
   int64_t u = b * base + (b < extra ? b : extra);
   const int64_t u1 = u + base + (b < extra ? 1 : 0);
-  double twt = 0.;  // this lane's part of <t_c, Omega_c t_c>, c = lane & 15
-  for (; u + 4 <= u1; u += 4)
-    dkd_dot_units<4>(K, n, P, ldn, XT, v, rowscale, out, out_stride, u, img, wave, lane, twt);
-  if (u1 - u == 3)
-    dkd_dot_units<3>(K, n, P, ldn, XT, v, rowscale, out, out_stride, u, img, wave, lane, twt);
-  else if (u1 - u == 2)
-    dkd_dot_units<2>(K, n, P, ldn, XT, v, rowscale, out, out_stride, u, img, wave, lane, twt);
-  else if (u1 - u == 1)
-    dkd_dot_units<1>(K, n, P, ldn, XT, v, rowscale, out, out_stride, u, img, wave, lane, twt);
+  // this lane's parts of <t_c, Omega_c t_c>, c = 16 g + (lane & 15)
+  double twt[NG];
+#pragma unroll
+  for (int gq = 0; gq < NG; ++gq) twt[gq] = 0.;
+#define DKD_UNITS(C)                                                          \
+  dkd_dot_units<C, NG>(K, n, P, ldn, XT, v, rowscale, out, out_stride, u, img, \
+                       wave, lane, twt)
+  for (; u + 4 <= u1; u += 4) DKD_UNITS(4);
+  if (u1 - u == 3) DKD_UNITS(3);
+  else if (u1 - u == 2) DKD_UNITS(2);
+  else if (u1 - u == 1) DKD_UNITS(1);
+#undef DKD_UNITS
   if (twt_part) {
     // lanes i, i + 16, i + 32, i + 48 hold chain i's parts: fixed order
-    double a = twt + __shfl_xor(twt, 16);
-    a = a + __shfl_xor(a, 32);
-    if (lane < 16) s_twt[wave][lane] = a;
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+      double a = twt[gq] + __shfl_xor(twt[gq], 16);
+      a = a + __shfl_xor(a, 32);
+      if (lane < 16) s_twt[wave][16 * gq + lane] = a;
+    }
     __syncthreads();
     if (tid < K) {
       double tot = 0.;
@@ -382,14 +432,16 @@ bool dense_batch_applies(const bbx_design* h) {
 }
 
 static int dk_set_attr() {
-  BBX_HIP(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&dense_tdot_kd_kernel),
-      hipFuncAttributeMaxDynamicSharedMemorySize, DKD_IMG));
-  BBX_HIP(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&dense_dot_kd_kernel),
-      hipFuncAttributeMaxDynamicSharedMemorySize, DKD_IMG));
+  for (const void* f : {reinterpret_cast<const void*>(&dense_tdot_kd_kernel<1>),
+                        reinterpret_cast<const void*>(&dense_tdot_kd_kernel<2>),
+                        reinterpret_cast<const void*>(&dense_dot_kd_kernel<1>),
+                        reinterpret_cast<const void*>(&dense_dot_kd_kernel<2>)})
+    BBX_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                DKD_IMG));
   return BBX_OK;
 }
+
+int dense_batch_stride(int K) { return K > DK_KS ? 2 * DK_KS : DK_KS; }
 
 int launch_dot_dense_k(bbx_design* h, int K, const double* d_v,
                        const TiledBatchArgs& ba, double* d_twt_part) {
@@ -399,10 +451,15 @@ int launch_dot_dense_k(bbx_design* h, int K, const double* d_v,
   BBX_TRY(ensure_dense_transpose(h));
   h->n_dot += 1;
   BBX_TRY(timer_begin(h, 0));
-  hipLaunchKernelGGL(dense_dot_kd_kernel, dim3(DK_DOT_WGS),
-                     dim3(DKD_WAVES * WAVE), DKD_IMG, h->stream, K, h->n, h->P,
-                     h->dense_xt_ld, h->dense_xt.as<float>(), d_v, ba.rowscale,
-                     ba.out, ba.out_stride, d_twt_part, h->skip_flag);
+#define DK_LAUNCH_DOT(NG)                                                     \
+  hipLaunchKernelGGL(dense_dot_kd_kernel<NG>, dim3(DK_DOT_WGS),               \
+                     dim3(DKD_WAVES* WAVE), DKD_IMG, h->stream, K, h->n, h->P, \
+                     h->dense_xt_ld, h->dense_xt.as<float>(), d_v,            \
+                     ba.rowscale, ba.out, ba.out_stride, d_twt_part,          \
+                     h->skip_flag)
+  if (K > DK_KS) DK_LAUNCH_DOT(2);
+  else DK_LAUNCH_DOT(1);
+#undef DK_LAUNCH_DOT
   BBX_HIP(hipGetLastError());
   return timer_end(h, 0);
 }
@@ -413,7 +470,7 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
     return fail(BBX_ERR_STATE, "batched dense products need f32 storage");
   BBX_TRY(dk_set_attr());
   const size_t need = sizeof(double) * (size_t)DK_TDOT_CHUNKS *
-                      (size_t)h->dense_ld * (size_t)DK_KS;
+                      (size_t)h->dense_ld * (size_t)dense_batch_stride(K);
   if (h->dense_batch_slab.bytes < need) {
     BBX_TRY(h->dense_batch_slab.alloc(need));
     // columns past the batch's chains are never written: keep them zero
@@ -424,11 +481,15 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
   const int64_t rows_per_wave = ((h->n + parts - 1) / parts + 3) / 4 * 4;
   h->n_tdot += 1;
   BBX_TRY(timer_begin(h, 1));
-  hipLaunchKernelGGL(dense_tdot_kd_kernel,
-                     dim3((unsigned)(n_colblk * DK_TDOT_CHUNKS)),
-                     dim3(DKD_WAVES * WAVE), DKD_IMG, h->stream, K, h->n,
-                     h->dense_ld, rows_per_wave, h->dense.as<float>(), d_w,
-                     h->dense_batch_slab.as<double>(), h->skip_flag);
+#define DK_LAUNCH_TDOT(NG)                                                    \
+  hipLaunchKernelGGL(dense_tdot_kd_kernel<NG>,                                \
+                     dim3((unsigned)(n_colblk * DK_TDOT_CHUNKS)),             \
+                     dim3(DKD_WAVES* WAVE), DKD_IMG, h->stream, K, h->n,      \
+                     h->dense_ld, rows_per_wave, h->dense.as<float>(), d_w,   \
+                     h->dense_batch_slab.as<double>(), h->skip_flag)
+  if (K > DK_KS) DK_LAUNCH_TDOT(2);
+  else DK_LAUNCH_TDOT(1);
+#undef DK_LAUNCH_TDOT
   BBX_HIP(hipGetLastError());
   BBX_TRY(timer_end(h, 1));
   *slab = h->dense_batch_slab.as<double>();
@@ -441,8 +502,9 @@ int dense_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
   // the matrix (X or its transposed copy) once + the 16-column operands
   // (padding columns are read too) + what the chains' columns write
   const int64_t mat = h->n * h->dense_ld * 4;
-  *dot_bytes = mat + 8 * (int64_t)DK_KS * h->dense_ld + 8 * (int64_t)K * h->n;
-  *tdot_bytes = mat + 8 * (int64_t)DK_KS * h->n +
+  const int64_t ks = dense_batch_stride(K);
+  *dot_bytes = mat + 8 * ks * h->dense_ld + 8 * (int64_t)K * h->n;
+  *tdot_bytes = mat + 8 * ks * h->n +
                 8 * (int64_t)K * DK_TDOT_CHUNKS * h->dense_ld;
   return BBX_OK;
 }

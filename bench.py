@@ -420,7 +420,7 @@ def main():
     state = None
     widths = args.multi_chain
     if widths is None:
-        widths = "4,8,16" if dense else "2,4"
+        widths = "4,8,16,32" if dense else "2,4"
     widths = [int(v) for v in widths.split(",") if int(v) > 1]
     solo = rank == 0 and world == 1 and env_world is None
     if solo and ((args.cpu_baseline_iters > 0 and not dense) or widths):

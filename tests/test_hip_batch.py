@@ -180,7 +180,7 @@ def _dense_problem(n, p, seed=2):
     return X, y, hip
 
 
-@pytest.mark.parametrize("K", [2, 4, 8, 16])
+@pytest.mark.parametrize("K", [2, 4, 8, 16, 32])
 @pytest.mark.parametrize("shape", [(5000, 700), (20000, 4500), (4097, 8190),
                                    (200003, 37), (140000, 21), (263000, 12)])
 def test_dense_batched_products_on_the_matrix_cores(K, shape):
@@ -211,18 +211,23 @@ def test_dense_batched_products_on_the_matrix_cores(K, shape):
     assert np.abs(hip.Tdot(w[0]) - got_w[0]).max() <= 1e-11 * np.abs(ref_w).max()
 
 
-@pytest.mark.parametrize("K", [2, 4, 8])
+@pytest.mark.parametrize("K", [2, 4, 8, 32])
 def test_a_dense_chain_does_not_depend_on_its_batch(K):
-    """The dense counterpart of test_a_chain_does_not_depend_on_its_batch."""
+    """The dense counterpart of test_a_chain_does_not_depend_on_its_batch
+    (32 chains: two B operands per pass; chain A moves from the first to the
+    second group of 16)."""
     from bayesbridge_amd import HipChainBatch
     X, y, hip = _dense_problem(6000, 400)
-    seeds_1 = [17, 23, 31, 47, 3, 5, 7, 11][:K]
-    seeds_2 = [61, 17, 6, 9, 13, 19, 29, 37][:K]    # A = seed 17 moves to slot 1
+    seeds_1 = ([17, 23, 31, 47, 3, 5, 7, 11] + list(range(100, 124)))[:K]
+    seeds_2 = ([61, 17, 6, 9, 13, 19, 29, 37] + list(range(200, 224)))[:K]
+    if K == 32:
+        seeds_2[1], seeds_2[20] = seeds_2[20], 17   # A = seed 17 in slot 20
+    slot = 20 if K == 32 else 1                     # else: A moves to slot 1
     s1, u1 = HipChainBatch(_chains(hip, y, 'linear', seeds_1)).run(5)
     s2, u2 = HipChainBatch(_chains(hip, y, 'linear', seeds_2)).run(5)
     assert u1 == 0 and u2 == 0
     for key in ('coef', 'global_scale', 'logp', 'n_cg_iter'):
-        assert np.array_equal(s1[key][0], s2[key][1]), key
+        assert np.array_equal(s1[key][0], s2[key][slot]), key
     alone = _chains(hip, y, 'linear', [17])[0]
     kept, _ = alone.run(5, save=('coef',))
     scale = max(1., np.abs(kept['coef'][0]).max())
