@@ -182,7 +182,8 @@ def _dense_problem(n, p, seed=2):
 
 @pytest.mark.parametrize("K", [2, 4, 8, 16, 32])
 @pytest.mark.parametrize("shape", [(5000, 700), (20000, 4500), (4097, 8190),
-                                   (200003, 37), (140000, 21), (263000, 12)])
+                                   (200003, 37), (140000, 21), (263000, 12),
+                                   (37, 5), (64, 255)])
 def test_dense_batched_products_on_the_matrix_cores(K, shape):
     """K-column dense products (dense_batch.hip: v_mfma_f64_16x16x4_f64, the
     chains in the 16 columns of the B operand) against NumPy in f64 on the
