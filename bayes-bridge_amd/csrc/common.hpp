@@ -200,6 +200,7 @@ struct bbx_design {
   bbx::DevMem dense_batch_slab;  // batched Tdot: [row chunks][dense_ld][K]
   bbx::DevMem dense_xt;          // batched dot: X^T, row-major [dense_ld + pad][dense_xt_ld] f32
   int64_t dense_xt_ld = 0;
+  bool dense_batch_attr = false;  // LDS size attribute of the batch kernels set on this device
   int dense_fused_wgs = 0;
   int64_t dense_ld = 0;
   int dense_chunks = 1;

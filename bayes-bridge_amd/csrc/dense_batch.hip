@@ -431,13 +431,15 @@ bool dense_batch_applies(const bbx_design* h) {
   return !h->sparse && h->dense_dtype == BBX_F32 && h->dense_ld % 8 == 0;
 }
 
-static int dk_set_attr() {
+static int dk_set_attr(bbx_design* h) {
+  if (h->dense_batch_attr) return BBX_OK;   // per design, i.e. per device
   for (const void* f : {reinterpret_cast<const void*>(&dense_tdot_kd_kernel<1>),
                         reinterpret_cast<const void*>(&dense_tdot_kd_kernel<2>),
                         reinterpret_cast<const void*>(&dense_dot_kd_kernel<1>),
                         reinterpret_cast<const void*>(&dense_dot_kd_kernel<2>)})
     BBX_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 DKD_IMG));
+  h->dense_batch_attr = true;
   return BBX_OK;
 }
 
@@ -447,7 +449,7 @@ int launch_dot_dense_k(bbx_design* h, int K, const double* d_v,
                        const TiledBatchArgs& ba, double* d_twt_part) {
   if (!dense_batch_applies(h))
     return fail(BBX_ERR_STATE, "batched dense products need f32 storage");
-  BBX_TRY(dk_set_attr());
+  BBX_TRY(dk_set_attr(h));
   BBX_TRY(ensure_dense_transpose(h));
   h->n_dot += 1;
   BBX_TRY(timer_begin(h, 0));
@@ -468,7 +470,7 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
                         const double** slab, int* G) {
   if (!dense_batch_applies(h))
     return fail(BBX_ERR_STATE, "batched dense products need f32 storage");
-  BBX_TRY(dk_set_attr());
+  BBX_TRY(dk_set_attr(h));
   const size_t need = sizeof(double) * (size_t)DK_TDOT_CHUNKS *
                       (size_t)h->dense_ld * (size_t)dense_batch_stride(K);
   if (h->dense_batch_slab.bytes < need) {
