@@ -819,6 +819,7 @@ int bbx_design_storage_bytes(const bbx_design* h, int64_t* bytes) {
   b += (int64_t)(h->t_chunk_row.bytes + h->t_chunk_begin.bytes +
                  h->t_row_chunk_ptr.bytes);
   b += (int64_t)h->dense.bytes;
+  b += (int64_t)h->dense_xt.bytes;  // transposed copy, once a batch has run
   b += tiled_storage_bytes(h);
   if (bytes) *bytes = b;
   return BBX_OK;

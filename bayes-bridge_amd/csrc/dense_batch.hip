@@ -1,4 +1,4 @@
-// Dense design, batched chains: the two products of the CG operator for K <= 16
+// Dense design, batched chains: the two products of the CG operator for K <= 32
 // right-hand sides at once, on the matrix cores.
 //
 // A GEMV cannot feed v_mfma_f64_16x16x4_f64 (one right-hand side: 15 of the 16
@@ -6,7 +6,8 @@
 // DESIGN.md 3.3).  K chains that share the pass over X are the shape that can:
 //   T[n x K] = X[n x P] V[P x K]          (dense_matrix.py:42, K at a time)
 //   G[P x K] = X^T[P x n] W[n x K]        (dense_matrix.py:52, K at a time)
-// with the chains in the 16 columns of B / D.  The single-chain path fuses the
+// with the chains in the 16 columns of B / D (32 chains: two B operands per A
+// operand).  The single-chain path fuses the
 // two products into one pass (dense.hip) because its slice of v and of the
 // result fits a thread's registers; for K chains that state is 2 P K doubles
 // per workgroup (512 KB at K = 4: a CU's whole register file), so the batch
@@ -40,7 +41,9 @@ constexpr int DK_TDOT_CHUNKS = 8;           // row chunks of the transposed prod
 // cores, and every stage paid an LDS round trip before its first MFMA: 1.57 /
 // 1.37 ms per product where the HBM pass is 1.0-1.1 ms on these boxes and the
 // MFMAs 0.66 ms.  A wave's registers (512 per lane at one wave per SIMD) hold
-// three times what its LDS share does, and one orientation needs no staging:
+// three times what its LDS share does (an LDS ring in the same place was also
+// tried: scripts/experiments/r03_dense_lds_ring.hip.txt), and one orientation
+// needs no staging at all:
 //
 //   G = M^T B for a row-major M: lane (i, k) loads 16 bytes M[r + k][c0 + 4 i
 //   .. + 3].  A wave's load is 4 rows x 256 contiguous bytes (the DMA's shape)

@@ -139,7 +139,8 @@ int bbx_design_is_sparse(const bbx_design* h, int* flag);
 int bbx_design_device(const bbx_design* h, int* device);
 /* Format actually in use (BBX_FORMAT_CSR / BBX_FORMAT_TILED; 0 for dense). */
 int bbx_design_format(const bbx_design* h, int* format);
-/* HBM bytes held by the operator's matrix storage (both orientations). */
+/* HBM bytes held by the operator's matrix storage (both orientations; a dense
+ * design's transposed copy exists once a batch of chains has run on it). */
 int bbx_design_storage_bytes(const bbx_design* h, int64_t* bytes);
 /* Algorithmic HBM bytes of one dot / one Tdot in the storage format actually
  * read (nnz*(b_val+b_idx) + row pointers + in + out). */
