@@ -252,3 +252,35 @@ def test_lds_ring_variant_of_the_single_pass_operator_is_bit_identical(shape):
         assert m, res.stdout[-2000:]
         digest[flag] = m.group(1)
     assert digest["0"] == digest["22"]
+
+
+@pytest.mark.parametrize("K", [16, 32])
+def test_config4_batched_products_equal_the_single_chain_operator(full_dense, K):
+    """The K-column products of dense_batch.hip at full size (X^T W from X, X V
+    from the transposed copy; 32 chains: two B operands per A operand) against
+    the single-chain kernels of the same handle, column by column, and the
+    adjoint identity between the two batched products themselves."""
+    from bayesbridge_amd import HipChainBatch, HipGibbsChain
+    hip, *_ = full_dense
+    n, P = hip.shape
+    rng = np.random.default_rng(21)
+    y = rng.standard_normal(n)
+    batch = HipChainBatch([HipGibbsChain(hip, 'linear', y, sd_unshrunk=[np.inf],
+                                         bridge_exponent=.5, slab_size=2.,
+                                         seed=s) for s in range(K)])
+    V, W = rng.standard_normal((K, P)), rng.standard_normal((K, n))
+    T, G = batch.dot(V), batch.Tdot(W)
+    for c in (0, 7, K - 1):
+        t, g = hip.dot(V[c]), hip.Tdot(W[c])
+        assert np.abs(T[c] - t).max() <= 1e-11 * np.abs(t).max()
+        assert np.abs(G[c] - g).max() <= 1e-10 * np.abs(g).max()
+    lhs = np.einsum('cn,cn->c', T, W)       # <X v_c, w_c> = <v_c, X^T w_c>
+    rhs = np.einsum('cp,cp->c', V, G)
+    assert np.all(np.abs(lhs - rhs) <= 1e-9 * np.maximum(np.abs(lhs), 1.))
+    # the transposed copy is accounted for
+    assert hip.storage_bytes > 2 * 6.4e9
+    # three lock-step Gibbs iterations: every chain converges, chains differ
+    samples, n_unconverged = batch.run(3, save_coef=False)
+    assert n_unconverged == 0
+    assert np.all(samples['n_cg_iter'] > 0)
+    assert len(np.unique(samples['logp'][:, -1])) == K
