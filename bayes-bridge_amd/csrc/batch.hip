@@ -52,7 +52,6 @@ struct bbx_batch {
   bbx::DevMem state;              // BatchState
   void* pinned = nullptr;
   int last_cg_iter = 0;
-  hipStream_t branch = nullptr;   // tau / lambda branches, in chain order
 };
 
 namespace bbx {
@@ -620,10 +619,15 @@ static int batch_step(bbx_batch* b, int maxiter, double atol, int* n_cg,
   BBX_TRY(cg_sample_batch(b, maxiter, atol, cold, n_cg, info));
   for (int c = 0; c < K; ++c) b->chain[c]->mean_zero = false;
   BBX_TRY(batch_linear_predictor(b));
-  if (!b->branch)
-    BBX_HIP(hipStreamCreateWithFlags(&b->branch, hipStreamNonBlocking));
-  for (int c = 0; c < K; ++c)
-    BBX_TRY(chain_post_draw(b->chain[c], true, b->branch, c == K - 1));
+  // every chain's tau / lambda branch first (K second streams side by side:
+  // the lambda kernel is latency bound), then the Omega updates one after the
+  // other on the design's stream (they are ALU bound), then the joins
+  // (at most BRANCH_STREAMS queues: chains c, c + 4, ... share one, in order)
+  constexpr int BRANCH_STREAMS = 4;
+  for (int phase : {POST_BRANCH, POST_MAIN, POST_JOIN})
+    for (int c = 0; c < K; ++c)
+      BBX_TRY(chain_post_draw(b->chain[c], true, phase,
+                              b->chain[c % BRANCH_STREAMS]));
   return BBX_OK;
 }
 
@@ -716,10 +720,6 @@ int bbx_batch_destroy(bbx_batch* b) {
   if (b->h) {
     (void)hipSetDevice(b->h->device);
     (void)hipStreamSynchronize(b->h->stream);
-  }
-  if (b->branch) {
-    (void)hipStreamSynchronize(b->branch);
-    (void)hipStreamDestroy(b->branch);
   }
   if (b->pinned) (void)hipHostFree(b->pinned);
   delete b;  // the chains and the design stay the caller's

@@ -531,8 +531,8 @@ int chain_pre_draw(bbx_chain* c) {
   return BBX_OK;
 }
 
-int chain_post_draw(bbx_chain* c, bool have_psi, hipStream_t branch,
-                    bool join_branch) {
+int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
+                    bbx_chain* branch_of) {
   bbx_design* h = c->h;
   hipStream_t s = h->stream;
   const int64_t P = h->P, n = h->n;
@@ -559,21 +559,23 @@ int chain_post_draw(bbx_chain* c, bool have_psi, hipStream_t branch,
       getenv("BBX_CHAIN_FORK") ? atoi(getenv("BBX_CHAIN_FORK")) : -1;
   const bool fork = fork_env >= 0 ? fork_env == 1
                                   : (n >= 50000 && n_shrunk >= 2048);
-  if (fork && branch == nullptr && c->stream2 == nullptr) {
+  bbx_chain* owner = branch_of ? branch_of : c;   // whose second stream carries the branch
+  if (fork && owner->stream2 == nullptr) {
     // created on first use: chains that never fork keep a single queue
-    BBX_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    BBX_HIP(hipStreamCreateWithFlags(&owner->stream2, hipStreamNonBlocking));
   }
   if (fork && c->ev_join == nullptr)
     BBX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-  hipStream_t s_b = !fork ? s : (branch ? branch : c->stream2);
+  hipStream_t s_b = !fork ? s : owner->stream2;
 
   // --- Omega | beta  (bayesbridge.py:397-410).  Launch order = what has to
   // start first: the pass over the matrix, then the whole second branch (it
   // starts under that pass: the lambda kernel and the Polya-Gamma kernel are
   // both ALU-bound and slow each other down, the pass is bandwidth-bound),
   // then the n Polya-Gamma draws.
-  if (!have_psi) BBX_TRY(chain_linear_predictor(c));
+  if (!have_psi && (phases & POST_BRANCH)) BBX_TRY(chain_linear_predictor(c));
 
+  if (phases & POST_BRANCH) {
   // --- running summaries of beta (with the tau and lambda it was drawn
   // under), then tau | beta, then lambda | tau, beta, then log posterior
   hipLaunchKernelGGL(chain_summary_kernel, dim3(NPART), dim3(256), 0, s_b, P,
@@ -581,7 +583,8 @@ int chain_post_draw(bbx_chain* c, bool have_psi, hipStream_t branch,
                      c->lscale.as<double>(), c->coef.as<double>(),
                      c->mean.as<double>(), c->square.as<double>());
   c->n_averaged += 1;
-  double* pp = part_slot(h, PS_MISC);
+  // the chain's own partial slots: the branches of a batch's chains run side by side
+  double* pp = c->misc_part.as<double>();
   hipLaunchKernelGGL(chain_coef_sums_kernel, dim3(NPART), dim3(256), 0, s_b, P,
                      nu, c->bridge_exp, c->slab, c->coef.as<double>(),
                      c->sd_unshrunk.as<double>(), pp, pp + NPART,
@@ -605,7 +608,10 @@ int chain_post_draw(bbx_chain* c, bool have_psi, hipStream_t branch,
                        c->coef.as<double>(), c->lscale.as<double>(), items,
                        ts_cost_threshold());
   }
+  }  // POST_BRANCH
 
+  hipError_t launch_err = hipSuccess;
+  if (phases & POST_MAIN) {
   // --- Omega | beta, continued
   const int rg = grid_for(n, ROW_GRID);
   double* rp = c->row_part.as<double>();
@@ -622,14 +628,18 @@ int chain_post_draw(bbx_chain* c, bool have_psi, hipStream_t branch,
                      c->model, 0, n, c->seed,
                      iter_stream(STREAM_OBSVAR, c->iter), rp, rg, sc);
 
+  }  // POST_MAIN
+
   // the second branch is joined on every path, a failed launch included
-  const hipError_t launch_err = hipGetLastError();
-  if (fork && join_branch) {
-    BBX_HIP(hipEventRecord(c->ev_join, s_b));
-    BBX_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
+  launch_err = hipGetLastError();
+  if (phases & POST_JOIN) {
+    if (fork) {
+      BBX_HIP(hipEventRecord(c->ev_join, s_b));
+      BBX_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
+    }
+    c->iter += 1;
   }
   BBX_HIP(launch_err);
-  c->iter += 1;
   return BBX_OK;
 }
 
@@ -645,7 +655,7 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
       &info, c->mean_zero ? 1 : 0);
   if (st < 0) return st;
   c->mean_zero = false;
-  BBX_TRY(chain_post_draw(c, false, nullptr, true));
+  BBX_TRY(chain_post_draw(c, false, POST_ALL));
   return info;
 }
 
@@ -748,6 +758,7 @@ int bbx_chain_create(bbx_design* design, int model, const double* outcome,
     BBX_TRY(c->lscale.alloc(sizeof(double) * (size_t)(P - n_unshrunk + 1)));
     BBX_TRY(c->scalars.alloc(sizeof(ChainScalars)));
     BBX_TRY(c->row_part.alloc(sizeof(double) * ROW_GRID * 2));
+    BBX_TRY(c->misc_part.alloc(sizeof(double) * NPART * 3));
     BBX_HIP(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
     BBX_HIP(hipMemcpy(c->outcome.ptr, outcome, nb, hipMemcpyHostToDevice));
     if (model == BBX_MODEL_LOGIT) {

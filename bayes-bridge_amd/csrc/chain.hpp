@@ -46,6 +46,7 @@ struct bbx_chain {
   bbx::DevMem obs_prec, psi;            // n
   bbx::DevMem scalars;                  // ChainScalars
   bbx::DevMem row_part;                 // ROW_GRID partials x 2
+  bbx::DevMem misc_part;                // NPART x 3: sums over the coefficients (tau branch)
   bbx::DevMem samp_gscale, samp_logp;   // per kept sample (device)
   void* pinned = nullptr;
   // second stream for the tau / lambda branch of an iteration
@@ -66,11 +67,17 @@ int chain_pre_draw(bbx_chain* c);
 // Everything after the coefficient draw: Omega | beta (the linear predictor
 // psi = X~ beta unless `have_psi`: a batch computes it for all its chains in
 // one pass), running summaries, tau | beta, lambda | tau, beta, log posterior.
-// `branch` != nullptr overrides the stream of the tau / lambda branch (a batch
-// serialises its chains' branches on one stream: they share the design's
-// scratch partial slots).  Advances c->iter.
-int chain_post_draw(bbx_chain* c, bool have_psi, hipStream_t branch,
-                    bool join_branch);
+// In three phases, so that a batch can start the tau / lambda branch of EVERY
+// chain (each on the chain's own second stream, with the chain's own partial
+// slots) before the first Omega update occupies the design's stream:
+// POST_BRANCH launches the branch, POST_MAIN the Omega update on the design's
+// stream, POST_JOIN makes the design's stream wait for the branch and advances
+// c->iter.  One chain on its own: POST_ALL.  `branch_of`: the chain whose second
+// stream carries this chain's branch (a wide batch folds its chains' branches
+// onto a few streams); nullptr = the chain's own.
+enum { POST_BRANCH = 1, POST_MAIN = 2, POST_JOIN = 4, POST_ALL = 7 };
+int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
+                    bbx_chain* branch_of = nullptr);
 // Sample bookkeeping of a run (gibbs_util.py:126-174): per-sample scalars are
 // collected on the device and copied out once at the end.
 int chain_begin_run(bbx_chain* c, int n_sample);
