@@ -50,6 +50,7 @@ def _declare(lib):
         "bbx_design_shape": ([hp, POINTER(c_int64), POINTER(c_int64)], c_int),
         "bbx_design_nnz": ([hp, POINTER(c_int64)], c_int),
         "bbx_design_is_sparse": ([hp, POINTER(c_int)], c_int),
+        "bbx_design_is_binary": ([hp, POINTER(c_int)], c_int),
         "bbx_design_device": ([hp, POINTER(c_int)], c_int),
         "bbx_design_format": ([hp, POINTER(c_int)], c_int),
         "bbx_design_storage_bytes": ([hp, POINTER(c_int64)], c_int),

@@ -224,8 +224,10 @@ class BayesBridge():
     def batch_width(self, n_chain, params_to_save=('coef', 'global_scale',
                                                    'logp'), options=None):
         """How many of `n_chain` chains one batch can hold on this model's
-        design (0: batching does not apply): sparse tiled designs 2 or 4 (2
-        with stored values; pairs are what pays), dense f32
+        design (0: batching does not apply or does not pay): all-binary sparse
+        tiled designs 2 (pairs are what pays; designs with stored
+        values can be batched explicitly -- HipChainBatch -- but run faster one
+        chain at a time), dense f32
         designs 4, 8, 16 or 32 (the batched dense products read the matrix twice
         per operator application whatever the width -- 2.3 single-chain
         applications, 2.9 at 32 chains: two chains run faster one after the
@@ -242,6 +244,11 @@ class BayesBridge():
             return 0
         if design.is_sparse:
             if design.storage_format != 'tiled':
+                return 0
+            if design.hybrid_info is not None or not design.is_binary:
+                # designs with stored values (mixed ones included) batch
+                # through the plain valued K-layout: measured 2x SLOWER than
+                # two chains one after the other on the split layout
                 return 0
             widths = (2,)
         else:

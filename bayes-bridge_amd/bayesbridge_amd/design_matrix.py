@@ -142,6 +142,14 @@ class HipDesignMatrix():
         return out
 
     @property
+    def is_binary(self):
+        """True for a sparse design whose stored entries all equal 1.0."""
+        from ctypes import c_int
+        f = c_int()
+        _lib.check(self._lib.bbx_design_is_binary(self._h, byref(f)))
+        return bool(f.value)
+
+    @property
     def hybrid_info(self):
         """None, or how a mixed design was split by value in the tiled format:
         {'ones_nnz', 'rest_nnz', 'dense_nnz', 'dense_cols'} (entries equal to

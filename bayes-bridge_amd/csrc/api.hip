@@ -533,6 +533,12 @@ int bbx_design_is_sparse(const bbx_design* h, int* flag) {
   return BBX_OK;
 }
 
+int bbx_design_is_binary(const bbx_design* h, int* flag) {
+  BBX_TRY(check_handle(h));
+  if (flag) *flag = (h->sparse && h->binary) ? 1 : 0;
+  return BBX_OK;
+}
+
 int bbx_design_device(const bbx_design* h, int* device) {
   BBX_TRY(check_handle(h));
   if (device) *device = h->device;

@@ -134,6 +134,9 @@ int bbx_design_destroy(bbx_design* h);
 int bbx_design_shape(const bbx_design* h, int64_t* n, int64_t* P);
 int bbx_design_nnz(const bbx_design* h, int64_t* nnz);
 int bbx_design_is_sparse(const bbx_design* h, int* flag);
+/* 1 for a sparse design whose stored entries all equal 1.0 (kept value-free,
+ * the counterpart of cython_matmal/binary_matmul.pyx:21-25), else 0. */
+int bbx_design_is_binary(const bbx_design* h, int* flag);
 /* HIP device index the handle lives on (the reference's counterpart is the
  * CuPy array's device, sparse_matrix.py:35). */
 int bbx_design_device(const bbx_design* h, int* device);

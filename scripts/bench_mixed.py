@@ -54,5 +54,25 @@ for label, X in (("all-binary", Xb if valued_frac == 0 else None),
              t['dot'][1] / t['dot'][0], db / (t['dot'][1] / t['dot'][0]) / 1e6,
              t['tdot'][1] / t['tdot'][0],
              tb / (t['tdot'][1] / t['tdot'][0]) / 1e6, err))
+    if os.environ.get("BENCH_MIXED_PAIR") == "1":
+        # the K = 2 products of a batch on the same design (valued K-layout)
+        from bayesbridge_amd import HipChainBatch, HipGibbsChain
+        y = (rng.random(nn) < .3).astype(np.float64)
+        chains = [HipGibbsChain(d, 'logit', y, n_trial=np.ones(nn), seed=s_)
+                  for s_ in (1, 2)]
+        batch = HipChainBatch(chains)
+        V, W = rng.standard_normal((2, P)), rng.standard_normal((2, nn))
+        T = batch.dot(V)
+        batch.Tdot(W)
+        errk = np.abs(T[0] - d.dot(V[0])).max() / np.abs(T[0]).max()
+        d.reset_timing()
+        for _ in range(20):
+            batch.dot(V)
+            batch.Tdot(W)
+        t = d.get_timing()
+        print("%-10s pair products: dot %.4f ms, tdot %.4f ms (both chains), "
+              "rel err vs single %.1e" % (label, t['dot'][1] / t['dot'][0],
+                                          t['tdot'][1] / t['tdot'][0], errk))
+        del batch, chains
     d.close() if hasattr(d, 'close') else None
     del d

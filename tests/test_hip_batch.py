@@ -289,3 +289,22 @@ def test_batch_argument_checks():
     with pytest.raises(BbxError):
         HipChainBatch([a, other])            # another design
     HipChainBatch([a, b]).run(1)
+
+
+def test_batch_width_leaves_designs_with_stored_values_alone():
+    """Mixed and valued designs can be batched explicitly (parity above) but the
+    automatic path does not: their pair products go through the plain valued
+    K-layout and run slower than two chains on the split layout
+    (profiles/r03_mixed.txt)."""
+    import scipy.sparse as sparse
+    from bayesbridge_amd import (BayesBridge, RegressionCoefPrior,
+                                 RegressionModel, simulate)
+    rng = np.random.default_rng(12)
+    Xb = simulate.simulate_binary_csr_fast(3000, 200, .05, seed=5)
+    Xm = sparse.hstack([Xb, sparse.csr_matrix(rng.standard_normal((3000, 3)))]).tocsr()
+    y = (rng.random(3000) < .4).astype(float)
+    prior = RegressionCoefPrior(bridge_exponent=.5, regularizing_slab_size=2.)
+    for X, want in ((Xb, 2), (Xm, 0)):
+        model = RegressionModel((y, np.ones(3000)), X, 'logit')
+        assert model.design.is_binary == (want == 2)
+        assert BayesBridge(model, prior).batch_width(4) == want
