@@ -225,7 +225,7 @@ class BayesBridge():
                                                    'logp'), options=None):
         """How many of `n_chain` chains one batch can hold on this model's
         design (0: batching does not apply or does not pay): all-binary sparse
-        tiled designs 2 (pairs are what pays; designs with stored
+        tiled designs 4 while they are small, else 2 (designs with stored
         values can be batched explicitly -- HipChainBatch -- but run faster one
         chain at a time), dense f32
         designs 4, 8, 16 or 32 (the batched dense products read the matrix twice
@@ -250,7 +250,11 @@ class BayesBridge():
                 # through the plain valued K-layout: measured 2x SLOWER than
                 # two chains one after the other on the split layout
                 return 0
-            widths = (2,)
+            # four chains per pass pay while the design is small (fixed costs
+            # per launch dominate: 1.4-1.9x at 5k x 500 ... 100k x 10k against
+            # 1.1-1.5x for pairs); at 1M x 50k the four planes shrink the LDS
+            # tiles too far (0.99x against 1.32x; profiles/r03_small_batches.txt)
+            widths = (4, 2) if design.nnz <= 3e7 else (2,)
         else:
             if design.storage_dtype != 'float32':
                 return 0

@@ -241,8 +241,8 @@ def test_a_dense_chain_does_not_depend_on_its_batch(K):
 
 def test_gibbs_batch_and_run_chains_go_through_batches():
     """BayesBridge.gibbs_batch returns per-chain (samples, mcmc_info) in
-    gibbs()'s format; chains.run_chains (one process, 5 chains) pairs its
-    chains into batches and runs the odd one alone -- chain k has seed + k
+    gibbs()'s format; chains.run_chains (one process, 5 chains) puts four
+    of its chains into a batch and runs the odd one alone -- chain k has seed + k
     either way, and a batched chain equals the same chain from gibbs_batch."""
     from bayesbridge_amd import (BayesBridge, HipSparseDesignMatrix,
                                  RegressionCoefPrior, RegressionModel, chains,
@@ -255,22 +255,23 @@ def test_gibbs_batch_and_run_chains_go_through_batches():
     bridge = BayesBridge(RegressionModel(y, hip, 'logit'),
                          RegressionCoefPrior(bridge_exponent=.5,
                                              regularizing_slab_size=2.))
-    assert bridge.batch_width(5) == 2 and bridge.batch_width(1) == 0
+    assert bridge.batch_width(5) == 4 and bridge.batch_width(3) == 2
+    assert bridge.batch_width(1) == 0
     assert bridge.batch_width(4, params_to_save='all') == 0
     init = {'global_scale': .05, 'coef': np.zeros(301)}
-    res = bridge.gibbs_batch([11, 12], 6, n_burnin=2, init=init)
-    assert len(res) == 2
+    res = bridge.gibbs_batch([11, 12, 13, 14], 6, n_burnin=2, init=init)
+    assert len(res) == 4
     for samples, info in res:
         assert samples['coef'].shape == (301, 4)          # MCMC index last
         assert samples['logp'].shape == (4,)
         assert info['_reg_coef_sampling_info']['n_cg_iter'].shape == (4,)
-        assert info['batch']['width'] == 2
+        assert info['batch']['width'] == 4
     merged, infos = chains.run_chains(bridge, 5, 6, n_burnin=2, seed=11,
                                       init=init)
     assert merged['coef'].shape == (5, 301, 4)
     assert [i['chain'] for i in infos] == [0, 1, 2, 3, 4]
     assert ['batch' in i for i in infos] == [True] * 4 + [False]
-    for k in range(2):
+    for k in range(4):
         assert np.array_equal(merged['coef'][k], res[k][0]['coef'])
     alone, _ = bridge.gibbs(6, n_burnin=2, seed=15, init=init)
     assert np.array_equal(merged['coef'][4], alone['coef'])
@@ -304,7 +305,7 @@ def test_batch_width_leaves_designs_with_stored_values_alone():
     Xm = sparse.hstack([Xb, sparse.csr_matrix(rng.standard_normal((3000, 3)))]).tocsr()
     y = (rng.random(3000) < .4).astype(float)
     prior = RegressionCoefPrior(bridge_exponent=.5, regularizing_slab_size=2.)
-    for X, want in ((Xb, 2), (Xm, 0)):
+    for X, want in ((Xb, 4), (Xm, 0)):
         model = RegressionModel((y, np.ones(3000)), X, 'logit')
-        assert model.design.is_binary == (want == 2)
+        assert model.design.is_binary == (want == 4)
         assert BayesBridge(model, prior).batch_width(4) == want
