@@ -227,8 +227,8 @@ class BayesBridge():
         design (0: batching does not apply or does not pay): all-binary sparse
         tiled designs 4 while they are small, else 2 (designs with stored
         values can be batched explicitly -- HipChainBatch -- but run faster one
-        chain at a time), dense f32
-        designs 4, 8, 16 or 32 (the batched dense products read the matrix twice
+        chain at a time), dense
+        designs (f32 or f64 storage) 4, 8, 16 or 32 (the batched dense products read the matrix twice
         per operator application whatever the width -- 2.3 single-chain
         applications, 2.9 at 32 chains: two chains run faster one after the
         other).  Batches keep 'coef', 'global_scale', 'logp' and use
@@ -256,8 +256,6 @@ class BayesBridge():
             # tiles too far (0.99x against 1.32x; profiles/r03_small_batches.txt)
             widths = (4, 2) if design.nnz <= 3e7 else (2,)
         else:
-            if design.storage_dtype != 'float32':
-                return 0
             widths = (32, 16, 8, 4)
         for w in widths:
             if w <= n_chain:

@@ -664,7 +664,7 @@ int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,
                 "batched chains need the tiled format of a sparse design");
   if (!h->sparse && !dense_batch_applies(h))
     return fail(BBX_ERR_STATE,
-                "batched chains need f32 storage of a dense design");
+                "batched chains: this dense layout is not supported");
   if (h->sparse && !h->binary && n_chain > 2)
     return fail(BBX_ERR_INVALID,
                 "designs with stored values batch at most 2 chains (four valued "

@@ -101,7 +101,7 @@ int no_throw(F&& f) noexcept {
 
 // Chains that may share one pass over a sparse design (batched chains); the
 // per-chain device pointers the batched kernels take by value.
-constexpr int BATCH_MAX = 32;  // (sparse designs: 4; dense f32 designs: 32)
+constexpr int BATCH_MAX = 32;  // (sparse designs: 4; dense designs: 32)
 // Dense batches interleave their vectors with a FIXED stride of 16 -- the 16
 // columns of the MFMA's B operand -- whatever the number of chains; unused
 // columns (and the rows of padding the kernels' last stages read) stay zero,
@@ -361,7 +361,7 @@ int launch_tdot_tiled_k(bbx_design* h, int K, const double* d_w,
                         const double** slab, int* G);
 int tiled_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
                       int64_t* tdot_bytes);
-// The same two products for dense f32 designs on the matrix cores, K <= 16
+// The same two products for dense designs (f32 or f64 storage) on the matrix cores, K <= 32
 // chains (dense_batch.hip): t_c = rowscale_c .* (X v_c) with the partials of
 // <t_c, Omega_c t_c> (d_twt_part[c * NPART + ...], may be null), and the slabs
 // [G][ld][16] of X^T w_c.  d_v is [ld + 64][16] and d_w [n + 64][16], zero

@@ -77,9 +77,10 @@ constexpr int DK_TDOT_CHUNKS = 8;           // row chunks of the transposed prod
 
 typedef float dk_f4 __attribute__((ext_vector_type(4)));
 
-template <int IMM>
-__device__ __forceinline__ void dk_ld_x4(dk_f4& dst, unsigned voff,
+template <int IMM, typename V>
+__device__ __forceinline__ void dk_ld_x4(V& dst, unsigned voff,
                                          const void* sbase) {
+  static_assert(sizeof(V) == 16, "one 16-byte load per lane");
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt"
                : "=v"(dst)
                : "v"(voff), "s"(sbase), "n"(IMM)
@@ -135,35 +136,60 @@ __device__ __forceinline__ void dk_mfma2(dk_d4& acc0, dk_d4& acc1, float x,
       : "v"(x), "v"(b0), "v"(b1));
 }
 
-constexpr int DKD_WAVES = 4;        // one per SIMD: 512 registers per lane
-constexpr int DKD_C = 4;            // 64-column units a sweep carries
-constexpr int DKD_IMG = DKD_WAVES * DKD_C * 16 * WAVE * 8;  // 128 KB of LDS
+// f64 storage: the lane's 16 bytes are two doubles, fed to the MFMAs as they
+// are (no VALU between the counted load and the matrix core; the s_nop spaces
+// a B operand the VALU may have just produced).
+__device__ __forceinline__ void dk_mfma(dk_d4& acc, double x, double b) {
+  asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0"
+               : "+a"(acc)
+               : "v"(x), "v"(b));
+}
+__device__ __forceinline__ void dk_mfma2(dk_d4& acc0, dk_d4& acc1, double x,
+                                         double b0, double b1) {
+  asm volatile(
+      "s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %2, %3, %0\n\t"
+      "v_mfma_f64_16x16x4_f64 %1, %2, %4, %1"
+      : "+a"(acc0), "+a"(acc1)
+      : "v"(x), "v"(b0), "v"(b1));
+}
 
-// One wave's sweep: acc[c][e] += sum over rows [r_begin, r_begin + 4 n_slot) of
-// M[r][col0 + 64 c + 4 i' + e] * B[r][chain], i' the MFMA's row index.
-// m_rows = rows of M that exist including its padding (addresses are clamped
-// for waves without work only; the ring's read-ahead relies on the padding).
-template <int C, int D, int NG>
-__device__ __forceinline__ void dkd_sweep(const float* __restrict__ M,
-                                          int64_t ldm, int64_t col0,
-                                          int64_t r_begin, int n_slot,
-                                          const double* __restrict__ Bop,
-                                          int lane, dk_d4 (&acc)[NG][DKD_C][4]) {
+constexpr int DKD_WAVES = 4;        // one per SIMD: 512 registers per lane
+constexpr int DKD_C = 4;            // units (one load instruction wide) a sweep carries
+// Per storage type T: a lane's 16 bytes are E elements, a load instruction
+// covers 4 rows x U = 16 E columns (a "unit": 64 columns of f32, 32 of f64)
+template <typename T>
+struct DkT {
+  static constexpr int E = 16 / (int)sizeof(T);
+  static constexpr int U = 16 * E;
+  typedef T vec __attribute__((ext_vector_type(16 / sizeof(T))));
+};
+constexpr int DKD_IMG = DKD_WAVES * DKD_C * 16 * WAVE * 8;  // 128 KB of LDS (f32; f64 half)
+
+// One wave's sweep: acc[g][c][e] += sum over rows [r_begin, r_begin + 4 n_slot)
+// of M[r][col0 + U c + E i' + e] * B[r][16 g + chain], i' the MFMA's row index.
+// (A wave without rows primes its ring on the first rows and computes
+// nothing; the ring's read-ahead relies on the padding of M and B.)
+template <typename T, int C, int D, int NG>
+__device__ __forceinline__ void dkd_sweep(
+    const T* __restrict__ M, int64_t ldm, int64_t col0, int64_t r_begin,
+    int n_slot, const double* __restrict__ Bop, int lane,
+    dk_d4 (&acc)[NG][DKD_C][DkT<T>::E]) {
   static_assert(C >= 1 && C <= DKD_C, "units per sweep");
   static_assert(NG == 1 || NG == 2, "groups of 16 chains");
+  constexpr int E = DkT<T>::E;
+  typedef typename DkT<T>::vec vec_t;
   constexpr int KS = NG * DK_KS;
   constexpr int LPS = C + NG;
   constexpr int WAITC = (D - 1) * LPS;
   static_assert(WAITC < 64, "vmcnt is a 6-bit field");
   const int i = lane & 15, k = lane >> 4;
   const int n_period = (n_slot + D - 1) / D;
-  const unsigned voff_a = (unsigned)(((int64_t)k * ldm + 4 * i) * 4);
+  const unsigned voff_a = (unsigned)(((int64_t)k * ldm + E * i) * sizeof(T));
   const unsigned voff_b = (unsigned)((k * KS + i) * 8);
-  // (a wave without rows primes its ring on the first rows and computes nothing)
   const int64_t r_ring = n_slot > 0 ? r_begin : 0;
-  const float* sa = M + r_ring * ldm + col0;     // wave-uniform, 4 rows per slot
+  const T* sa = M + r_ring * ldm + col0;         // wave-uniform, 4 rows per slot
   const double* sb = Bop + r_ring * KS;
-  dk_f4 xa[D][C];
+  vec_t xa[D][C];
   double bw[D][NG];
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing of the compiler's in the queue
 #define DKD_ISSUE(KK)                                                         \
@@ -199,7 +225,7 @@ __device__ __forceinline__ void dkd_sweep(const float* __restrict__ M,
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < E; ++e) {
           if (DK_ABLATE == 2) acc[0][c][e][0] += (double)xa[kk][c][e] * (b0 + b1);
           else if (NG == 1) dk_mfma(acc[0][c][e], xa[kk][c][e], b0);
           else dk_mfma2(acc[0][c][e], acc[NG - 1][c][e], xa[kk][c][e], b0, b1);
@@ -220,77 +246,79 @@ __device__ __forceinline__ void dkd_sweep(const float* __restrict__ M,
 #pragma unroll
     for (int c = 0; c < DKD_C; ++c)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < E; ++e)
         if (g + c + e > 0) asm volatile("" : "+a"(acc[g][c][e]));
 }
 
 // The four waves' accumulators through LDS, added in the fixed order
-// (w0 + w1) + (w2 + w3); wave c' returns sub-block c' in g[e][reg]:
-// g[e][reg] = G[col0 + 64 c' + 4 ((lane >> 4) + 4 reg) + e][chain lane & 15].
-__device__ __forceinline__ void dkd_fold(const dk_d4 (&acc)[DKD_C][4],
+// (w0 + w1) + (w2 + w3); wave c' returns unit c' in g[e][reg]:
+// g[e][reg] = G[col0 + U c' + E ((lane >> 4) + 4 reg) + e][chain lane & 15].
+template <int E>
+__device__ __forceinline__ void dkd_fold(const dk_d4 (&acc)[DKD_C][E],
                                          double* img, int wave, int lane,
-                                         double (&g)[4][4]) {
+                                         double (&g)[E][4]) {
 #pragma unroll
   for (int c = 0; c < DKD_C; ++c)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < E; ++e)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg)
-        img[((((wave * DKD_C + c) * 4 + e) * 4 + reg) << 6) + lane] = acc[c][e][reg];
+        img[((((wave * DKD_C + c) * E + e) * 4 + reg) << 6) + lane] = acc[c][e][reg];
   __syncthreads();
-  constexpr int WS = DKD_C * 16 * WAVE;
+  constexpr int WS = DKD_C * E * 4 * WAVE;
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
+  for (int e = 0; e < E; ++e)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int o = (((wave * 4 + e) * 4 + reg) << 6) + lane;
+      const int o = (((wave * E + e) * 4 + reg) << 6) + lane;
       g[e][reg] = (img[o] + img[WS + o]) + (img[2 * WS + o] + img[3 * WS + o]);
     }
   __syncthreads();   // the image is free again (next group of chains, next sweep)
 }
 
-// X^T W: a workgroup = (block of 256 columns, one of DK_TDOT_CHUNKS row chunks);
-// its four waves take quarters of the chunk's rows.  blockIdx.x % 8 = the
-// chunk: under round-robin placement the workgroups of an XCD share a row
+// X^T W: a workgroup = (block of C units of columns, one of DK_TDOT_CHUNKS row
+// chunks); its four waves take quarters of the chunk's rows.  blockIdx.x % 8 =
+// the chunk: under round-robin placement the workgroups of an XCD share a row
 // chunk, and its slice of W streams through that XCD's L2 once.
-template <int NG>
+template <typename T, int NG>
 __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_tdot_kd_kernel(
     int K, int64_t n, int64_t ld, int64_t rows_per_wave,
-    const float* __restrict__ X, const double* __restrict__ w,
+    const T* __restrict__ X, const double* __restrict__ w,
     double* __restrict__ slab, const int* __restrict__ skip_flag) {
   if (skip_flag && *skip_flag) return;
+  constexpr int E = DkT<T>::E, U = DkT<T>::U;
   extern __shared__ __attribute__((aligned(16))) unsigned char dk_smem[];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int chunk = (int)(blockIdx.x % DK_TDOT_CHUNKS);
   const int colblk = (int)(blockIdx.x / DK_TDOT_CHUNKS);
-  const int64_t col0 = (int64_t)colblk * (64 * DKD_C);
+  const int64_t col0 = (int64_t)colblk * (U * DKD_C);
   const int64_t r_begin =
       ((int64_t)chunk * DKD_WAVES + wave) * rows_per_wave;  // multiple of 4
   int64_t r_end = r_begin + rows_per_wave;
   if (r_end > n) r_end = n;
   const int n_slot = r_end > r_begin ? (int)((r_end - r_begin + 3) / 4) : 0;
-  dk_d4 acc[NG][DKD_C][4];
+  dk_d4 acc[NG][DKD_C][E];
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
     for (int c = 0; c < DKD_C; ++c)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[gq][c][e] = dk_d4{0., 0., 0., 0.};
-  dkd_sweep<DKD_C, (NG == 1 ? DKT_D : DKT_D2), NG>(X, ld, col0, r_begin, n_slot, w,
-                                                   lane, acc);
+      for (int e = 0; e < E; ++e) acc[gq][c][e] = dk_d4{0., 0., 0., 0.};
+  dkd_sweep<T, DKD_C, (NG == 1 ? DKT_D : DKT_D2), NG>(X, ld, col0, r_begin, n_slot, w,
+                                                      lane, acc);
   const int i = lane & 15, k = lane >> 4;
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq) {
-    double g[4][4];
-    dkd_fold(acc[gq], reinterpret_cast<double*>(dk_smem), wave, lane, g);
+    double g[E][4];
+    dkd_fold<E>(acc[gq], reinterpret_cast<double*>(dk_smem), wave, lane, g);
     const int chain = 16 * gq + i;
     if (chain < K) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < E; ++e)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const int64_t col = col0 + 64 * wave + 4 * (k + 4 * reg) + e;
+          const int64_t col = col0 + U * wave + E * (k + 4 * reg) + e;
           if (col < ld)
             slab[((int64_t)chunk * ld + col) * (NG * DK_KS) + chain] = g[e][reg];
         }
@@ -299,44 +327,46 @@ __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_tdot_kd_kernel(
 }
 
 // X V through the transposed copy: T = (X^T)^T V, XT row-major [P + pad][ldn].
-// 256 persistent workgroups; workgroup b owns the 64-row units [u0, u1) of T
-// (12 or 13 of them at 200 000 rows) and sweeps all P rows of XT once per four
-// units, its waves taking quarters of P; the tail of fewer than four units is
-// a narrower sweep.  Epilogue per unit: rowscale, the store, <t, Omega t>.
-template <int C, int NG>
+// 256 persistent workgroups; workgroup b owns the units [u0, u1) of result
+// rows (12 or 13 of them at 200 000 rows of f32) and sweeps all P rows of XT
+// once per four units, its waves taking quarters of P; the tail of fewer than
+// four units is a narrower sweep.  Epilogue per unit: rowscale, the store,
+// <t, Omega t>.
+template <typename T, int C, int NG>
 __device__ __forceinline__ void dkd_dot_units(
-    int K, int64_t n, int64_t P, int64_t ldn, const float* __restrict__ XT,
+    int K, int64_t n, int64_t P, int64_t ldn, const T* __restrict__ XT,
     const double* __restrict__ v, const ChainPtrs& rowscale, const ChainOut& out,
     int out_stride, int64_t unit0, double* img, int wave, int lane,
     double (&twt)[NG]) {
+  constexpr int E = DkT<T>::E, U = DkT<T>::U;
   const int64_t rows_per_wave = ((P + DKD_WAVES - 1) / DKD_WAVES + 3) / 4 * 4;
   const int64_t r_begin = (int64_t)wave * rows_per_wave;
   int64_t r_end = r_begin + rows_per_wave;
   if (r_end > P) r_end = P;
   const int n_slot = r_end > r_begin ? (int)((r_end - r_begin + 3) / 4) : 0;
-  dk_d4 acc[NG][DKD_C][4];
+  dk_d4 acc[NG][DKD_C][E];
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
     for (int c = 0; c < DKD_C; ++c)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[gq][c][e] = dk_d4{0., 0., 0., 0.};
-  dkd_sweep<C, (NG == 1 ? DKT_D : DKT_D2), NG>(XT, ldn, unit0 * 64, r_begin, n_slot,
-                                               v, lane, acc);
+      for (int e = 0; e < E; ++e) acc[gq][c][e] = dk_d4{0., 0., 0., 0.};
+  dkd_sweep<T, C, (NG == 1 ? DKT_D : DKT_D2), NG>(XT, ldn, unit0 * U, r_begin, n_slot,
+                                                  v, lane, acc);
   const int i = lane & 15, k = lane >> 4;
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq) {
-    double g[4][4];
-    dkd_fold(acc[gq], img, wave, lane, g);
+    double g[E][4];
+    dkd_fold<E>(acc[gq], img, wave, lane, g);
     const int chain = 16 * gq + i;
     if (wave < C && chain < K) {
       const double* rs = rowscale.p[chain];
       double* o = out.p[chain];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < E; ++e)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const int64_t row = (unit0 + wave) * 64 + 4 * (k + 4 * reg) + e;
+          const int64_t row = (unit0 + wave) * U + E * (k + 4 * reg) + e;
           if (row < n) {
             const double t = g[e][reg];
             double w = t;
@@ -349,9 +379,9 @@ __device__ __forceinline__ void dkd_dot_units(
   }
 }
 
-template <int NG>
+template <typename T, int NG>
 __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_dot_kd_kernel(
-    int K, int64_t n, int64_t P, int64_t ldn, const float* __restrict__ XT,
+    int K, int64_t n, int64_t P, int64_t ldn, const T* __restrict__ XT,
     const double* __restrict__ v, ChainPtrs rowscale, ChainOut out,
     int out_stride, double* __restrict__ twt_part,
     const int* __restrict__ skip_flag) {
@@ -361,7 +391,7 @@ __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_dot_kd_kernel(
   double* img = reinterpret_cast<double*>(dk_smem);
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
-  const int64_t n_unit = ldn / 64;
+  const int64_t n_unit = ldn / DkT<T>::U;
   const int64_t base = n_unit / gridDim.x, extra = n_unit % gridDim.x;
   const int64_t b = blockIdx.x;
   int64_t u = b * base + (b < extra ? b : extra);
@@ -371,8 +401,8 @@ __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_dot_kd_kernel(
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq) twt[gq] = 0.;
 #define DKD_UNITS(C)                                                          \
-  dkd_dot_units<C, NG>(K, n, P, ldn, XT, v, rowscale, out, out_stride, u, img, \
-                       wave, lane, twt)
+  dkd_dot_units<T, C, NG>(K, n, P, ldn, XT, v, rowscale, out, out_stride, u,  \
+                          img, wave, lane, twt)
   for (; u + 4 <= u1; u += 4) DKD_UNITS(4);
   if (u1 - u == 3) DKD_UNITS(3);
   else if (u1 - u == 2) DKD_UNITS(2);
@@ -397,15 +427,16 @@ __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_dot_kd_kernel(
 
 // XT[c][r] = X[r][c] for c < ld (rows of XT past P: X's zero padding columns;
 // past ld and columns past n: zero)
+template <typename T>
 __global__ __launch_bounds__(256) void dense_transpose_kernel(
     int64_t n, int64_t ld, int64_t ldn, int64_t xt_rows,
-    const float* __restrict__ X, float* __restrict__ XT) {
-  __shared__ float tile[64][65];
+    const T* __restrict__ X, T* __restrict__ XT) {
+  __shared__ T tile[64][65];
   const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int j = ty; j < 64; j += 4) {
     const int64_t r = r0 + j, c = c0 + tx;
-    tile[j][tx] = (r < n && c < ld) ? X[r * ld + c] : 0.f;
+    tile[j][tx] = (r < n && c < ld) ? X[r * ld + c] : (T)0;
   }
   __syncthreads();
   for (int j = ty; j < 64; j += 4) {
@@ -414,32 +445,43 @@ __global__ __launch_bounds__(256) void dense_transpose_kernel(
   }
 }
 
-static int ensure_dense_transpose(bbx_design* h) {
-  if (h->dense_xt.ptr) return BBX_OK;
+template <typename T>
+static int ensure_dense_transpose_t(bbx_design* h) {
   const int64_t ldn = (h->n + 63) / 64 * 64;
   const int64_t rows = (h->dense_ld + 63) / 64 * 64 + DENSE_PAD_ROWS;
-  BBX_TRY(h->dense_xt.alloc(sizeof(float) * (size_t)rows * (size_t)ldn));
+  BBX_TRY(h->dense_xt.alloc(sizeof(T) * (size_t)rows * (size_t)ldn));
   BBX_HIP(hipMemsetAsync(h->dense_xt.ptr, 0,
-                         sizeof(float) * (size_t)rows * (size_t)ldn, h->stream));
+                         sizeof(T) * (size_t)rows * (size_t)ldn, h->stream));
   const dim3 grid((unsigned)(ldn / 64), (unsigned)((h->dense_ld + 63) / 64));
-  hipLaunchKernelGGL(dense_transpose_kernel, grid, dim3(256), 0, h->stream,
-                     h->n, h->dense_ld, ldn, rows, h->dense.as<float>(),
-                     h->dense_xt.as<float>());
+  hipLaunchKernelGGL(dense_transpose_kernel<T>, grid, dim3(256), 0, h->stream,
+                     h->n, h->dense_ld, ldn, rows, h->dense.as<T>(),
+                     h->dense_xt.as<T>());
   BBX_HIP(hipGetLastError());
   h->dense_xt_ld = ldn;
   return BBX_OK;
 }
+static int ensure_dense_transpose(bbx_design* h) {
+  if (h->dense_xt.ptr) return BBX_OK;
+  return h->dense_dtype == BBX_F32 ? ensure_dense_transpose_t<float>(h)
+                                   : ensure_dense_transpose_t<double>(h);
+}
 
 bool dense_batch_applies(const bbx_design* h) {
-  return !h->sparse && h->dense_dtype == BBX_F32 && h->dense_ld % 8 == 0;
+  // rows start on 16-byte boundaries: ld is a multiple of 8 elements
+  return !h->sparse && h->dense_ld % 8 == 0;
 }
 
 static int dk_set_attr(bbx_design* h) {
   if (h->dense_batch_attr) return BBX_OK;   // per design, i.e. per device
-  for (const void* f : {reinterpret_cast<const void*>(&dense_tdot_kd_kernel<1>),
-                        reinterpret_cast<const void*>(&dense_tdot_kd_kernel<2>),
-                        reinterpret_cast<const void*>(&dense_dot_kd_kernel<1>),
-                        reinterpret_cast<const void*>(&dense_dot_kd_kernel<2>)})
+  for (const void* f :
+       {reinterpret_cast<const void*>(&dense_tdot_kd_kernel<float, 1>),
+        reinterpret_cast<const void*>(&dense_tdot_kd_kernel<float, 2>),
+        reinterpret_cast<const void*>(&dense_dot_kd_kernel<float, 1>),
+        reinterpret_cast<const void*>(&dense_dot_kd_kernel<float, 2>),
+        reinterpret_cast<const void*>(&dense_tdot_kd_kernel<double, 1>),
+        reinterpret_cast<const void*>(&dense_tdot_kd_kernel<double, 2>),
+        reinterpret_cast<const void*>(&dense_dot_kd_kernel<double, 1>),
+        reinterpret_cast<const void*>(&dense_dot_kd_kernel<double, 2>)})
     BBX_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 DKD_IMG));
   h->dense_batch_attr = true;
@@ -451,19 +493,21 @@ int dense_batch_stride(int K) { return K > DK_KS ? 2 * DK_KS : DK_KS; }
 int launch_dot_dense_k(bbx_design* h, int K, const double* d_v,
                        const TiledBatchArgs& ba, double* d_twt_part) {
   if (!dense_batch_applies(h))
-    return fail(BBX_ERR_STATE, "batched dense products need f32 storage");
+    return fail(BBX_ERR_STATE, "batched dense products: unsupported layout");
   BBX_TRY(dk_set_attr(h));
   BBX_TRY(ensure_dense_transpose(h));
   h->n_dot += 1;
   BBX_TRY(timer_begin(h, 0));
-#define DK_LAUNCH_DOT(NG)                                                     \
-  hipLaunchKernelGGL(dense_dot_kd_kernel<NG>, dim3(DK_DOT_WGS),               \
+#define DK_LAUNCH_DOT(T, NG)                                                  \
+  hipLaunchKernelGGL((dense_dot_kd_kernel<T, NG>), dim3(DK_DOT_WGS),          \
                      dim3(DKD_WAVES* WAVE), DKD_IMG, h->stream, K, h->n, h->P, \
-                     h->dense_xt_ld, h->dense_xt.as<float>(), d_v,            \
-                     ba.rowscale, ba.out, ba.out_stride, d_twt_part,          \
-                     h->skip_flag)
-  if (K > DK_KS) DK_LAUNCH_DOT(2);
-  else DK_LAUNCH_DOT(1);
+                     h->dense_xt_ld, h->dense_xt.as<T>(), d_v, ba.rowscale,   \
+                     ba.out, ba.out_stride, d_twt_part, h->skip_flag)
+  const bool f32 = h->dense_dtype == BBX_F32;
+  if (f32 && K > DK_KS) DK_LAUNCH_DOT(float, 2);
+  else if (f32) DK_LAUNCH_DOT(float, 1);
+  else if (K > DK_KS) DK_LAUNCH_DOT(double, 2);
+  else DK_LAUNCH_DOT(double, 1);
 #undef DK_LAUNCH_DOT
   BBX_HIP(hipGetLastError());
   return timer_end(h, 0);
@@ -472,7 +516,7 @@ int launch_dot_dense_k(bbx_design* h, int K, const double* d_v,
 int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
                         const double** slab, int* G) {
   if (!dense_batch_applies(h))
-    return fail(BBX_ERR_STATE, "batched dense products need f32 storage");
+    return fail(BBX_ERR_STATE, "batched dense products: unsupported layout");
   BBX_TRY(dk_set_attr(h));
   const size_t need = sizeof(double) * (size_t)DK_TDOT_CHUNKS *
                       (size_t)h->dense_ld * (size_t)dense_batch_stride(K);
@@ -481,19 +525,23 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
     // columns past the batch's chains are never written: keep them zero
     BBX_HIP(hipMemsetAsync(h->dense_batch_slab.ptr, 0, need, h->stream));
   }
-  const int n_colblk = (int)((h->dense_ld + 64 * DKD_C - 1) / (64 * DKD_C));
+  const bool f32 = h->dense_dtype == BBX_F32;
+  const int unit = f32 ? DkT<float>::U : DkT<double>::U;
+  const int n_colblk = (int)((h->dense_ld + unit * DKD_C - 1) / (unit * DKD_C));
   const int64_t parts = (int64_t)DK_TDOT_CHUNKS * DKD_WAVES;
   const int64_t rows_per_wave = ((h->n + parts - 1) / parts + 3) / 4 * 4;
   h->n_tdot += 1;
   BBX_TRY(timer_begin(h, 1));
-#define DK_LAUNCH_TDOT(NG)                                                    \
-  hipLaunchKernelGGL(dense_tdot_kd_kernel<NG>,                                \
+#define DK_LAUNCH_TDOT(T, NG)                                                 \
+  hipLaunchKernelGGL((dense_tdot_kd_kernel<T, NG>),                           \
                      dim3((unsigned)(n_colblk * DK_TDOT_CHUNKS)),             \
                      dim3(DKD_WAVES* WAVE), DKD_IMG, h->stream, K, h->n,      \
-                     h->dense_ld, rows_per_wave, h->dense.as<float>(), d_w,   \
+                     h->dense_ld, rows_per_wave, h->dense.as<T>(), d_w,       \
                      h->dense_batch_slab.as<double>(), h->skip_flag)
-  if (K > DK_KS) DK_LAUNCH_TDOT(2);
-  else DK_LAUNCH_TDOT(1);
+  if (f32 && K > DK_KS) DK_LAUNCH_TDOT(float, 2);
+  else if (f32) DK_LAUNCH_TDOT(float, 1);
+  else if (K > DK_KS) DK_LAUNCH_TDOT(double, 2);
+  else DK_LAUNCH_TDOT(double, 1);
 #undef DK_LAUNCH_TDOT
   BBX_HIP(hipGetLastError());
   BBX_TRY(timer_end(h, 1));
@@ -506,7 +554,7 @@ int dense_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
                       int64_t* tdot_bytes) {
   // the matrix (X or its transposed copy) once + the 16-column operands
   // (padding columns are read too) + what the chains' columns write
-  const int64_t mat = h->n * h->dense_ld * 4;
+  const int64_t mat = h->n * h->dense_ld * (h->dense_dtype == BBX_F32 ? 4 : 8);
   const int64_t ks = dense_batch_stride(K);
   *dot_bytes = mat + 8 * ks * h->dense_ld + 8 * (int64_t)K * h->n;
   *tdot_bytes = mat + 8 * ks * h->n +

@@ -61,6 +61,11 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-baseline-iters", type=int, default=5,
                     help="Gibbs iterations of each CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=111)
+    ap.add_argument("--dense-storage", default="float32",
+                    choices=["float32", "float64"],
+                    help="config4 only: storage type of the dense matrix "
+                         "(BASELINE: float32; float64 is the reference's own "
+                         "type, 12.8 GB)")
     ap.add_argument("--multi-chain", default=None,
                     help="comma-separated batch widths for the `multi_chain` "
                          "object (k chains on ONE GPU sharing every pass over "
@@ -373,7 +378,7 @@ def main():
         design = HipDenseDesignMatrix.from_device_array(
             n, p, prob["X"].data_ptr(), prob["offset"].data_ptr(),
             add_intercept=True, device=dev_index, in_dtype='float32',
-            storage_dtype='float32')
+            storage_dtype=args.dense_storage)
         del prob["X"]
         outcome = prob["y"].cpu().numpy()
         def make_chain(seed):
@@ -550,10 +555,12 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": (
-                    "%s: linear, dense N(0,1) %dx%d stored f32 (torch Philox "
+                    "%s: linear, dense N(0,1) %dx%d stored %s (torch Philox "
                     "seed %d), centred + intercept, one independent chain "
-                    "per GPU, seeds %d+rank" % (args.config, n, p, args.seed,
-                                                args.seed)) if dense else (
+                    "per GPU, seeds %d+rank"
+                    % (args.config, n, p,
+                       "f32" if args.dense_storage == "float32" else "f64",
+                       args.seed, args.seed)) if dense else (
                     "%s: logit, sparse binary CSR %dx%d nnz=%d "
                     "(simulate_data.py distribution, f=%g), one "
                     "independent chain per GPU, seeds %d+rank"

@@ -412,9 +412,9 @@ int bbx_chain_run_host(bbx_chain* c, int n_iter, int n_burnin, int thin,
  *
  * `chains`: n_chain chains created with bbx_chain_create on `design` -- 2 or 4
  * for sparse designs in the tiled format (2 when values are stored), 2, 4, 8,
- * 16 or 32 for dense designs with f32 storage (there the K-column products run
+ * 16 or 32 for dense designs, f32 or f64 storage (there the K-column products run
  * on the matrix cores, v_mfma_f64_16x16x4_f64, 16 chains per B operand; the
- * first batch builds a transposed copy of the matrix, n x P x 4 bytes).  The batch borrows them:
+ * first batch builds a transposed copy of the matrix, as large as the matrix).  The batch borrows them:
  * set/get their state through the bbx_chain_* calls between runs, destroy the
  * batch before its chains.  The first batch of a width builds the matching
  * layout of the design (host pass, ~1 s at 1M x 50k). */

@@ -167,16 +167,18 @@ def test_batched_chain_on_a_mixed_design_and_resume():
         assert np.array_equal(joined, s[key]), key
 
 
-def _dense_problem(n, p, seed=2):
+def _dense_problem(n, p, seed=2, storage='float32'):
     from bayesbridge_amd import HipDenseDesignMatrix
     rng = np.random.default_rng(seed)
     # f32-representable entries: the f64 reference sees the stored numbers
-    X = rng.standard_normal((n, p)).astype(np.float32).astype(np.float64)
+    X = rng.standard_normal((n, p))
+    if storage == 'float32':
+        X = X.astype(np.float32).astype(np.float64)
     beta = np.zeros(p)
     beta[:5], beta[5:10] = 1.5, -1.
     y = X @ beta + rng.standard_normal(n)
     hip = HipDenseDesignMatrix(X, center_predictor=False, add_intercept=True,
-                               storage_dtype='float32')
+                               storage_dtype=storage)
     return X, y, hip
 
 
@@ -184,7 +186,8 @@ def _dense_problem(n, p, seed=2):
 @pytest.mark.parametrize("shape", [(5000, 700), (20000, 4500), (4097, 8190),
                                    (200003, 37), (140000, 21), (263000, 12),
                                    (37, 5), (64, 255)])
-def test_dense_batched_products_on_the_matrix_cores(K, shape):
+@pytest.mark.parametrize("storage", ['float32', 'float64'])
+def test_dense_batched_products_on_the_matrix_cores(K, shape, storage):
     """K-column dense products (dense_batch.hip: v_mfma_f64_16x16x4_f64, the
     chains in the 16 columns of the B operand) against NumPy in f64 on the
     stored f32 entries: <= 1e-11 of the result's scale (the reference's own
@@ -194,7 +197,9 @@ def test_dense_batched_products_on_the_matrix_cores(K, shape):
     (two sweeps) 9 row tiles -- the kernel is instantiated per tile count."""
     from bayesbridge_amd import HipChainBatch
     n, p = shape
-    X, y, hip = _dense_problem(n, p)
+    if storage == 'float64' and n * p > 5e7:
+        pytest.skip("one storage type is enough at this size")
+    X, y, hip = _dense_problem(n, p, storage=storage)
     batch = HipChainBatch(_chains(hip, y, 'linear', list(range(K))))
     rng = np.random.default_rng(9)
     P = p + 1
@@ -212,13 +217,14 @@ def test_dense_batched_products_on_the_matrix_cores(K, shape):
     assert np.abs(hip.Tdot(w[0]) - got_w[0]).max() <= 1e-11 * np.abs(ref_w).max()
 
 
+@pytest.mark.parametrize("storage", ['float32', 'float64'])
 @pytest.mark.parametrize("K", [2, 4, 8, 32])
-def test_a_dense_chain_does_not_depend_on_its_batch(K):
+def test_a_dense_chain_does_not_depend_on_its_batch(K, storage):
     """The dense counterpart of test_a_chain_does_not_depend_on_its_batch
     (32 chains: two B operands per pass; chain A moves from the first to the
     second group of 16)."""
     from bayesbridge_amd import HipChainBatch
-    X, y, hip = _dense_problem(6000, 400)
+    X, y, hip = _dense_problem(6000, 400, storage=storage)
     seeds_1 = ([17, 23, 31, 47, 3, 5, 7, 11] + list(range(100, 124)))[:K]
     seeds_2 = ([61, 17, 6, 9, 13, 19, 29, 37] + list(range(200, 224)))[:K]
     if K == 32:
