@@ -547,8 +547,9 @@ static size_t fused_ring_lds(int KQ, int RB, int D, int64_t rows_per_wg) {
 
 // Does the single-pass operator kernel apply to this design?
 bool dense_fused_applies(const bbx_design* h) {
-  // f64 storage: 8 registers per column group and row, one group per thread
-  const int64_t ld_max = h->dense_dtype == BBX_F32 ? 8192 : 4096;
+  // one or two column groups (4 columns each) per thread; with f64 storage two
+  // groups take 112 of the 128 registers
+  const int64_t ld_max = 8192;
   return !(h->sparse || h->dense_ld > ld_max || h->n < 4096);
 }
 
@@ -597,7 +598,7 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
                     (ring_env > 0 || rows_per_wg >= 64) &&
                     fused_ring_lds(2, 2, 2, rows_per_wg) <= 160 * 1024;
   if (h->dense_dtype != BBX_F32) {
-    BBX_FUSED_LAUNCH(double, 1, 2);
+    if (kq1) BBX_FUSED_LAUNCH(double, 1, 2); else BBX_FUSED_LAUNCH(double, 2, 2);
   } else if (ring) {
     if (kq1) BBX_RING_LAUNCH(1, 2, 2); else BBX_RING_LAUNCH(2, 2, 2);
   } else if (kq1) {

@@ -506,7 +506,8 @@ def main():
                 ceiling_gbs=round(probe_small[0], 1),
                 frac=round(ach / probe_small[0], 4) if probe_small[0] > 0
                 else None)
-        kernel_name = ("operator X^T(Omega(X v)), one pass (dense f32)"
+        kernel_name = ("operator X^T(Omega(X v)), one pass (dense %s)"
+                       % ("f32" if args.dense_storage == "float32" else "f64")
                        if dense and fused_b and dom == "dot"
                        else dom + " (" + design.storage_format + ")")
         roofline = dict(

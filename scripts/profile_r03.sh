@@ -19,7 +19,13 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/r03_write -- python3 script
 # products on their own
 { python3 scripts/bench_spmv.py config3 tiled 200; python3 scripts/bench_spmv.py config2 tiled 200; } 2>&1 | grep -E "tiled geometry|avg|max abs err" > $O/r03_spmv.txt
 { for k in 2 4; do python3 scripts/bench_batch_products.py config3 $k 20; done; } 2>&1 | grep avg > $O/r03_batch_products.txt
-{ for k in 4 8 16; do python3 scripts/bench_dense_batch.py 200000 8000 $k 5; done; } 2>&1 | grep avg > $O/r03_dense_batch.txt
+{ for k in 4 8 16 32; do python3 scripts/bench_dense_batch.py 200000 8000 $k 5; done; } 2>&1 | grep avg > $O/r03_dense_batch_new.txt   # prepended to profiles/r03_dense_batch.txt by hand (its history stays)
+python3 bench.py --config config4 --dense-storage float64 --steps 10 --warmup 3 --multi-chain-steps 6 --cpu-baseline-iters 0 > $O/r03_bench_config4_f64.json 2>> $O/r03_bench.err
+python3 scripts/bench_small_batches.py 2>&1 | grep -E "^dense|^sparse" > $O/r03_small_batches.txt
+BENCH_MIXED_PAIR=1 python3 scripts/bench_mixed.py 5 50 2>&1 | grep -E "pair products" > $O/r03_mixed_pair.txt
+bash scripts/dense_batch_traffic.sh > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/bt_trace -- python3 scripts/batch_timeline.py config3 2 360 > $O/bt.log 2>&1
+python3 scripts/batch_timeline.py --analyse $O/bt_trace > $O/r03_batch_timeline.txt; rm -rf $O/bt_trace
 { for c in 0 5 20 50; do python3 scripts/bench_mixed.py $c 100; done; python3 scripts/bench_mixed.py 20 100 0.02; } 2>&1 | grep -E "^all-binary|^mixed" > $O/r03_mixed.txt
 { for a in "1 1" "2 1" "1 2" "2 2"; do python3 scripts/overlap_probe.py $a 40; done; } 2>&1 | grep procs > $O/r03_overlap_probe.txt
 (cd scripts/probes && hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_f64_rate mfma_f64_rate.hip && /tmp/mfma_f64_rate) > $O/r03_mfma_f64_rate.txt 2>&1

@@ -284,3 +284,25 @@ def test_config4_batched_products_equal_the_single_chain_operator(full_dense, K)
     assert n_unconverged == 0
     assert np.all(samples['n_cg_iter'] > 0)
     assert len(np.unique(samples['logp'][:, -1])) == K
+
+
+@pytest.mark.parametrize("shape", [(9000, 3000), (12345, 5001), (4100, 8100)])
+def test_single_pass_operator_with_f64_storage(shape):
+    """dense_fused_kernel<double, KQ, 2> (one and two column groups per thread:
+    up to 8192 stored columns) against the two separate products and NumPy."""
+    from bayesbridge_amd import HipDenseDesignMatrix
+    n, p = shape
+    rng = np.random.default_rng(31)
+    X = rng.standard_normal((n, p))
+    hip = HipDenseDesignMatrix(X, center_predictor=True, add_intercept=True,
+                               storage_dtype='float64')
+    assert hip.fused_operator_bytes > 0
+    v, omega = rng.standard_normal(p + 1), rng.gamma(2., .5, n)
+    hip.reset_matvec_count()
+    fused = hip.gram_matvec(omega, v)
+    assert hip.get_dot_count() == (1, 1)
+    two = hip.Tdot(omega * hip.dot(v))
+    assert np.abs(fused - two).max() <= 1e-11 * np.abs(two).max()
+    Xi = np.hstack([np.ones((n, 1)), X - X.mean(axis=0)])
+    ref = Xi.T @ (omega * (Xi @ v))
+    assert np.abs(fused - ref).max() <= 1e-10 * np.abs(ref).max()
