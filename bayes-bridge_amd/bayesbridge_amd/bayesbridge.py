@@ -256,6 +256,18 @@ class BayesBridge():
             # tiles too far (0.99x against 1.32x; profiles/r03_small_batches.txt)
             widths = (4, 2) if design.nnz <= 3e7 else (2,)
         else:
+            # the first batch on a dense design builds a transposed copy of
+            # the matrix: it has to fit next to the matrix itself
+            try:
+                import torch
+                free, _ = torch.cuda.mem_get_info(design.device)
+                n_, P_ = design.shape
+                el = 4 if design.storage_dtype == 'float32' else 8
+                have_copy = design.storage_bytes > 1.9 * n_ * P_ * el
+                if not have_copy and free < 1.1 * n_ * P_ * el + (1 << 30):
+                    return 0
+            except Exception:
+                pass
             widths = (32, 16, 8, 4)
         for w in widths:
             if w <= n_chain:
