@@ -44,6 +44,14 @@ def test_single_gpu_line_has_roofline_and_both_cpu_baselines():
         assert b["sample"].startswith("5 Gibbs iterations")
     assert line["cpu_baseline"]["kind"] == "port"
     assert line["cpu_baseline_omp"]["kind"] == "port-omp"
+    assert line["cpu_baseline_omp"]["dot_gbs"] > 0
+    # k chains per GPU sharing the passes over X; `value` stays the one-chain rate
+    mc = line["multi_chain"]
+    assert abs(mc["k=1"]["chain_iters_per_sec"] - line["value"]) < 1e-2 * line["value"]
+    for k in ("k=2", "k=4"):
+        assert mc[k]["chain_iters_per_sec"] > 0 and mc[k]["vs_k1"] > 0
+        assert mc[k]["dot"]["bytes"] > 0 and mc[k]["tdot"]["launches"] > 0
+    assert line["config"]["startup_s"] > 0 and line["config"]["peak_host_rss_mb"] > 0
 
 
 def test_gpus_2_launches_two_ranks_by_itself():
