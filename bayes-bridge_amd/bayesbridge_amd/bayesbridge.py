@@ -224,8 +224,9 @@ class BayesBridge():
     def batch_width(self, n_chain, params_to_save=('coef', 'global_scale',
                                                    'logp'), options=None):
         """How many of `n_chain` chains one batch can hold on this model's
-        design (0: batching does not apply or does not pay): all-binary sparse
-        tiled designs 4 while they are small, else 2 (designs with stored
+        design (0: batching does not apply or does not pay): sparse tiled
+        designs of binary covariates (plus, possibly, dense continuous columns)
+        4 while they are small, else 2 (designs with other stored
         values can be batched explicitly -- HipChainBatch -- but run faster one
         chain at a time), dense
         designs (f32 or f64 storage) 4, 8, 16 or 32 (the batched dense products read the matrix twice
@@ -245,10 +246,13 @@ class BayesBridge():
         if design.is_sparse:
             if design.storage_format != 'tiled':
                 return 0
-            if design.hybrid_info is not None or not design.is_binary:
-                # designs with stored values (mixed ones included) batch
-                # through the plain valued K-layout: measured 2x SLOWER than
-                # two chains one after the other on the split layout
+            hy = design.hybrid_info
+            if not design.is_binary and (hy is None or hy['rest_nnz'] > 0):
+                # stored values outside dense continuous columns: the batch
+                # would go through the plain valued K-layout, measured 2x
+                # SLOWER than two chains one after the other.  (Binary
+                # covariates plus dense continuous columns keep their split
+                # layout in a batch: value-free K-layout + the dense block.)
                 return 0
             # four chains per pass pay while the design is small (fixed costs
             # per launch dominate: 1.4-1.9x at 5k x 500 ... 100k x 10k against

@@ -665,7 +665,7 @@ int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,
   if (!h->sparse && !dense_batch_applies(h))
     return fail(BBX_ERR_STATE,
                 "batched chains: this dense layout is not supported");
-  if (h->sparse && !h->binary && n_chain > 2)
+  if (h->sparse && !tiled_batch_value_free(h) && n_chain > 2)
     return fail(BBX_ERR_INVALID,
                 "designs with stored values batch at most 2 chains (four valued "
                 "right-hand sides exceed the kernel's register budget)");

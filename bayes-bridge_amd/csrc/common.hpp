@@ -340,6 +340,7 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
 bool dense_fused_applies(const bbx_design* h);
 int build_tiled(bbx_design* h);
 void destroy_tiled(bbx_design* h);
+bool tiled_batch_value_free(const bbx_design* h);  // batches of any width (else pairs only)
 int ensure_tiled_k(bbx_design* h, int K);
 // Per-chain arguments of a batched launch of the tiled kernels (K > 1).
 struct TiledBatchArgs {

@@ -128,6 +128,12 @@ struct HybridParts {
   DevMem d_part;         // double[HYB_TDOT_CHUNKS][kd]: partial sums of D^T w
   DevMem slab;           // double[(G_B + G_S + 1)][p]
   int n_slab = 0;
+  // batches (K = 2, 4 right-hand sides) of a design WITHOUT a valued rest keep
+  // the split: B in its K-layout (bbx_design::tiled_k), D shared
+  bool split_k[2] = {false, false};   // slot K == 2, K == 4
+  DevMem addend_k;       // double[n][K]
+  DevMem d_part_k;       // double[HYB_TDOT_CHUNKS][kd][K]
+  DevMem slab_k[2];      // double[(G_B_k + 1)][p][K]
 };
 
 // ------------------------------------------------------------------ kernel
@@ -634,7 +640,9 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
               const int c = 2 * q + hh;
-              const double t = cc[c] + (hh ? a.y : a.x);
+              double t = cc[c] + (hh ? a.y : a.x);
+              // mixed designs: the dense block's product, interleaved [n][K]
+              if (addend) t += addend[(int64_t)(row0 + r) * K + c];
               double v = t;
               if (rowscale_k.p[c]) v *= rs_pre[u][c];
               out_k.p[c][(row0 + r) * out_stride] = v;
@@ -1072,6 +1080,52 @@ int build_tiled(bbx_design* h) {
   return BBX_OK;
 }
 
+// K-layout of a mixed design WITHOUT a valued rest: the value-free part B in
+// its K-layout, the dense block D as it is (HybridParts).
+static int build_split_k(bbx_design* h, int K, void** slot) {
+  HybridParts* hp = static_cast<HybridParts*>(h->hybrid);
+  const int64_t n = h->n, p = h->p;
+  const int ks = K == 2 ? 0 : 1;
+  TiledPair* tp = new (std::nothrow) TiledPair();
+  if (!tp) return fail(BBX_ERR_INVALID, "out of host memory");
+  *slot = tp;  // owned by the handle from here on (destroy_tiled)
+  std::vector<uint8_t> is_dense((size_t)p, 0);
+  if (hp->kd > 0) {
+    std::vector<int32_t> cols((size_t)hp->kd);
+    BBX_HIP(hipMemcpy(cols.data(), hp->dense_cols.ptr, sizeof(int32_t) * cols.size(),
+                      hipMemcpyDeviceToHost));
+    for (int32_t j : cols) is_dense[(size_t)j] = 1;
+  }
+  HostCsr c, ones, rest;
+  BBX_TRY(fetch_host_csr(h, false, &c));
+  split_rows(n, c, false, is_dense, &ones, &rest);
+  BBX_TRY(build_one(tp->x, n, p, hp->ones_nnz, ones.rowptr.data(),
+                    ones.colidx.data(), nullptr, false, K));
+  BBX_TRY(fetch_host_csr(h, true, &c));
+  split_rows(p, c, true, is_dense, &ones, &rest);
+  BBX_TRY(build_one(tp->xt, p, n, hp->ones_nnz, ones.rowptr.data(),
+                    ones.colidx.data(), nullptr, true, K));
+  BBX_TRY(check_lds(tp));
+  const size_t slab_bytes = sizeof(double) * (size_t)(tp->xt.G + 1) * (size_t)p * (size_t)K;
+  BBX_TRY(hp->slab_k[ks].alloc(slab_bytes));
+  BBX_HIP(hipMemset(hp->slab_k[ks].ptr, 0, slab_bytes));
+  if (hp->addend_k.bytes < sizeof(double) * (size_t)n * 4)
+    BBX_TRY(hp->addend_k.alloc(sizeof(double) * (size_t)n * 4));
+  if (hp->kd > 0 &&
+      hp->d_part_k.bytes < sizeof(double) * HYB_TDOT_CHUNKS * (size_t)hp->kd * 4)
+    BBX_TRY(hp->d_part_k.alloc(sizeof(double) * HYB_TDOT_CHUNKS * (size_t)hp->kd * 4));
+  hp->split_k[ks] = true;
+  return BBX_OK;
+}
+
+// Does a batch on this design run through value-free kernels (any width), or
+// through the valued ones (pairs only)?
+bool tiled_batch_value_free(const bbx_design* h) {
+  if (h->binary) return true;
+  const HybridParts* hp = static_cast<const HybridParts*>(h->hybrid);
+  return hp && hp->rest_nnz == 0;
+}
+
 // The layout sized for K right-hand sides (K = 2, 4), built on first use.
 int ensure_tiled_k(bbx_design* h, int K) {
   // (a mixed design's K-layout is the plain valued one of the whole matrix)
@@ -1081,7 +1135,10 @@ int ensure_tiled_k(bbx_design* h, int K) {
   if (K != 2 && K != 4) return fail(BBX_ERR_INVALID, "K must be 1, 2 or 4");
   void** slot = &h->tiled_k[K == 2 ? 0 : 1];
   if (*slot) return BBX_OK;
-  const int st = build_tiled_pair(h, K, slot);
+  HybridParts* hp = static_cast<HybridParts*>(h->hybrid);
+  const int st = (hp && hp->rest_nnz == 0)
+                     ? no_throw([&]() -> int { return build_split_k(h, K, slot); })
+                     : build_tiled_pair(h, K, slot);
   if (st < 0) {
     delete static_cast<TiledPair*>(*slot);
     *slot = nullptr;
@@ -1274,6 +1331,82 @@ __global__ __launch_bounds__(WAVE) void hyb_dense_scatter_kernel(
   if (threadIdx.x == 0) slab_row[dense_cols[j]] = a;
 }
 
+// ---- the same for K interleaved right-hand sides (designs without a valued
+// rest): addend[i][c] = sum_j D[j][i] v[intercept + dense_cols[j]][c]
+template <int K>
+__global__ __launch_bounds__(256) void hyb_addend_k_kernel(
+    int64_t n, int kd, int intercept, const double* __restrict__ D,
+    const int32_t* __restrict__ dense_cols, const double* __restrict__ v_il,
+    double* __restrict__ addend, const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  extern __shared__ double s_v[];   // [kd][K]
+  for (int t = threadIdx.x; t < kd * K; t += 256)
+    s_v[t] = v_il[(int64_t)(intercept + dense_cols[t / K]) * K + (t % K)];
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * 256) {
+    double a[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) a[c] = 0.;
+    for (int j = 0; j < kd; ++j) {
+      const double d = D[(int64_t)j * n + i];
+#pragma unroll
+      for (int c = 0; c < K; ++c) a[c] += d * s_v[j * K + c];
+    }
+#pragma unroll
+    for (int c = 0; c < K; ++c) addend[i * K + c] = a[c];
+  }
+}
+
+// part[(chunk kd + j) K + c] = sum over the chunk's rows of D[j][i] w[i][c]:
+// one wave per (column, chunk)
+template <int K>
+__global__ __launch_bounds__(256) void hyb_dense_tdot_k_kernel(
+    int64_t n, int kd, int n_chunk, const double* __restrict__ D,
+    const double* __restrict__ w_il, double* __restrict__ part,
+    const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t task = (int64_t)blockIdx.x * (256 / WAVE) + threadIdx.x / WAVE;
+  if (task >= (int64_t)kd * n_chunk) return;
+  const int j = (int)(task / n_chunk), ch = (int)(task - (int64_t)j * n_chunk);
+  const int64_t rows = (n + n_chunk - 1) / n_chunk;
+  const int64_t r0 = (int64_t)ch * rows;
+  const int64_t r1 = (r0 + rows < n) ? r0 + rows : n;
+  const double* __restrict__ Dj = D + (int64_t)j * n;
+  double a[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) a[c] = 0.;
+  for (int64_t i = r0 + lane; i < r1; i += WAVE) {
+    const double d = Dj[i];
+#pragma unroll
+    for (int c = 0; c < K; ++c) a[c] += d * w_il[i * K + c];
+  }
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    const double t = wave_allsum(a[c]);
+    if (lane == 0) part[((int64_t)ch * kd + j) * K + c] = t;
+  }
+}
+
+// slab_row[dense_cols[j]][c] = sum over the chunks, fixed order
+template <int K>
+__global__ __launch_bounds__(WAVE) void hyb_dense_scatter_k_kernel(
+    int kd, int n_chunk, const int32_t* __restrict__ dense_cols,
+    const double* __restrict__ part, double* __restrict__ slab_row,
+    const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  const int j = blockIdx.x;
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    double a = 0.;
+    for (int ch = threadIdx.x; ch < n_chunk; ch += WAVE)
+      a += part[((int64_t)ch * kd + j) * K + c];
+    a = wave_allsum(a);
+    if (threadIdx.x == 0) slab_row[(int64_t)dense_cols[j] * K + c] = a;
+  }
+}
+
 static int launch_dot_hybrid(bbx_design* h, const double* d_v,
                              const double* d_rowscale, double* d_t,
                              double* d_sum_part, int* sum_done,
@@ -1432,7 +1565,8 @@ __global__ __launch_bounds__(256) void tiled_dot_finalize_k_kernel(
     int64_t R, int G, const double* __restrict__ slab,
     const double* __restrict__ c_part, const double* x0_ptr,
     ChainPtrs rowscale, ChainOut out, int out_stride, int part_stride,
-    double* __restrict__ sum_part, int twt_off) {
+    double* __restrict__ sum_part, int twt_off,
+    const double* __restrict__ addend) {
   __shared__ double s_c[K];
   __shared__ double s_w[2 * K][256 / WAVE];
   if (threadIdx.x < K) {
@@ -1454,6 +1588,7 @@ __global__ __launch_bounds__(256) void tiled_dot_finalize_k_kernel(
     for (int c = 0; c < K; ++c) {
       double a = 0.;
       for (int g = 0; g < G; ++g) a += slab[((int64_t)g * R + r) * K + c];
+      if (addend) a += addend[r * K + c];
       const double t = s_c[c] + a;
       double v = t;
       if (rowscale.p[c]) v *= rowscale.p[c][r];
@@ -1492,11 +1627,28 @@ int launch_dot_tiled_k(bbx_design* h, int K, const double* d_v,
   const double* x = d_v + (size_t)h->intercept * K;
   const double* x0 = h->intercept ? d_v : nullptr;
   h->n_dot += 1;
+  // mixed design kept split: the dense block's product first, the value-free
+  // kernel's epilogue adds it
+  HybridParts* hp = static_cast<HybridParts*>(h->hybrid);
+  const bool split = hp && hp->split_k[K == 2 ? 0 : 1];
+  const double* addend = nullptr;
+  if (split && hp->kd > 0) {
+    const size_t lds = sizeof(double) * (size_t)hp->kd * (size_t)K;
+#define BBX_ADDEND_K(KK)                                                       \
+  hipLaunchKernelGGL(hyb_addend_k_kernel<KK>, dim3(1024), dim3(256), lds,      \
+                     h->stream, h->n, hp->kd, h->intercept, hp->D.as<double>(), \
+                     hp->dense_cols.as<int32_t>(), d_v,                        \
+                     hp->addend_k.as<double>(), h->skip_flag)
+    if (K == 2) BBX_ADDEND_K(2); else BBX_ADDEND_K(4);
+#undef BBX_ADDEND_K
+    BBX_HIP(hipGetLastError());
+    addend = hp->addend_k.as<double>();
+  }
   if (m.G == 1 && m.n_panel <= NPART) {
     hipEvent_t ea, eb;
     BBX_TRY(timer_arm(h, 0, &ea, &eb));
     return launch_tiled(h, m, x, d_c_part, x0, nullptr, nullptr, nullptr,
-                        d_sum_part, ea, eb, twt_off, &ba);
+                        d_sum_part, ea, eb, twt_off, &ba, addend);
   }
   // several column groups (or more panels than partial slots): slabs, then
   // the finalize kernel
@@ -1510,7 +1662,7 @@ int launch_dot_tiled_k(bbx_design* h, int K, const double* d_v,
   hipLaunchKernelGGL(tiled_dot_finalize_k_kernel<KK>, dim3(NPART), dim3(256),  \
                      0, h->stream, m.R, m.G, m.slab.as<double>(), d_c_part,    \
                      x0, ba.rowscale, ba.out, ba.out_stride, ba.part_stride,   \
-                     d_sum_part, twt_off)
+                     d_sum_part, twt_off, addend)
   if (K == 2) BBX_DOT_FIN(2); else BBX_DOT_FIN(4);
 #undef BBX_DOT_FIN
   BBX_HIP(hipGetLastError());
@@ -1526,6 +1678,38 @@ int launch_tdot_tiled_k(bbx_design* h, int K, const double* d_w,
   hipEvent_t ea, eb;
   BBX_TRY(timer_arm(h, 1, &ea, &eb));
   TiledBatchArgs none;
+  HybridParts* hp = static_cast<HybridParts*>(h->hybrid);
+  const int ks = K == 2 ? 0 : 1;
+  if (hp && hp->split_k[ks]) {
+    // mixed design kept split: B's slabs, then one more slab for D^T W
+    double* sl = hp->slab_k[ks].as<double>();
+    BBX_TRY(launch_tiled(h, m, d_w, nullptr, nullptr, nullptr, nullptr, sl,
+                         nullptr, ea, eb, 0, &none));
+    int at = m.G;
+    if (hp->kd > 0) {
+      const int64_t n_task = (int64_t)hp->kd * HYB_TDOT_CHUNKS;
+      double* row = sl + (size_t)at * (size_t)h->p * (size_t)K;
+#define BBX_DENSE_TDOT_K(KK)                                                   \
+  do {                                                                         \
+    hipLaunchKernelGGL(hyb_dense_tdot_k_kernel<KK>,                            \
+                       dim3((unsigned)((n_task + 3) / 4)), dim3(256), 0,       \
+                       h->stream, h->n, hp->kd, HYB_TDOT_CHUNKS,               \
+                       hp->D.as<double>(), d_w, hp->d_part_k.as<double>(),     \
+                       h->skip_flag);                                          \
+    hipLaunchKernelGGL(hyb_dense_scatter_k_kernel<KK>, dim3((unsigned)hp->kd), \
+                       dim3(WAVE), 0, h->stream, hp->kd, HYB_TDOT_CHUNKS,      \
+                       hp->dense_cols.as<int32_t>(),                           \
+                       hp->d_part_k.as<double>(), row, h->skip_flag);          \
+  } while (0)
+      if (K == 2) BBX_DENSE_TDOT_K(2); else BBX_DENSE_TDOT_K(4);
+#undef BBX_DENSE_TDOT_K
+      BBX_HIP(hipGetLastError());
+      at += 1;
+    }
+    *slab = sl;
+    *G = at;
+    return BBX_OK;
+  }
   BBX_TRY(launch_tiled(h, m, d_w, nullptr, nullptr, nullptr, nullptr,
                        m.slab.as<double>(), nullptr, ea, eb, 0, &none));
   *slab = m.slab.as<double>();
@@ -1544,6 +1728,13 @@ int tiled_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
                (tp->x.G > 1 ? 16 * (int64_t)K * tp->x.G * h->n : 0);
   *tdot_bytes = tp->xt.stream_bytes() + 8 * (int64_t)K * h->n +
                 8 * (int64_t)K * tp->xt.G * h->p;
+  const HybridParts* hp = static_cast<const HybridParts*>(h->hybrid);
+  if (hp && hp->split_k[K == 2 ? 0 : 1]) {
+    // the dense block once per product, the addend written and read back
+    const int64_t dense = 8 * (int64_t)hp->kd * h->n;
+    *dot_bytes += dense + 16 * (int64_t)K * h->n;
+    *tdot_bytes += dense + 8 * (int64_t)K * h->n;
+  }
   return BBX_OK;
 }
 

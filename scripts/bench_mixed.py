@@ -70,9 +70,29 @@ for label, X in (("all-binary", Xb if valued_frac == 0 else None),
             batch.dot(V)
             batch.Tdot(W)
         t = d.get_timing()
-        print("%-10s pair products: dot %.4f ms, tdot %.4f ms (both chains), "
-              "rel err vs single %.1e" % (label, t['dot'][1] / t['dot'][0],
-                                          t['tdot'][1] / t['tdot'][0], errk))
-        del batch, chains
+        print("%-10s pair products: dot %.4f ms, tdot %.4f ms (both chains; "
+              "the tiled kernels only: the dense block's kernels run outside the "
+              "timers), rel err vs single %.1e"
+              % (label, t['dot'][1] / t['dot'][0], t['tdot'][1] / t['tdot'][0], errk))
+        # whole Gibbs iterations: one chain against the pair
+        d.set_timing(False)
+        for ch in chains:
+            ch.set_state(global_scale=.01)
+            ch.init_obs_prec()
+        one = HipGibbsChain(d, 'logit', y, n_trial=np.ones(nn), seed=9)
+        one.set_state(global_scale=.01)
+        one.init_obs_prec()
+        one.run(60, save=())
+        t1 = time.time()
+        r1 = one.run(40, save=())[0]
+        t1 = time.time() - t1
+        batch.run(60, save_coef=False)
+        t2 = time.time()
+        r2 = batch.run(40, save_coef=False)[0]
+        t2 = time.time() - t2
+        print("%-10s one chain %.1f it/s (n_cg %.1f); pair %.1f chain-it/s = %.2fx "
+              "(n_cg %.1f)" % (label, 40 / t1, r1['n_cg_iter'].mean(), 80 / t2,
+                               80 / t2 / (40 / t1), r2['n_cg_iter'].mean()))
+        del batch, chains, one
     d.close() if hasattr(d, 'close') else None
     del d
