@@ -124,7 +124,6 @@ struct HybridParts {
   DevMem dense_cols;     // int32[kd]: column of X (0-based, without intercept)
   DevMem D;              // double[kd][n], column-major
   DevMem addend;         // double[n]
-  DevMem v_dense;        // double[kd]
   DevMem d_part;         // double[HYB_TDOT_CHUNKS][kd]: partial sums of D^T w
   DevMem slab;           // double[(G_B + G_S + 1)][p]
   int n_slab = 0;
@@ -1034,7 +1033,6 @@ static int build_hybrid(bbx_design* h) {
     BBX_TRY(upload(hp->D, D.data(), D.size() * sizeof(double)));
     BBX_TRY(upload(hp->dense_cols, dense_cols.data(),
                    dense_cols.size() * sizeof(int32_t)));
-    BBX_TRY(hp->v_dense.alloc(sizeof(double) * (size_t)hp->kd));
     BBX_TRY(hp->d_part.alloc(sizeof(double) * HYB_TDOT_CHUNKS * (size_t)hp->kd));
   }
   {  // transposed orientation of B and S
@@ -1247,23 +1245,16 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
 
 // ---- mixed designs (HybridParts): the small kernels around the tiled ones
 
-// v_dense[j] = v[intercept + dense_cols[j]]
-__global__ void hyb_gather_kernel(int kd, int intercept,
-                                  const int32_t* __restrict__ dense_cols,
-                                  const double* __restrict__ v,
-                                  double* __restrict__ v_dense) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < kd) v_dense[j] = v[intercept + dense_cols[j]];
-}
-
-// addend[i] = sum_g rest_slab[g][i] + sum_j D[j][i] v_dense[j]   (fixed order)
+// addend[i] = sum_g rest_slab[g][i] + sum_j D[j][i] v[intercept + dense_cols[j]]
+// (fixed order)
 __global__ __launch_bounds__(256) void hyb_addend_kernel(
-    int64_t n, int kd, const double* __restrict__ D,
-    const double* __restrict__ v_dense, const double* __restrict__ rest_slab,
-    int G_rest, double* __restrict__ addend, const int* __restrict__ skip_flag) {
+    int64_t n, int kd, int intercept, const double* __restrict__ D,
+    const int32_t* __restrict__ dense_cols, const double* __restrict__ v,
+    const double* __restrict__ rest_slab, int G_rest,
+    double* __restrict__ addend, const int* __restrict__ skip_flag) {
   if (skip_flag && *skip_flag) return;
   extern __shared__ double s_v[];
-  for (int j = threadIdx.x; j < kd; j += 256) s_v[j] = v_dense[j];
+  for (int j = threadIdx.x; j < kd; j += 256) s_v[j] = v[intercept + dense_cols[j]];
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * 256) {
@@ -1424,15 +1415,11 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
     rest_slab = ms.slab.as<double>();
     G_rest = ms.G;
   }
-  if (hp->kd > 0)
-    hipLaunchKernelGGL(hyb_gather_kernel, dim3((hp->kd + 255) / 256), dim3(256),
-                       0, h->stream, hp->kd, h->intercept,
-                       hp->dense_cols.as<int32_t>(), d_v,
-                       hp->v_dense.as<double>());
   hipLaunchKernelGGL(hyb_addend_kernel, dim3(1024), dim3(256),
                      sizeof(double) * (size_t)(hp->kd + 1), h->stream, h->n,
-                     hp->kd, hp->D.as<double>(), hp->v_dense.as<double>(),
-                     rest_slab, G_rest, hp->addend.as<double>(), h->skip_flag);
+                     hp->kd, h->intercept, hp->D.as<double>(),
+                     hp->dense_cols.as<int32_t>(), d_v, rest_slab, G_rest,
+                     hp->addend.as<double>(), h->skip_flag);
   BBX_HIP(hipGetLastError());
   const TiledMatrix& mb = hp->ones.x;
   if (mb.G > 1 || mb.n_panel > NPART) {
@@ -1468,6 +1455,10 @@ static int launch_tdot_hybrid(bbx_design* h, const double* d_w,
   HybridParts* hp = static_cast<HybridParts*>(h->hybrid);
   double* slab = hp->slab.as<double>();
   BBX_TRY(timer_begin(h, 1));
+  // (The dense block's kernels on a second stream, beside the tiled kernel,
+  // were measured: 65 -> 80 us with five dense columns, 102 -> 175 us with
+  // twenty -- they take CUs the one-workgroup-per-CU tiled kernel then waits
+  // for.  So: one stream, the tiled kernels first.)
   const TiledMatrix& mb = hp->ones.xt;
   BBX_TRY(launch_tiled(h, mb, d_w, nullptr, nullptr, nullptr, nullptr, slab,
                        nullptr));
