@@ -247,13 +247,14 @@ class BayesBridge():
             if design.storage_format != 'tiled':
                 return 0
             hy = design.hybrid_info
-            if not design.is_binary and (hy is None or hy['rest_nnz'] > 0):
-                # stored values outside dense continuous columns: the batch
-                # would go through the plain valued K-layout, measured 2x
-                # SLOWER than two chains one after the other.  (Binary
-                # covariates plus dense continuous columns keep their split
-                # layout in a batch: value-free K-layout + the dense block.)
+            if not design.is_binary and hy is None:
+                # stored values throughout: the batch would go through the
+                # plain valued K-layout, slower than two chains one after the
+                # other.  (Mixed designs keep their split layout in a batch:
+                # value-free K-layout + dense block + valued rest.)
                 return 0
+            if hy is not None and hy['rest_nnz'] > 0:
+                return 2 if n_chain >= 2 else 0    # valued kernels: pairs only
             # four chains per pass pay while the design is small (fixed costs
             # per launch dominate: 1.4-1.9x at 5k x 500 ... 100k x 10k against
             # 1.1-1.5x for pairs); at 1M x 50k the four planes shrink the LDS

@@ -130,6 +130,8 @@ struct HybridParts {
   // batches (K = 2, 4 right-hand sides) of a design WITHOUT a valued rest keep
   // the split: B in its K-layout (bbx_design::tiled_k), D shared
   bool split_k[2] = {false, false};   // slot K == 2, K == 4
+  TiledPair* rest_k = nullptr;        // S in its K = 2 layout (pairs only), or null
+  ~HybridParts() { delete rest_k; }
   DevMem addend_k;       // double[n][K]
   DevMem d_part_k;       // double[HYB_TDOT_CHUNKS][kd][K]
   DevMem slab_k[2];      // double[(G_B_k + 1)][p][K]
@@ -1078,8 +1080,8 @@ int build_tiled(bbx_design* h) {
   return BBX_OK;
 }
 
-// K-layout of a mixed design WITHOUT a valued rest: the value-free part B in
-// its K-layout, the dense block D as it is (HybridParts).
+// K-layout of a mixed design: the value-free part B in its K-layout, the dense
+// block D as it is, the valued rest S (if any; pairs only) in its K-layout.
 static int build_split_k(bbx_design* h, int K, void** slot) {
   HybridParts* hp = static_cast<HybridParts*>(h->hybrid);
   const int64_t n = h->n, p = h->p;
@@ -1099,12 +1101,27 @@ static int build_split_k(bbx_design* h, int K, void** slot) {
   split_rows(n, c, false, is_dense, &ones, &rest);
   BBX_TRY(build_one(tp->x, n, p, hp->ones_nnz, ones.rowptr.data(),
                     ones.colidx.data(), nullptr, false, K));
+  if (hp->rest_nnz > 0) {
+    if (K != 2) return fail(BBX_ERR_INVALID, "valued designs batch at most 2 chains");
+    if (!hp->rest_k) hp->rest_k = new (std::nothrow) TiledPair();
+    if (!hp->rest_k) return fail(BBX_ERR_INVALID, "out of host memory");
+    BBX_TRY(build_one(hp->rest_k->x, n, p, hp->rest_nnz, rest.rowptr.data(),
+                      rest.colidx.data(), rest.vals.data(), false, K));
+  }
   BBX_TRY(fetch_host_csr(h, true, &c));
   split_rows(p, c, true, is_dense, &ones, &rest);
   BBX_TRY(build_one(tp->xt, p, n, hp->ones_nnz, ones.rowptr.data(),
                     ones.colidx.data(), nullptr, true, K));
+  int G_rest = 0;
+  if (hp->rest_nnz > 0) {
+    BBX_TRY(build_one(hp->rest_k->xt, p, n, hp->rest_nnz, rest.rowptr.data(),
+                      rest.colidx.data(), rest.vals.data(), true, K));
+    BBX_TRY(check_lds(hp->rest_k));
+    G_rest = hp->rest_k->xt.G;
+  }
   BBX_TRY(check_lds(tp));
-  const size_t slab_bytes = sizeof(double) * (size_t)(tp->xt.G + 1) * (size_t)p * (size_t)K;
+  const size_t slab_bytes =
+      sizeof(double) * (size_t)(tp->xt.G + G_rest + 1) * (size_t)p * (size_t)K;
   BBX_TRY(hp->slab_k[ks].alloc(slab_bytes));
   BBX_HIP(hipMemset(hp->slab_k[ks].ptr, 0, slab_bytes));
   if (hp->addend_k.bytes < sizeof(double) * (size_t)n * 4)
@@ -1134,7 +1151,7 @@ int ensure_tiled_k(bbx_design* h, int K) {
   void** slot = &h->tiled_k[K == 2 ? 0 : 1];
   if (*slot) return BBX_OK;
   HybridParts* hp = static_cast<HybridParts*>(h->hybrid);
-  const int st = (hp && hp->rest_nnz == 0)
+  const int st = (hp && (hp->rest_nnz == 0 || K == 2))
                      ? no_throw([&]() -> int { return build_split_k(h, K, slot); })
                      : build_tiled_pair(h, K, slot);
   if (st < 0) {
@@ -1322,12 +1339,13 @@ __global__ __launch_bounds__(WAVE) void hyb_dense_scatter_kernel(
   if (threadIdx.x == 0) slab_row[dense_cols[j]] = a;
 }
 
-// ---- the same for K interleaved right-hand sides (designs without a valued
-// rest): addend[i][c] = sum_j D[j][i] v[intercept + dense_cols[j]][c]
+// ---- the same for K interleaved right-hand sides: addend[i][c] =
+// sum_g rest_slab[g][i][c] + sum_j D[j][i] v[intercept + dense_cols[j]][c]
 template <int K>
 __global__ __launch_bounds__(256) void hyb_addend_k_kernel(
     int64_t n, int kd, int intercept, const double* __restrict__ D,
     const int32_t* __restrict__ dense_cols, const double* __restrict__ v_il,
+    const double* __restrict__ rest_slab, int G_rest,
     double* __restrict__ addend, const int* __restrict__ skip_flag) {
   if (skip_flag && *skip_flag) return;
   extern __shared__ double s_v[];   // [kd][K]
@@ -1339,6 +1357,10 @@ __global__ __launch_bounds__(256) void hyb_addend_k_kernel(
     double a[K];
 #pragma unroll
     for (int c = 0; c < K; ++c) a[c] = 0.;
+    for (int g = 0; g < G_rest; ++g) {
+#pragma unroll
+      for (int c = 0; c < K; ++c) a[c] += rest_slab[((int64_t)g * n + i) * K + c];
+    }
     for (int j = 0; j < kd; ++j) {
       const double d = D[(int64_t)j * n + i];
 #pragma unroll
@@ -1623,12 +1645,24 @@ int launch_dot_tiled_k(bbx_design* h, int K, const double* d_v,
   HybridParts* hp = static_cast<HybridParts*>(h->hybrid);
   const bool split = hp && hp->split_k[K == 2 ? 0 : 1];
   const double* addend = nullptr;
-  if (split && hp->kd > 0) {
-    const size_t lds = sizeof(double) * (size_t)hp->kd * (size_t)K;
+  if (split && (hp->kd > 0 || hp->rest_nnz > 0)) {
+    const double* rest_slab = nullptr;
+    int G_rest = 0;
+    if (hp->rest_nnz > 0) {
+      const TiledMatrix& ms = hp->rest_k->x;
+      TiledBatchArgs slab_rest = ba;
+      slab_rest.out = ChainOut{};
+      BBX_TRY(launch_tiled(h, ms, x, nullptr, nullptr, nullptr, nullptr,
+                           ms.slab.as<double>(), nullptr, nullptr, nullptr, 0,
+                           &slab_rest));
+      rest_slab = ms.slab.as<double>();
+      G_rest = ms.G;
+    }
+    const size_t lds = sizeof(double) * (size_t)(hp->kd * K + 1);
 #define BBX_ADDEND_K(KK)                                                       \
   hipLaunchKernelGGL(hyb_addend_k_kernel<KK>, dim3(1024), dim3(256), lds,      \
                      h->stream, h->n, hp->kd, h->intercept, hp->D.as<double>(), \
-                     hp->dense_cols.as<int32_t>(), d_v,                        \
+                     hp->dense_cols.as<int32_t>(), d_v, rest_slab, G_rest,     \
                      hp->addend_k.as<double>(), h->skip_flag)
     if (K == 2) BBX_ADDEND_K(2); else BBX_ADDEND_K(4);
 #undef BBX_ADDEND_K
@@ -1677,6 +1711,13 @@ int launch_tdot_tiled_k(bbx_design* h, int K, const double* d_w,
     BBX_TRY(launch_tiled(h, m, d_w, nullptr, nullptr, nullptr, nullptr, sl,
                          nullptr, ea, eb, 0, &none));
     int at = m.G;
+    if (hp->rest_nnz > 0) {
+      const TiledMatrix& ms = hp->rest_k->xt;
+      BBX_TRY(launch_tiled(h, ms, d_w, nullptr, nullptr, nullptr, nullptr,
+                           sl + (size_t)at * (size_t)h->p * (size_t)K, nullptr,
+                           nullptr, nullptr, 0, &none));
+      at += ms.G;
+    }
     if (hp->kd > 0) {
       const int64_t n_task = (int64_t)hp->kd * HYB_TDOT_CHUNKS;
       double* row = sl + (size_t)at * (size_t)h->p * (size_t)K;
@@ -1725,6 +1766,10 @@ int tiled_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
     const int64_t dense = 8 * (int64_t)hp->kd * h->n;
     *dot_bytes += dense + 16 * (int64_t)K * h->n;
     *tdot_bytes += dense + 8 * (int64_t)K * h->n;
+    if (hp->rest_k) {
+      *dot_bytes += hp->rest_k->x.stream_bytes() + 16 * (int64_t)K * hp->rest_k->x.G * h->n;
+      *tdot_bytes += hp->rest_k->xt.stream_bytes() + 8 * (int64_t)K * hp->rest_k->xt.G * h->p;
+    }
   }
   return BBX_OK;
 }

@@ -302,9 +302,10 @@ def test_batch_width_and_parity_on_mixed_designs():
     """Binary covariates plus dense continuous columns keep their split layout
     in a batch (value-free K-layout + the dense block, spmv_tiled.hip
     build_split_k): batched products against SciPy, chain independence, and
-    the automatic path takes them.  Stored values scattered OUTSIDE dense
-    columns would go through the plain valued K-layout, which runs slower than
-    two chains one after the other (profiles/r03_mixed.txt): batch_width 0."""
+    the automatic path takes them; stored values scattered outside dense
+    columns travel as a valued rest in its own K = 2 layout (pairs).  A design
+    with values throughout would go through the plain valued K-layout, which
+    runs slower than two chains one after the other: batch_width 0."""
     import scipy.sparse as sparse
     from bayesbridge_amd import (BayesBridge, HipChainBatch, HipGibbsChain,
                                  RegressionCoefPrior, RegressionModel, simulate)
@@ -312,37 +313,40 @@ def test_batch_width_and_parity_on_mixed_designs():
     n = 6000
     Xb = simulate.simulate_binary_csr_fast(n, 300, .05, seed=5)
     Xm = sparse.hstack([Xb, sparse.csr_matrix(rng.standard_normal((n, 3)))]).tocsr()
-    Xv = Xb.copy().astype(np.float64)
-    Xv.data[rng.random(Xv.nnz) < .15] = 2.5
+    Xr = Xm.copy()                                   # + a valued rest
+    Xr.data[(rng.random(Xr.nnz) < .1) & (Xr.data == 1.)] = 2.5
+    Xv = Xb.copy().astype(np.float64)                # values throughout
+    Xv.data[:] = rng.standard_normal(Xv.nnz)
     y = (rng.random(n) < .4).astype(float)
     prior = RegressionCoefPrior(bridge_exponent=.5, regularizing_slab_size=2.)
-    for X, want in ((Xb, 4), (Xm, 4), (Xv, 0)):
+    for X, want in ((Xb, 4), (Xm, 4), (Xr, 2), (Xv, 0)):
         model = RegressionModel((y, np.ones(n)), X, 'logit')
         assert BayesBridge(model, prior).batch_width(4) == want
-    model = RegressionModel((y, np.ones(n)), Xm, 'logit')
-    hip = model.design
-    assert hip.hybrid_info['rest_nnz'] == 0 and hip.hybrid_info['dense_cols'] == 3
-    Xc = sparse.csr_matrix(Xm)
-    off = np.asarray(Xc.mean(axis=0)).ravel()
-    for K in (2, 4):
-        chains = _chains(hip, (y, np.ones(n)), 'logit', list(range(K)))
-        batch = HipChainBatch(chains)
-        P = Xm.shape[1] + 1
-        V, W = rng.standard_normal((K, P)), rng.standard_normal((K, n))
-        T, G = batch.dot(V), batch.Tdot(W)
-        for c in range(K):
-            ref_t = V[c, 0] + Xc @ V[c, 1:] - off @ V[c, 1:]
-            sw = W[c].sum()
-            ref_g = np.concatenate([[sw], Xc.T @ W[c] - sw * off])
-            assert np.abs(T[c] - ref_t).max() <= 1e-11 * np.abs(ref_t).max()
-            assert np.abs(G[c] - ref_g).max() <= 1e-11 * np.abs(ref_g).max()
-        perm = np.roll(np.arange(K), 1)
-        assert np.array_equal(batch.dot(V[perm]), T[perm])
-        assert np.array_equal(batch.Tdot(W[perm]), G[perm])
-        s1, u1 = batch.run(4)
-        assert u1 == 0 and np.all(np.isfinite(s1['coef']))
-        # the same chain alone: agrees to the rounding of differently blocked sums
-        alone = _chains(hip, (y, np.ones(n)), 'logit', [0])[0]
-        kept, _ = alone.run(1, save=('coef',))
-        scale = max(1., np.abs(kept['coef'][0]).max())
-        assert np.abs(kept['coef'][0] - s1['coef'][0][0]).max() <= 1e-5 * scale
+    for Xc, widths in ((sparse.csr_matrix(Xm), (2, 4)), (sparse.csr_matrix(Xr), (2,))):
+      model = RegressionModel((y, np.ones(n)), Xc, 'logit')
+      hip = model.design
+      assert hip.hybrid_info['dense_cols'] == 3
+      assert (hip.hybrid_info['rest_nnz'] > 0) == (len(widths) == 1)
+      off = np.asarray(Xc.mean(axis=0)).ravel()
+      for K in widths:
+          chains = _chains(hip, (y, np.ones(n)), 'logit', list(range(K)))
+          batch = HipChainBatch(chains)
+          P = Xm.shape[1] + 1
+          V, W = rng.standard_normal((K, P)), rng.standard_normal((K, n))
+          T, G = batch.dot(V), batch.Tdot(W)
+          for c in range(K):
+              ref_t = V[c, 0] + Xc @ V[c, 1:] - off @ V[c, 1:]
+              sw = W[c].sum()
+              ref_g = np.concatenate([[sw], Xc.T @ W[c] - sw * off])
+              assert np.abs(T[c] - ref_t).max() <= 1e-11 * np.abs(ref_t).max()
+              assert np.abs(G[c] - ref_g).max() <= 1e-11 * np.abs(ref_g).max()
+          perm = np.roll(np.arange(K), 1)
+          assert np.array_equal(batch.dot(V[perm]), T[perm])
+          assert np.array_equal(batch.Tdot(W[perm]), G[perm])
+          s1, u1 = batch.run(4)
+          assert u1 == 0 and np.all(np.isfinite(s1['coef']))
+          # the same chain alone: agrees to the rounding of differently blocked sums
+          alone = _chains(hip, (y, np.ones(n)), 'logit', [0])[0]
+          kept, _ = alone.run(1, save=('coef',))
+          scale = max(1., np.abs(kept['coef'][0]).max())
+          assert np.abs(kept['coef'][0] - s1['coef'][0][0]).max() <= 1e-5 * scale
