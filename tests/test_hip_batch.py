@@ -350,3 +350,27 @@ def test_batch_width_and_parity_on_mixed_designs():
           kept, _ = alone.run(1, save=('coef',))
           scale = max(1., np.abs(kept['coef'][0]).max())
           assert np.abs(kept['coef'][0] - s1['coef'][0][0]).max() <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("kind", ['sparse', 'dense'])
+def test_batch_with_exhausted_cg_counts_unconverged_and_agrees_with_single(kind):
+    """maxiter reached in every solve (cg_sampler.py:82-87 warns and goes on):
+    the batch reports the unconverged solves per chain-iteration, every chain
+    stops at maxiter, and the samples still equal the single chain's to
+    rounding -- both paths perform exactly maxiter CG iterations."""
+    from bayesbridge_amd import HipChainBatch
+    if kind == 'sparse':
+        X, y, hip = _problem(3000, 200, 'logit')
+        fam = 'logit'
+    else:
+        X, y, hip = _dense_problem(3000, 200)
+        fam = 'linear'
+    batch = HipChainBatch(_chains(hip, y, fam, [3, 4]))
+    s, n_unconv = batch.run(3, maxiter=4)
+    assert n_unconv == 6                              # 2 chains x 3 iterations
+    assert np.all(s['n_cg_iter'] == 4)
+    alone = _chains(hip, y, fam, [3])[0]
+    kept, n1 = alone.run(3, maxiter=4, save=('coef',))
+    assert n1 == 3 and np.all(kept['n_cg_iter'] == 4)
+    scale = max(1., np.abs(kept['coef']).max())
+    assert np.abs(kept['coef'] - s['coef'][0]).max() <= 1e-8 * scale
