@@ -374,3 +374,48 @@ def test_batch_with_exhausted_cg_counts_unconverged_and_agrees_with_single(kind)
     assert n1 == 3 and np.all(kept['n_cg_iter'] == 4)
     scale = max(1., np.abs(kept['coef']).max())
     assert np.abs(kept['coef'] - s['coef'][0]).max() <= 1e-8 * scale
+
+
+@pytest.mark.parametrize("kind", ['sparse', 'dense'])
+def test_batched_chains_sample_the_same_posterior_as_single_chains(kind):
+    """Distribution-level agreement: four chains stepped as a batch against the
+    exact-seed ('reference' stream) chain of the same model -- posterior means
+    of the large coefficients and of log tau within Monte Carlo error (the
+    criterion of test_device_chain_agrees_with_reference_stream_chain, with four
+    chains' worth of draws on the batch side)."""
+    import warnings
+    from bayesbridge_amd import (BayesBridge, RegressionCoefPrior,
+                                 RegressionModel, simulate)
+    rng = np.random.default_rng(17)
+    if kind == 'sparse':
+        X = simulate.simulate_binary_csr_fast(2500, 60, .1, seed=5)
+        beta = np.zeros(60)
+        beta[:6] = [1.5, -1.2, 1., -.8, .7, .6]
+        y = simulate.simulate_outcome(X, beta, 'logit', seed=4)
+        fam = 'logit'
+    else:
+        X = rng.standard_normal((2500, 60))
+        beta = np.zeros(60)
+        beta[:6] = [1.5, -1.2, 1., -.8, .7, .6]
+        y = X @ beta + rng.standard_normal(2500)
+        fam = 'linear'
+    prior = RegressionCoefPrior(bridge_exponent=.5, regularizing_slab_size=2.)
+    init = {'global_scale': .05, 'coef': np.zeros(61)}
+    n_iter, burn = 500, 150
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bridge = BayesBridge(RegressionModel(y, X, fam), prior)
+        res = bridge.gibbs_batch([21, 22, 23, 24], n_iter, n_burnin=burn,
+                                 init=dict(init))
+        ref, _ = BayesBridge(RegressionModel(y, X, fam), prior).gibbs(
+            n_iter, n_burnin=burn, init=dict(init), seed=1,
+            options={'rng': 'reference'})
+    coef_b = np.concatenate([s['coef'] for s, _ in res], axis=1)
+    mb, mr = coef_b.mean(axis=1), ref['coef'].mean(axis=1)
+    sdv = ref['coef'].std(axis=1)
+    big = np.abs(mr) > .3
+    assert big.sum() >= 5
+    assert np.all(np.abs(mb - mr)[big] < .5 * sdv[big] + .02)
+    lg_b = np.log(np.concatenate([s['global_scale'] for s, _ in res]))
+    lg_r = np.log(ref['global_scale'])
+    assert abs(lg_b.mean() - lg_r.mean()) < .5 * lg_r.std() + .1
