@@ -279,8 +279,22 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
-  const int panel = blockIdx.x / G;
-  const int group = blockIdx.x - panel * G;
+  // Placement: workgroups go to the 8 XCDs round robin (blockIdx.x % 8), and the
+  // panels of one column-block group all load the same vector slices, so they
+  // should share an L2.  With G a multiple of 8 the plain numbering (panel
+  // major) does that by itself; the K = 2 layout of X^T at 1M x 50k has G = 15
+  // and every XCD fetched every slice (PMC: 401 MB per launch against 287 MB
+  // algorithmic).  So XCD x takes a CONTIGUOUS range of the group-major order;
+  // `bid` = panel * G + group stays the workgroup's logical number (schedules,
+  // partial-sum slots: results do not depend on the placement).
+  const int n_wg = (int)gridDim.x;
+  const int xcd_q = n_wg >> 3, xcd_r = n_wg & 7;
+  const int xcd = (int)blockIdx.x & 7;
+  const int gm = xcd * xcd_q + (xcd < xcd_r ? xcd : xcd_r) + ((int)blockIdx.x >> 3);
+  const int n_panel_wg = n_wg / G;
+  const int group = gm / n_panel_wg;
+  const int panel = gm - group * n_panel_wg;
+  const int bid = panel * G + group;
   const int64_t row0 = (int64_t)panel * PR;
   const int rows_here = (int)((R - row0 < PR) ? (R - row0) : PR);
 
@@ -316,8 +330,8 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   // With equal-stride schedules the first descriptor block needs no lookup
   // (one dependent memory round trip less before the first stream load).
   int blk = desc_stride > 0
-                ? (int)(blockIdx.x * TILE_WAVES + wave) * desc_stride
-                : wave_desc[blockIdx.x * TILE_WAVES + wave];
+                ? (int)(bid * TILE_WAVES + wave) * desc_stride
+                : wave_desc[bid * TILE_WAVES + wave];
   int pos = 0;
   const uint4* __restrict__ desc4 = reinterpret_cast<const uint4*>(descs);
   uint4 dcur = desc4[blk + lane];
@@ -674,12 +688,12 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
             tot += scratch[K + (2 * tid) * TILE_WAVES + wv];
             tot2 += scratch[K + (2 * tid + 1) * TILE_WAVES + wv];
           }
-          out_sum_part[tid * part_stride + (int)blockIdx.x] = tot;
+          out_sum_part[tid * part_stride + bid] = tot;
           if (twt_off)
-            out_sum_part[tid * part_stride + twt_off + (int)blockIdx.x] = tot2;
+            out_sum_part[tid * part_stride + twt_off + bid] = tot2;
         }
         // consumers add NPART slots: the first workgroup clears the unused ones
-        if (blockIdx.x == 0 && (int)gridDim.x + tid < NPART) {
+        if (bid == 0 && (int)gridDim.x + tid < NPART) {
 #pragma unroll
           for (int c = 0; c < K; ++c) {
             out_sum_part[c * part_stride + gridDim.x + tid] = 0.;
@@ -773,11 +787,11 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
             tot += xs[wv];
             tot2 += xs[TILE_WAVES + wv];
           }
-          out_sum_part[blockIdx.x] = tot;
-          if (twt_off) out_sum_part[twt_off + (int)blockIdx.x] = tot2;
+          out_sum_part[bid] = tot;
+          if (twt_off) out_sum_part[twt_off + bid] = tot2;
         }
         // consumers add NPART slots: the first workgroup clears the unused ones
-        if (blockIdx.x == 0 && (int)gridDim.x + tid < NPART) {
+        if (bid == 0 && (int)gridDim.x + tid < NPART) {
           out_sum_part[gridDim.x + tid] = 0.;
           if (twt_off) out_sum_part[twt_off + (int)gridDim.x + tid] = 0.;
         }
@@ -788,7 +802,7 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     }
   }
   if (dbg && lane == 0) {
-    unsigned long long* o = dbg + ((size_t)blockIdx.x * TILE_WAVES + wave) * 4;
+    unsigned long long* o = dbg + ((size_t)bid * TILE_WAVES + wave) * 4;
     o[0] = (unsigned)__builtin_amdgcn_s_memtime() - t_start;  // whole wave
     o[1] = t_loop;    // stream loop incl. tile switches
     o[2] = t_switch;  // inside tile switches
