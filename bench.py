@@ -70,7 +70,7 @@ def parse_args(argv=None):
                     help="comma-separated batch widths for the `multi_chain` "
                          "object (k chains on ONE GPU sharing every pass over "
                          "X; rank 0 at N = 1 only; '0' = skip).  Default: 2,4 "
-                         "for the sparse configs, 4,8 for config4")
+                         "for the sparse configs, 4,8,16,32 for config4")
     ap.add_argument("--multi-chain-steps", type=int, default=20)
     return ap.parse_args(argv)
 
