@@ -19,7 +19,9 @@
 // numbers do not depend on the other chains of the batch (bit for bit).
 #include "common.hpp"
 
-// -DDK_ABLATE=2: plain arithmetic instead of the MFMAs -- timing only, wrong results
+// -DDK_ABLATE=2: plain arithmetic instead of the MFMAs; =3: the loads stay on the first rows
+// (cache hits: matrix cores + issue without the HBM stream); =4: no loads at all after the
+// ring's priming -- timing only, wrong results
 #ifndef DK_ABLATE
 #define DK_ABLATE 0
 #endif
@@ -70,6 +72,9 @@ constexpr int DK_TDOT_CHUNKS = 8;           // row chunks of the transposed prod
 // a zero B operand or a column that is never stored.
 #ifndef DKT_D
 #define DKT_D 12     // ring depth (slots of 4 rows)
+#endif
+#ifndef DK_UNIT_ASM
+#define DK_UNIT_ASM 1   // f32: four MFMAs per asm statement, conversions one unit ahead
 #endif
 #ifndef DKT_D2
 #define DKT_D2 6     // ... with two groups of chains: all 256 accumulation registers are taken
@@ -153,6 +158,81 @@ __device__ __forceinline__ void dk_mfma2(dk_d4& acc0, dk_d4& acc1, double x,
       : "v"(x), "v"(b0), "v"(b1));
 }
 
+// f32 storage, one UNIT (the four MFMAs of a lane's float4) per asm statement,
+// software-pipelined: the conversions of the NEXT unit sit in front of this
+// unit's MFMAs.  One statement per MFMA (conversion, wait states, MFMA) ran the
+// matrix cores at 45 ns per MFMA instead of the 27 ns they can sustain -- with
+// or without the HBM stream (-DDK_ABLATE=3): every MFMA waited for its own
+// conversion, and the conversion reused the register the previous MFMA was
+// still reading.  Here the operands of a unit were converted a whole unit (four
+// MFMAs) earlier into registers of their own.
+#define DK_MF(A, B, E) \
+  "v_mfma_f64_16x16x4_f64 %[" A #E "], %[c" #E "], %[" B "], %[" A #E "]\n\t"
+#define DK_CV(E) "v_cvt_f64_f32 %[n" #E "], %[x" #E "]\n\t"
+#ifndef DK_UNIT_ORDER
+#define DK_UNIT_ORDER 0   // 0: the four conversions, then the MFMAs; 1: interleaved
+#endif
+#if DK_UNIT_ORDER == 0
+#define DK_UNIT1_NEXT DK_CV(0) DK_CV(1) DK_CV(2) DK_CV(3) DK_MF("p", "b0", 0) \
+                      DK_MF("p", "b0", 1) DK_MF("p", "b0", 2) DK_MF("p", "b0", 3)
+#define DK_UNIT2_NEXT                                                         \
+  DK_CV(0) DK_CV(1) DK_CV(2) DK_CV(3) DK_MF("p", "b0", 0) DK_MF("q", "b1", 0) \
+  DK_MF("p", "b0", 1) DK_MF("q", "b1", 1) DK_MF("p", "b0", 2)                 \
+  DK_MF("q", "b1", 2) DK_MF("p", "b0", 3) DK_MF("q", "b1", 3)
+#else
+#define DK_UNIT1_NEXT "s_nop 1\n\t" DK_MF("p", "b0", 0) DK_CV(0) DK_MF("p", "b0", 1) DK_CV(1) \
+                      DK_MF("p", "b0", 2) DK_CV(2) DK_MF("p", "b0", 3) DK_CV(3)
+#define DK_UNIT2_NEXT                                                         \
+  "s_nop 1\n\t" DK_MF("p", "b0", 0) DK_MF("q", "b1", 0) DK_CV(0) DK_MF("p", "b0", 1)        \
+  DK_MF("q", "b1", 1) DK_CV(1) DK_MF("p", "b0", 2) DK_MF("q", "b1", 2)        \
+  DK_CV(2) DK_MF("p", "b0", 3) DK_MF("q", "b1", 3) DK_CV(3)
+#endif
+#define DK_UNIT1_LAST DK_MF("p", "b0", 0) DK_MF("p", "b0", 1) DK_MF("p", "b0", 2) \
+                      DK_MF("p", "b0", 3)
+#define DK_UNIT2_LAST                                                         \
+  DK_MF("p", "b0", 0) DK_MF("q", "b1", 0) DK_MF("p", "b0", 1)                 \
+  DK_MF("q", "b1", 1) DK_MF("p", "b0", 2) DK_MF("q", "b1", 2)                 \
+  DK_MF("p", "b0", 3) DK_MF("q", "b1", 3)
+template <int NG, bool NEXT>
+__device__ __forceinline__ void dk_unit_f32(dk_d4 (&p)[4], dk_d4 (&q)[4],
+                                            const double (&tc)[4],
+                                            double (&tn)[4], const dk_f4& xn,
+                                            double b0, double b1) {
+  if (NG == 1 && NEXT) {
+    asm volatile(DK_UNIT1_NEXT
+                 : [p0] "+a"(p[0]), [p1] "+a"(p[1]), [p2] "+a"(p[2]), [p3] "+a"(p[3]),
+                   [n0] "=&v"(tn[0]), [n1] "=&v"(tn[1]), [n2] "=&v"(tn[2]), [n3] "=&v"(tn[3])
+                 : [c0] "v"(tc[0]), [c1] "v"(tc[1]), [c2] "v"(tc[2]), [c3] "v"(tc[3]),
+                   [x0] "v"(xn[0]), [x1] "v"(xn[1]), [x2] "v"(xn[2]), [x3] "v"(xn[3]),
+                   [b0] "v"(b0));
+  } else if (NG == 1) {
+    asm volatile("s_nop 3\n\t" DK_UNIT1_LAST
+                 : [p0] "+a"(p[0]), [p1] "+a"(p[1]), [p2] "+a"(p[2]), [p3] "+a"(p[3])
+                 : [c0] "v"(tc[0]), [c1] "v"(tc[1]), [c2] "v"(tc[2]), [c3] "v"(tc[3]),
+                   [b0] "v"(b0));
+  } else if (NEXT) {
+    asm volatile(DK_UNIT2_NEXT
+                 : [p0] "+a"(p[0]), [p1] "+a"(p[1]), [p2] "+a"(p[2]), [p3] "+a"(p[3]),
+                   [q0] "+a"(q[0]), [q1] "+a"(q[1]), [q2] "+a"(q[2]), [q3] "+a"(q[3]),
+                   [n0] "=&v"(tn[0]), [n1] "=&v"(tn[1]), [n2] "=&v"(tn[2]), [n3] "=&v"(tn[3])
+                 : [c0] "v"(tc[0]), [c1] "v"(tc[1]), [c2] "v"(tc[2]), [c3] "v"(tc[3]),
+                   [x0] "v"(xn[0]), [x1] "v"(xn[1]), [x2] "v"(xn[2]), [x3] "v"(xn[3]),
+                   [b0] "v"(b0), [b1] "v"(b1));
+  } else {
+    asm volatile("s_nop 3\n\t" DK_UNIT2_LAST
+                 : [p0] "+a"(p[0]), [p1] "+a"(p[1]), [p2] "+a"(p[2]), [p3] "+a"(p[3]),
+                   [q0] "+a"(q[0]), [q1] "+a"(q[1]), [q2] "+a"(q[2]), [q3] "+a"(q[3])
+                 : [c0] "v"(tc[0]), [c1] "v"(tc[1]), [c2] "v"(tc[2]), [c3] "v"(tc[3]),
+                   [b0] "v"(b0), [b1] "v"(b1));
+  }
+}
+#undef DK_MF
+#undef DK_CV
+#undef DK_UNIT1_NEXT
+#undef DK_UNIT1_LAST
+#undef DK_UNIT2_NEXT
+#undef DK_UNIT2_LAST
+
 constexpr int DKD_WAVES = 4;        // one per SIMD: 512 registers per lane
 constexpr int DKD_C = 4;            // units (one load instruction wide) a sweep carries
 // Per storage type T: a lane's 16 bytes are E elements, a load instruction
@@ -200,8 +280,10 @@ __device__ __forceinline__ void dkd_sweep(
     if (C > 3) dk_ld_x4<768>(xa[KK][C > 3 ? 3 : 0], voff_a, sa);              \
     dk_ld_d<0>(bw[KK][0], voff_b, sb);                                        \
     if (NG > 1) dk_ld_d<DK_KS * 8>(bw[KK][NG - 1], voff_b, sb);               \
-    sa += 4 * ldm;                                                            \
-    sb += 4 * KS;                                                             \
+    if (DK_ABLATE != 3) { /* 3: every slot re-reads the first rows (cache) */ \
+      sa += 4 * ldm;                                                          \
+      sb += 4 * KS;                                                           \
+    }                                                                         \
   } while (0)
 #define DKD_TIE(KK)                                                           \
   do {                                                                        \
@@ -212,6 +294,38 @@ __device__ __forceinline__ void dkd_sweep(
   } while (0)
 #pragma unroll
   for (int kk = 0; kk < D; ++kk) DKD_ISSUE(kk);
+  if constexpr (E == 4 && DK_ABLATE != 2 && DK_UNIT_ASM) {
+    // f32: a unit (four MFMAs) per asm statement with the conversions of the
+    // NEXT unit between its MFMAs -- across slots too, so the next slot is
+    // waited for one step early (D - 2 slots stay in flight)
+    static_assert(D >= 3, "the unit pipeline looks one slot ahead");
+    constexpr int WAITN = (D - 2) * LPS;
+    double tc[4], tn[4];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITC) : "memory");
+    DKD_TIE(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tc[e] = (double)xa[0][0][e];
+    asm volatile("s_nop 3" ::: "memory");   // VALU result -> first MFMA
+    for (int p = 0; p < n_period; ++p) {
+#pragma unroll
+      for (int kk = 0; kk < D; ++kk) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+        DKD_TIE((kk + 1) % D);
+        const bool live = p * D + kk < n_slot;
+        const double b0 = live ? bw[kk][0] : 0.;
+        const double b1 = live ? bw[kk][NG - 1] : 0.;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const vec_t& xn = (c + 1 < C) ? xa[kk][c + 1 < C ? c + 1 : 0]
+                                        : xa[(kk + 1) % D][0];
+          dk_unit_f32<NG, true>(acc[0][c], acc[NG - 1][c], tc, tn, xn, b0, b1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tc[e] = tn[e];
+        }
+        if (DK_ABLATE != 4) DKD_ISSUE(kk);   // 4: no loads after the priming
+      }
+    }
+  } else {
   for (int p = 0; p < n_period; ++p) {
 #pragma unroll
     for (int kk = 0; kk < D; ++kk) {
@@ -232,6 +346,7 @@ __device__ __forceinline__ void dkd_sweep(
         }
       DKD_ISSUE(kk);
     }
+  }
   }
   // the D slots issued past the end: landed before their registers are free
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
