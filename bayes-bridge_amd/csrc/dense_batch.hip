@@ -71,13 +71,13 @@ constexpr int DK_TDOT_CHUNKS = 8;           // row chunks of the transposed prod
 // the matrix (the allocations are padded with zero rows); what they fetch meets
 // a zero B operand or a column that is never stored.
 #ifndef DKT_D
-#define DKT_D 12     // ring depth (slots of 4 rows)
+#define DKT_D 5      // ring depth (slots of 4 rows): 18 VGPRs per slot next to 128 of accumulators
 #endif
 #ifndef DK_UNIT_ASM
 #define DK_UNIT_ASM 1   // f32: four MFMAs per asm statement, conversions one unit ahead
 #endif
 #ifndef DKT_D2
-#define DKT_D2 6     // ... with two groups of chains: all 256 accumulation registers are taken
+#define DKT_D2 6     // ... with two groups of chains (two units per sweep at f32: 12 VGPRs per slot)
 #endif
 
 typedef float dk_f4 __attribute__((ext_vector_type(4)));
@@ -125,7 +125,7 @@ __device__ __forceinline__ void dk_mfma(dk_d4& acc, float x, double b) {
   asm volatile(
       "v_cvt_f64_f32 %1, %2\n\ts_nop 3\n\t"
       "v_mfma_f64_16x16x4_f64 %0, %1, %3, %0"
-      : "+a"(acc), "=&v"(t)
+      : "+v"(acc), "=&v"(t)
       : "v"(x), "v"(b));
 }
 
@@ -137,7 +137,7 @@ __device__ __forceinline__ void dk_mfma2(dk_d4& acc0, dk_d4& acc1, float x,
       "v_cvt_f64_f32 %2, %3\n\ts_nop 3\n\t"
       "v_mfma_f64_16x16x4_f64 %0, %2, %4, %0\n\t"
       "v_mfma_f64_16x16x4_f64 %1, %2, %5, %1"
-      : "+a"(acc0), "+a"(acc1), "=&v"(t)
+      : "+v"(acc0), "+v"(acc1), "=&v"(t)
       : "v"(x), "v"(b0), "v"(b1));
 }
 
@@ -146,7 +146,7 @@ __device__ __forceinline__ void dk_mfma2(dk_d4& acc0, dk_d4& acc1, float x,
 // a B operand the VALU may have just produced).
 __device__ __forceinline__ void dk_mfma(dk_d4& acc, double x, double b) {
   asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0"
-               : "+a"(acc)
+               : "+v"(acc)
                : "v"(x), "v"(b));
 }
 __device__ __forceinline__ void dk_mfma2(dk_d4& acc0, dk_d4& acc1, double x,
@@ -154,7 +154,7 @@ __device__ __forceinline__ void dk_mfma2(dk_d4& acc0, dk_d4& acc1, double x,
   asm volatile(
       "s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %2, %3, %0\n\t"
       "v_mfma_f64_16x16x4_f64 %1, %2, %4, %1"
-      : "+a"(acc0), "+a"(acc1)
+      : "+v"(acc0), "+v"(acc1)
       : "v"(x), "v"(b0), "v"(b1));
 }
 
@@ -200,28 +200,28 @@ __device__ __forceinline__ void dk_unit_f32(dk_d4 (&p)[4], dk_d4 (&q)[4],
                                             double b0, double b1) {
   if (NG == 1 && NEXT) {
     asm volatile(DK_UNIT1_NEXT
-                 : [p0] "+a"(p[0]), [p1] "+a"(p[1]), [p2] "+a"(p[2]), [p3] "+a"(p[3]),
+                 : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3]),
                    [n0] "=&v"(tn[0]), [n1] "=&v"(tn[1]), [n2] "=&v"(tn[2]), [n3] "=&v"(tn[3])
                  : [c0] "v"(tc[0]), [c1] "v"(tc[1]), [c2] "v"(tc[2]), [c3] "v"(tc[3]),
                    [x0] "v"(xn[0]), [x1] "v"(xn[1]), [x2] "v"(xn[2]), [x3] "v"(xn[3]),
                    [b0] "v"(b0));
   } else if (NG == 1) {
     asm volatile("s_nop 3\n\t" DK_UNIT1_LAST
-                 : [p0] "+a"(p[0]), [p1] "+a"(p[1]), [p2] "+a"(p[2]), [p3] "+a"(p[3])
+                 : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3])
                  : [c0] "v"(tc[0]), [c1] "v"(tc[1]), [c2] "v"(tc[2]), [c3] "v"(tc[3]),
                    [b0] "v"(b0));
   } else if (NEXT) {
     asm volatile(DK_UNIT2_NEXT
-                 : [p0] "+a"(p[0]), [p1] "+a"(p[1]), [p2] "+a"(p[2]), [p3] "+a"(p[3]),
-                   [q0] "+a"(q[0]), [q1] "+a"(q[1]), [q2] "+a"(q[2]), [q3] "+a"(q[3]),
+                 : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3]),
+                   [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3]),
                    [n0] "=&v"(tn[0]), [n1] "=&v"(tn[1]), [n2] "=&v"(tn[2]), [n3] "=&v"(tn[3])
                  : [c0] "v"(tc[0]), [c1] "v"(tc[1]), [c2] "v"(tc[2]), [c3] "v"(tc[3]),
                    [x0] "v"(xn[0]), [x1] "v"(xn[1]), [x2] "v"(xn[2]), [x3] "v"(xn[3]),
                    [b0] "v"(b0), [b1] "v"(b1));
   } else {
     asm volatile("s_nop 3\n\t" DK_UNIT2_LAST
-                 : [p0] "+a"(p[0]), [p1] "+a"(p[1]), [p2] "+a"(p[2]), [p3] "+a"(p[3]),
-                   [q0] "+a"(q[0]), [q1] "+a"(q[1]), [q2] "+a"(q[2]), [q3] "+a"(q[3])
+                 : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3]),
+                   [q0] "+v"(q[0]), [q1] "+v"(q[1]), [q2] "+v"(q[2]), [q3] "+v"(q[3])
                  : [c0] "v"(tc[0]), [c1] "v"(tc[1]), [c2] "v"(tc[2]), [c3] "v"(tc[3]),
                    [b0] "v"(b0), [b1] "v"(b1));
   }
@@ -234,7 +234,12 @@ __device__ __forceinline__ void dk_unit_f32(dk_d4 (&p)[4], dk_d4 (&q)[4],
 #undef DK_UNIT2_LAST
 
 constexpr int DKD_WAVES = 4;        // one per SIMD: 512 registers per lane
-constexpr int DKD_C = 4;            // units (one load instruction wide) a sweep carries
+constexpr int DKD_C = 4;            // most units (one load instruction wide) a sweep carries
+// Units per sweep: the accumulators (NG groups x CW units x E tiles x 8 registers)
+// have to fit 128 ARCHITECTURAL VGPRs -- with its accumulators in AGPRs
+// v_mfma_f64_16x16x4_f64 issues at 58-64 ns per MFMA per SIMD, in VGPRs at 27 ns
+// (scripts/probes/mfma_f64_acc.hip, profiles/r03_mfma_f64_acc.txt)
+constexpr int dkd_cw(int NG, int E) { return NG * E <= 4 ? 4 : 2; }
 // Per storage type T: a lane's 16 bytes are E elements, a load instruction
 // covers 4 rows x U = 16 E columns (a "unit": 64 columns of f32, 32 of f64)
 template <typename T>
@@ -243,7 +248,12 @@ struct DkT {
   static constexpr int U = 16 * E;
   typedef T vec __attribute__((ext_vector_type(16 / sizeof(T))));
 };
-constexpr int DKD_IMG = DKD_WAVES * DKD_C * 16 * WAVE * 8;  // 128 KB of LDS (f32; f64 half)
+constexpr int DKD_IMG = DKD_WAVES * DKD_C * 16 * WAVE * 8;  // 128 KB of LDS at most
+// the fold image of one instantiation: [waves][CW][E][4][64] doubles
+template <typename T, int NG>
+constexpr int dkd_img() {
+  return DKD_WAVES * dkd_cw(NG, DkT<T>::E) * DkT<T>::E * 4 * WAVE * 8;
+}
 
 // One wave's sweep: acc[g][c][e] += sum over rows [r_begin, r_begin + 4 n_slot)
 // of M[r][col0 + U c + E i' + e] * B[r][16 g + chain], i' the MFMA's row index.
@@ -253,8 +263,9 @@ template <typename T, int C, int D, int NG>
 __device__ __forceinline__ void dkd_sweep(
     const T* __restrict__ M, int64_t ldm, int64_t col0, int64_t r_begin,
     int n_slot, const double* __restrict__ Bop, int lane,
-    dk_d4 (&acc)[NG][DKD_C][DkT<T>::E]) {
-  static_assert(C >= 1 && C <= DKD_C, "units per sweep");
+    dk_d4 (&acc)[NG][dkd_cw(NG, DkT<T>::E)][DkT<T>::E]) {
+  constexpr int CW = dkd_cw(NG, DkT<T>::E);
+  static_assert(C >= 1 && C <= CW, "units per sweep");
   static_assert(NG == 1 || NG == 2, "groups of 16 chains");
   constexpr int E = DkT<T>::E;
   typedef typename DkT<T>::vec vec_t;
@@ -355,37 +366,38 @@ __device__ __forceinline__ void dkd_sweep(
 #undef DKD_ISSUE
 #undef DKD_TIE
   // 18 wait states between the last MFMA and a read of its result
-  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][0][0]));
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0][0]));
 #pragma unroll
   for (int g = 0; g < NG; ++g)
 #pragma unroll
-    for (int c = 0; c < DKD_C; ++c)
+    for (int c = 0; c < CW; ++c)
 #pragma unroll
       for (int e = 0; e < E; ++e)
-        if (g + c + e > 0) asm volatile("" : "+a"(acc[g][c][e]));
+        if (g + c + e > 0) asm volatile("" : "+v"(acc[g][c][e]));
 }
 
 // The four waves' accumulators through LDS, added in the fixed order
 // (w0 + w1) + (w2 + w3); wave c' returns unit c' in g[e][reg]:
 // g[e][reg] = G[col0 + U c' + E ((lane >> 4) + 4 reg) + e][chain lane & 15].
-template <int E>
-__device__ __forceinline__ void dkd_fold(const dk_d4 (&acc)[DKD_C][E],
+template <int E, int CW>
+__device__ __forceinline__ void dkd_fold(const dk_d4 (&acc)[CW][E],
                                          double* img, int wave, int lane,
                                          double (&g)[E][4]) {
 #pragma unroll
-  for (int c = 0; c < DKD_C; ++c)
+  for (int c = 0; c < CW; ++c)
 #pragma unroll
     for (int e = 0; e < E; ++e)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg)
-        img[((((wave * DKD_C + c) * E + e) * 4 + reg) << 6) + lane] = acc[c][e][reg];
+        img[((((wave * CW + c) * E + e) * 4 + reg) << 6) + lane] = acc[c][e][reg];
   __syncthreads();
-  constexpr int WS = DKD_C * E * 4 * WAVE;
+  constexpr int WS = CW * E * 4 * WAVE;
 #pragma unroll
   for (int e = 0; e < E; ++e)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int o = (((wave * E + e) * 4 + reg) << 6) + lane;
+      // (waves past the sweep's units read a neighbour's slot: never stored)
+      const int o = ((((wave % CW) * E + e) * 4 + reg) << 6) + lane;
       g[e][reg] = (img[o] + img[WS + o]) + (img[2 * WS + o] + img[3 * WS + o]);
     }
   __syncthreads();   // the image is free again (next group of chains, next sweep)
@@ -401,34 +413,34 @@ __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_tdot_kd_kernel(
     const T* __restrict__ X, const double* __restrict__ w,
     double* __restrict__ slab, const int* __restrict__ skip_flag) {
   if (skip_flag && *skip_flag) return;
-  constexpr int E = DkT<T>::E, U = DkT<T>::U;
+  constexpr int E = DkT<T>::E, U = DkT<T>::U, CW = dkd_cw(NG, E);
   extern __shared__ __attribute__((aligned(16))) unsigned char dk_smem[];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int chunk = (int)(blockIdx.x % DK_TDOT_CHUNKS);
   const int colblk = (int)(blockIdx.x / DK_TDOT_CHUNKS);
-  const int64_t col0 = (int64_t)colblk * (U * DKD_C);
+  const int64_t col0 = (int64_t)colblk * (U * CW);
   const int64_t r_begin =
       ((int64_t)chunk * DKD_WAVES + wave) * rows_per_wave;  // multiple of 4
   int64_t r_end = r_begin + rows_per_wave;
   if (r_end > n) r_end = n;
   const int n_slot = r_end > r_begin ? (int)((r_end - r_begin + 3) / 4) : 0;
-  dk_d4 acc[NG][DKD_C][E];
+  dk_d4 acc[NG][CW][E];
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
-    for (int c = 0; c < DKD_C; ++c)
+    for (int c = 0; c < CW; ++c)
 #pragma unroll
       for (int e = 0; e < E; ++e) acc[gq][c][e] = dk_d4{0., 0., 0., 0.};
-  dkd_sweep<T, DKD_C, (NG == 1 ? DKT_D : DKT_D2), NG>(X, ld, col0, r_begin, n_slot, w,
-                                                      lane, acc);
+  dkd_sweep<T, CW, (NG == 1 ? DKT_D : DKT_D2), NG>(X, ld, col0, r_begin, n_slot, w,
+                                                   lane, acc);
   const int i = lane & 15, k = lane >> 4;
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq) {
     double g[E][4];
-    dkd_fold<E>(acc[gq], reinterpret_cast<double*>(dk_smem), wave, lane, g);
+    dkd_fold<E, CW>(acc[gq], reinterpret_cast<double*>(dk_smem), wave, lane, g);
     const int chain = 16 * gq + i;
-    if (chain < K) {
+    if (wave < CW && chain < K) {
 #pragma unroll
       for (int e = 0; e < E; ++e)
 #pragma unroll
@@ -453,17 +465,17 @@ __device__ __forceinline__ void dkd_dot_units(
     const double* __restrict__ v, const ChainPtrs& rowscale, const ChainOut& out,
     int out_stride, int64_t unit0, double* img, int wave, int lane,
     double (&twt)[NG]) {
-  constexpr int E = DkT<T>::E, U = DkT<T>::U;
+  constexpr int E = DkT<T>::E, U = DkT<T>::U, CW = dkd_cw(NG, E);
   const int64_t rows_per_wave = ((P + DKD_WAVES - 1) / DKD_WAVES + 3) / 4 * 4;
   const int64_t r_begin = (int64_t)wave * rows_per_wave;
   int64_t r_end = r_begin + rows_per_wave;
   if (r_end > P) r_end = P;
   const int n_slot = r_end > r_begin ? (int)((r_end - r_begin + 3) / 4) : 0;
-  dk_d4 acc[NG][DKD_C][E];
+  dk_d4 acc[NG][CW][E];
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
-    for (int c = 0; c < DKD_C; ++c)
+    for (int c = 0; c < CW; ++c)
 #pragma unroll
       for (int e = 0; e < E; ++e) acc[gq][c][e] = dk_d4{0., 0., 0., 0.};
   dkd_sweep<T, C, (NG == 1 ? DKT_D : DKT_D2), NG>(XT, ldn, unit0 * U, r_begin, n_slot,
@@ -472,7 +484,7 @@ __device__ __forceinline__ void dkd_dot_units(
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq) {
     double g[E][4];
-    dkd_fold<E>(acc[gq], img, wave, lane, g);
+    dkd_fold<E, CW>(acc[gq], img, wave, lane, g);
     const int chain = 16 * gq + i;
     if (wave < C && chain < K) {
       const double* rs = rowscale.p[chain];
@@ -518,10 +530,15 @@ __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_dot_kd_kernel(
 #define DKD_UNITS(C)                                                          \
   dkd_dot_units<T, C, NG>(K, n, P, ldn, XT, v, rowscale, out, out_stride, u,  \
                           img, wave, lane, twt)
-  for (; u + 4 <= u1; u += 4) DKD_UNITS(4);
-  if (u1 - u == 3) DKD_UNITS(3);
-  else if (u1 - u == 2) DKD_UNITS(2);
-  else if (u1 - u == 1) DKD_UNITS(1);
+  constexpr int CW = dkd_cw(NG, DkT<T>::E);
+  for (; u + CW <= u1; u += CW) DKD_UNITS(CW);
+  if constexpr (CW == 4) {
+    if (u1 - u == 3) DKD_UNITS(3);
+    else if (u1 - u == 2) DKD_UNITS(2);
+    else if (u1 - u == 1) DKD_UNITS(1);
+  } else {
+    if (u1 - u == 1) DKD_UNITS(1);
+  }
 #undef DKD_UNITS
   if (twt_part) {
     // lanes i, i + 16, i + 32, i + 48 hold chain i's parts: fixed order
@@ -642,7 +659,8 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
   }
   const bool f32 = h->dense_dtype == BBX_F32;
   const int unit = f32 ? DkT<float>::U : DkT<double>::U;
-  const int n_colblk = (int)((h->dense_ld + unit * DKD_C - 1) / (unit * DKD_C));
+  const int cw = dkd_cw(K > DK_KS ? 2 : 1, f32 ? DkT<float>::E : DkT<double>::E);
+  const int n_colblk = (int)((h->dense_ld + unit * cw - 1) / (unit * cw));
   const int64_t parts = (int64_t)DK_TDOT_CHUNKS * DKD_WAVES;
   const int64_t rows_per_wave = ((h->n + parts - 1) / parts + 3) / 4 * 4;
   h->n_tdot += 1;
@@ -650,7 +668,7 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
 #define DK_LAUNCH_TDOT(T, NG)                                                 \
   hipLaunchKernelGGL((dense_tdot_kd_kernel<T, NG>),                           \
                      dim3((unsigned)(n_colblk * DK_TDOT_CHUNKS)),             \
-                     dim3(DKD_WAVES* WAVE), DKD_IMG, h->stream, K, h->n,      \
+                     dim3(DKD_WAVES* WAVE), (dkd_img<T, NG>()), h->stream, K, h->n, \
                      h->dense_ld, rows_per_wave, h->dense.as<T>(), d_w,       \
                      h->dense_batch_slab.as<double>(), h->skip_flag)
   if (f32 && K > DK_KS) DK_LAUNCH_TDOT(float, 2);
