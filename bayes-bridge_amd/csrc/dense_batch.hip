@@ -66,10 +66,18 @@ constexpr int DK_TDOT_CHUNKS = 8;           // row chunks of the transposed prod
 //
 // The sweep keeps a ring of D slots in registers (a slot = 4 rows: four A loads
 // and one B load, 16 MFMAs), issued through inline asm and retired with counted
-// waits (the idiom of spmv_tiled.hip): D - 1 slots -- 44 KB per wave -- are in
-// flight while one is consumed.  Reads may run past a wave's rows or the end of
-// the matrix (the allocations are padded with zero rows); what they fetch meets
-// a zero B operand or a column that is never stored.
+// waits (the idiom of spmv_tiled.hip).  Reads may run past a wave's rows or the
+// end of the matrix (the allocations are padded with zero rows); what they fetch
+// meets a zero B operand or a column that is never stored.
+//
+// What bounds the passes is the ISSUE of the matrix cores (-DDK_ABLATE=3 / 4:
+// without the HBM stream they take 85 % of their time), so:
+//  * accumulators live in ARCHITECTURAL VGPRs: with a[..] accumulators
+//    v_mfma_f64_16x16x4_f64 issues at 58-64 ns per MFMA per SIMD, with v[..] at
+//    27 ns (scripts/probes/mfma_f64_acc.hip).  128 registers of tiles, 18 per
+//    ring slot, and the rest have to fit the 256 VGPRs -- hence dkd_cw();
+//  * a statement is a UNIT (four MFMAs) with the next unit's conversions in
+//    front of it (dk_unit_f32): see there.
 #ifndef DKT_D
 #define DKT_D 5      // ring depth (slots of 4 rows): 18 VGPRs per slot next to 128 of accumulators
 #endif

@@ -10,7 +10,7 @@ import time
 from ctypes import c_void_p
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "bayes-bridge_amd"))
+sys.path.insert(0, os.environ.get("BBX_PACKAGE_DIR", os.path.join(ROOT, "bayes-bridge_amd")))
 import torch
 from bayesbridge_amd import HipDenseDesignMatrix, _lib
 
