@@ -108,15 +108,14 @@ __device__ __forceinline__ void dk_ld_d(double& dst, unsigned voff,
                : "memory");
 }
 
-// The MFMA of the direct kernels: f32 -> f64 conversion of the A operand, the
-// wait states between a VALU result and the matrix core's read of it, and the
-// MFMA with its accumulator pinned to the accumulation half of the register
-// file, as ONE asm statement.
-//  * Through the builtin the compiler carries the accumulators across the loop
-//    boundary in architectural VGPRs -- which the asm loads' ring already
-//    fills -- and copies every one of them in and out once per period
-//    (v_accvgpr_write/read x 8 per tile, each waiting for its MFMA; seen in
-//    the .s).
+// One MFMA per statement (f32 storage): conversion of the A operand, the wait
+// states between a VALU result and the matrix core's read of it, the MFMA.
+// Kept for the ablation builds and as the reference form; the kernels use
+// dk_unit_f32 below (-DDK_UNIT_ASM=0 selects this one: 45 ns per MFMA).
+//  * The MFMAs are written in asm with the accumulator as an explicit operand
+//    ("+v": architectural VGPRs, see the file header) because through the
+//    builtin the compiler picks AGPR accumulators, carries them across the loop
+//    boundary in VGPRs and copies all of them in and out every period.
 //  * An MFMA written in asm is invisible to the compiler's hazard recogniser:
 //    with the conversion left outside, `v_cvt_f64_f32 v[a:b], ..` directly in
 //    front of `v_mfma .., v[a:b], ..` read the register's OLD contents (there
@@ -126,8 +125,6 @@ __device__ __forceinline__ void dk_ld_d(double& dst, unsigned voff,
 //    accumulator is touched again only after >= 3 other MFMAs (the statements
 //    are volatile and keep their source order), and the epilogue's reads are
 //    preceded by explicit s_nops.
-//  The ~12 cycles of issue per statement sit in the shadow of the previous
-//  MFMA's 64.
 __device__ __forceinline__ void dk_mfma(dk_d4& acc, float x, double b) {
   double t;
   asm volatile(
