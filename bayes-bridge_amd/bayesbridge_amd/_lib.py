@@ -16,6 +16,7 @@ FORMAT_AUTO, FORMAT_CSR, FORMAT_TILED = 0, 1, 2
 F64, F32 = 0, 1
 MODEL_LINEAR, MODEL_LOGIT = 0, 1
 GSCALE_SAMPLE, GSCALE_OPTIMIZE, GSCALE_FIXED = 0, 1, 2
+BATCH_ALLOW_SLOW = 1
 # Philox stream ids of the chain's draws (csrc/philox.hpp)
 STREAM_ETA1, STREAM_ETA2 = 1, 2
 
@@ -34,6 +35,7 @@ def _declare(lib):
         "bbx_version": ([], c_int),
         "bbx_last_error": ([], c_char_p),
         "bbx_device_count": ([POINTER(c_int)], c_int),
+        "bbx_builder_threads": ([POINTER(c_int)], c_int),
         "bbx_design_create_csr": (
             [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
              c_int, c_int, c_int, POINTER(hp)], c_int),
@@ -119,6 +121,10 @@ def _declare(lib):
             [hp, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
              c_void_p, c_void_p, c_void_p, c_void_p], c_int),
         "bbx_batch_create": ([hp, c_int, c_void_p, POINTER(hp)], c_int),
+        "bbx_batch_create_opts": (
+            [hp, c_int, c_void_p, ctypes.c_uint, POINTER(hp)], c_int),
+        "bbx_batch_predict": ([hp, c_int, POINTER(c_double)], c_int),
+        "bbx_batch_unconverged": ([hp, POINTER(c_int)], c_int),
         "bbx_batch_destroy": ([hp], c_int),
         "bbx_batch_run": (
             [hp, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
@@ -196,6 +202,14 @@ def check(status):
 def device_count():
     n = c_int(0)
     check(load().bbx_device_count(byref(n)))
+    return n.value
+
+
+def builder_threads():
+    """Host threads the sparse layout builder uses in this process (affinity
+    mask, cgroup CPU quota, LOCAL_WORLD_SIZE; BBX_BUILD_THREADS overrides)."""
+    n = c_int(0)
+    check(load().bbx_builder_threads(byref(n)))
     return n.value
 
 

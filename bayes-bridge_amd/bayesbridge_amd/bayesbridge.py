@@ -253,13 +253,15 @@ class BayesBridge():
                 # other.  (Mixed designs keep their split layout in a batch:
                 # value-free K-layout + dense block + valued rest.)
                 return 0
-            if hy is not None and hy['rest_nnz'] > 0:
-                return 2 if n_chain >= 2 else 0    # valued kernels: pairs only
+            valued_rest = hy is not None and hy['rest_nnz'] > 0
             # four chains per pass pay while the design is small (fixed costs
             # per launch dominate: 1.4-1.9x at 5k x 500 ... 100k x 10k against
             # 1.1-1.5x for pairs); at 1M x 50k the four planes shrink the LDS
-            # tiles too far (0.99x against 1.32x; profiles/r03_small_batches.txt)
-            widths = (4, 2) if design.nnz <= 3e7 else (2,)
+            # tiles too far (0.99x against 1.32x; profiles/r03_small_batches.txt).
+            # The library's cost model decides (bbx_batch_predict: 0.67 for
+            # four chains at 1M x 50k, 2.6 at 100k x 10k); HipChainBatch
+            # refuses what it prices below 1.
+            widths = (2,) if valued_rest else (4, 2)   # valued kernels: pairs only
         else:
             # the first batch on a dense design builds a transposed copy of
             # the matrix: it has to fit next to the matrix itself
@@ -272,22 +274,25 @@ class BayesBridge():
                 if not have_copy and free < 1.1 * n_ * P_ * el + (1 << 30):
                     return 0
             except Exception:
-                pass
-            widths = (32, 16, 8, 4)
+                return 0     # no memory figure: do not risk the transposed copy
+            widths = (32, 16, 8, 4, 2)
+        from .device_chain import HipChainBatch
         for w in widths:
-            if w <= n_chain:
+            if w <= n_chain and HipChainBatch.predicted_speedup(design, w) > 1.:
                 return w
         return 0
 
     def gibbs_batch(self, seeds, n_iter, n_burnin=0, thin=1,
                     init={'global_scale': 0.1},
                     params_to_save=('coef', 'global_scale', 'logp'),
-                    options=None):
+                    options=None, allow_slow=False):
         """len(seeds) chains of `gibbs(...)` stepped as ONE batch that shares
         every pass over the design (HipChainBatch; csrc/batch.hip).  The
         reference's way to more chains is more processes (bayesbridge.py:109).
         Returns a list of (samples, mcmc_info), one per seed, in gibbs()'s
-        format; a chain's samples do not depend on its companions."""
+        format; a chain's samples do not depend on its companions (they do
+        depend on the batch WIDTH, to rounding).  A width the cost model prices
+        below single chains raises unless `allow_slow`."""
         import copy
         from .device_chain import HipChainBatch
         if not isinstance(options, SamplerOptions):
@@ -300,42 +305,52 @@ class BayesBridge():
         start_time = time.time()
         seeds = [int(sd) for sd in seeds]
         chains, setups = [], []
-        for sd in seeds:
-            chain = self._new_chain(sd)
-            setups.append(self._device_setup(chain, sd, copy.deepcopy(init),
-                                             options))
-            chains.append(chain)
-        batch = HipChainBatch(chains)
-        kept, n_unconv = batch.run(n_iter, n_burnin, thin, maxiter=500,
-                                   atol=0., save_coef='coef' in params_to_save)
-        batch.close()
-        runtime = time.time() - start_time
-        results = []
-        for k, (chain, sd) in enumerate(zip(chains, seeds)):
-            mine = {key: val[k] for key, val in kept.items()}
-            out = self._device_collect(chain, sd, mine,
-                                       n_unconv if k == 0 else 0, n_iter,
-                                       n_burnin, thin, params_to_save,
-                                       *setups[k])
-            results.append(self._package(out, n_iter, n_burnin, thin, sd,
-                                         params_to_save, options, runtime))
-            results[-1][1]['batch'] = {'width': len(seeds), 'slot': k}
-            chain.close()
-        return results
+        batch = None
+        try:
+            for sd in seeds:
+                chain = self._new_chain(sd)
+                chains.append(chain)
+                setups.append(self._device_setup(chain, sd,
+                                                 copy.deepcopy(init), options))
+            batch = HipChainBatch(chains, allow_slow=allow_slow)
+            kept, _ = batch.run(n_iter, n_burnin, thin, maxiter=500, atol=0.,
+                                save_coef='coef' in params_to_save)
+            n_unconv = batch.n_unconverged       # per chain
+            runtime = time.time() - start_time
+            results = []
+            for k, (chain, sd) in enumerate(zip(chains, seeds)):
+                mine = {key: val[k] for key, val in kept.items()}
+                out = self._device_collect(chain, sd, mine, n_unconv[k],
+                                           n_iter, n_burnin, thin,
+                                           params_to_save, *setups[k])
+                results.append(self._package(out, n_iter, n_burnin, thin, sd,
+                                             params_to_save, options, runtime))
+                results[-1][1]['batch'] = {'width': len(seeds), 'slot': k}
+            return results
+        finally:
+            # an error inside the run (BBX_ERR_NUMERIC, out of memory while the
+            # dense transposed copy is built) must not leave up to 32 chains'
+            # device buffers to the garbage collector
+            if batch is not None:
+                batch.close()
+            for chain in chains:
+                chain.close()
 
     def gibbs_multichain(self, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
                          init={'global_scale': 0.1},
                          params_to_save=('coef', 'global_scale', 'logp'),
-                         options=None):
+                         options=None, batch=False):
         """`n_chain` independent chains, seeds seed + k; under
         torch.distributed.run one rank per GPU shares them and the samples are
         gathered once over RCCL on rank 0 (`chains.run_chains`).  The
         reference has one chain per process (bayesbridge.py:109); this is the
         multi-GPU capability of SURVEY.md 8(e).  Returns (samples, infos) with
-        samples[name] shaped (n_chain, ..., n_sample) on rank 0."""
+        samples[name] shaped (n_chain, ..., n_sample) on rank 0.  `batch`:
+        False (default; chain k's samples do not depend on the number of
+        ranks), 'auto' or a width -- see chains.run_chains."""
         from . import chains
         return chains.run_chains(self, n_chain, n_iter, n_burnin, thin, seed,
-                                 init, params_to_save, options)
+                                 init, params_to_save, options, batch=batch)
 
     # ------------------------------------------------- shared initialisation
     def _pre_allocate(self, n_post_burnin, thin, params_to_save):

@@ -128,14 +128,32 @@ def split_chains(n_chain, world, rank):
 
 def run_chains(bridge, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
                init=None, params_to_save=('coef', 'global_scale', 'logp'),
-               options=None, dst=0):
+               options=None, dst=0, batch=False):
     """`n_chain` independent chains of `bridge.gibbs(...)` (BASELINE config 5).
 
     Inside a torch.distributed.run launch (one rank per GPU, each with its own
     replica of the design) rank r runs chains r, r + world, ...; chain k uses
-    seed `seed + k` whatever the number of ranks, so the result does not depend
-    on how many GPUs shared the work.  Nothing is exchanged while sampling; at
-    the end each saved parameter is gathered ONCE on rank `dst`.
+    seed `seed + k` whatever the number of ranks.  Nothing is exchanged while
+    sampling; at the end each saved parameter is gathered ONCE on rank `dst`.
+
+    batch: what a rank does with SEVERAL chains.
+      False (default)  one after the other through `bridge.gibbs`: chain k's
+                       samples are bit-for-bit the same whatever the number of
+                       ranks (8 chains on 8, 2 or 1 GPU) -- the reproducibility
+                       contract of this function;
+      'auto'           in batches that share every pass over X
+                       (`bridge.gibbs_batch`), of the width
+                       `bridge.batch_width` picks from the library's cost model
+                       and the free GPU memory -- faster (1.35x for sparse pairs
+                       at 1M x 50k, 6.7x for 16 dense chains), but a batched chain
+                       equals its single run only to rounding, and an MCMC
+                       trajectory diverges from rounding differences: the
+                       samples then DEPEND on how the chains were grouped, i.e.
+                       on the number of ranks and on the chosen width;
+      int k            batches of exactly k where k chains are left (k = 2, 4
+                       sparse; 2 ... 32 dense), the rest alone; same caveat.
+    The decision is recorded per chain in mcmc_info['batch'] = {'requested':
+    batch, 'width': w, 'slot': i} (width 1: run alone).
 
     Returns on `dst` (samples, infos): samples[name] has the chain index first
     and the MCMC index last, e.g. 'coef' is (n_chain, P, n_sample); infos is
@@ -158,15 +176,25 @@ def run_chains(bridge, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
         samples['n_cg_iter'] = info['_reg_coef_sampling_info']['n_cg_iter']
         for name, arr in samples.items():
             kept.setdefault(name, []).append(np.asarray(arr, dtype=np.float64))
-    # More chains than ranks: this rank's chains go through the design in
-    # BATCHES that share every pass over X (BayesBridge.gibbs_batch) instead of
-    # one after the other; what does not fill a batch runs alone.  A chain's
-    # seed (hence its Philox streams) is seed + k either way; batched and
-    # single runs of a chain agree to rounding, not bit for bit.
+    # batch != False: this rank's chains go through the design in BATCHES that
+    # share every pass over X (BayesBridge.gibbs_batch) instead of one after
+    # the other; what does not fill a batch runs alone.  A chain's seed (hence
+    # its Philox streams) is seed + k either way; batched and single runs of a
+    # chain agree to rounding, not bit for bit.
+    if batch not in (False, None, 'auto') and not (
+            isinstance(batch, int) and batch >= 2):
+        raise ValueError("batch must be False, 'auto' or a width >= 2")
     todo = list(mine)
-    width_of = getattr(bridge, 'batch_width', None)
+    width_of = getattr(bridge, 'batch_width', None) if batch == 'auto' else None
+
+    def pick_width(n_left):
+        if batch == 'auto':
+            return width_of(n_left, params_to_save, options) if width_of else 0
+        if batch and n_left >= int(batch):
+            return int(batch)
+        return 0
     while todo:
-        width = width_of(len(todo), params_to_save, options) if width_of else 0
+        width = pick_width(len(todo))
         if width >= 2:
             group, todo = todo[:width], todo[width:]
             results = bridge.gibbs_batch(
@@ -174,6 +202,7 @@ def run_chains(bridge, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
                 init=copy.deepcopy(init), params_to_save=params_to_save,
                 options=options)
             for k, (samples, info) in zip(group, results):
+                info['batch']['requested'] = batch
                 keep(k, samples, info)
         else:
             k = todo.pop(0)
@@ -181,6 +210,7 @@ def run_chains(bridge, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
                 n_iter, n_burnin, thin, seed=chain_seed(seed, k),
                 init=copy.deepcopy(init), params_to_save=params_to_save,
                 coef_sampler_type='cg', options=options)
+            info['batch'] = {'requested': batch or False, 'width': 1, 'slot': 0}
             keep(k, samples, info)
     names = sorted(kept) if kept else None
     if world > 1:                                 # ranks without a chain

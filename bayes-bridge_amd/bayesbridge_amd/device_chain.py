@@ -219,10 +219,15 @@ class HipChainBatch():
     once for all chains of the batch (K-column products over one read of the
     matrix).  The reference has one chain per process (bayesbridge.py:109);
     this is how more chains than GPUs are run here.  `chains`: 2 or 4
-    HipGibbsChain objects on the same design; set / get their state through
-    the chains themselves between runs."""
+    HipGibbsChain objects on the same design (2 ... 32 on dense designs); set
+    / get their state through the chains themselves between runs.
 
-    def __init__(self, chains):
+    A width the library's cost model prices below single chains
+    (`predicted_speedup(design, k) < 1`: four chains on a 1M x 50k sparse
+    design, two on an f32 dense one) raises; `allow_slow=True` builds it
+    anyway (parity tests, measurements)."""
+
+    def __init__(self, chains, allow_slow=False):
         import ctypes
         chains = list(chains)
         self._lib = _lib.load()
@@ -231,9 +236,27 @@ class HipChainBatch():
         self.design = chains[0].design
         self.P = chains[0].P
         arr = (c_void_p * len(chains))(*[c.handle.value for c in chains])
-        _lib.check(self._lib.bbx_batch_create(
+        _lib.check(self._lib.bbx_batch_create_opts(
             self.design.handle, len(chains), ctypes.cast(arr, c_void_p),
-            byref(self._b)))
+            _lib.BATCH_ALLOW_SLOW if allow_slow else 0, byref(self._b)))
+
+    @staticmethod
+    def predicted_speedup(design, n_chain):
+        """The cost model's estimate of (throughput of a batch of n_chain
+        chains) / (the same chains one at a time) on `design`; no layout is
+        built (`bbx_batch_predict`)."""
+        s = c_double()
+        _lib.check(_lib.load().bbx_batch_predict(design.handle, int(n_chain),
+                                                 byref(s)))
+        return float(s.value)
+
+    @property
+    def n_unconverged(self):
+        """Per chain: CG solves of the last run() that hit maxiter."""
+        from ctypes import c_int
+        arr = (c_int * len(self.chains))()
+        _lib.check(self._lib.bbx_batch_unconverged(self._b, arr))
+        return [int(v) for v in arr]
 
     def close(self):
         b = getattr(self, '_b', None)

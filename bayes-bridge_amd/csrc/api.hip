@@ -6,6 +6,7 @@
 #include <new>
 
 #include "common.hpp"
+#include "tiled_layout.hpp"
 
 namespace bbx {
 
@@ -378,6 +379,12 @@ int bbx_device_count(int* count) {
   hipError_t e = hipGetDeviceCount(&c);
   if (e != hipSuccess) c = 0;
   *count = c;
+  return BBX_OK;
+}
+
+int bbx_builder_threads(int* count) {
+  if (!count) return fail(BBX_ERR_INVALID, "count is NULL");
+  *count = builder_threads(TiledOptions().max_threads);
   return BBX_OK;
 }
 

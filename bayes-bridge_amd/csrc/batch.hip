@@ -23,6 +23,7 @@
 // r are no longer touched, the id stream is read once either way).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <new>
 #include <vector>
 
@@ -52,6 +53,7 @@ struct bbx_batch {
   bbx::DevMem state;              // BatchState
   void* pinned = nullptr;
   int last_cg_iter = 0;
+  int n_unconverged[bbx::BATCH_MAX] = {};  // per chain, of the last run
 };
 
 namespace bbx {
@@ -637,8 +639,27 @@ using namespace bbx;
 
 extern "C" {
 
+int bbx_batch_predict(bbx_design* design, int n_chain, double* speedup) {
+  if (!design || !speedup) return fail(BBX_ERR_INVALID, "NULL argument");
+  *speedup = 0.;
+  if (design->sparse) return tiled_batch_predict(design, n_chain, speedup);
+  if (n_chain != 2 && n_chain != 4 && n_chain != 8 && n_chain != 16 &&
+      n_chain != 32)
+    return fail(BBX_ERR_INVALID, "a batch holds 2, 4, 8, 16 or 32 chains");
+  if (!dense_batch_applies(design))
+    return fail(BBX_ERR_STATE,
+                "batched chains: this dense layout is not supported");
+  return dense_batch_predict(design, n_chain, speedup);
+}
+
 int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,
                      bbx_batch** out) {
+  return bbx_batch_create_opts(design, n_chain, chains, 0u, out);
+}
+
+int bbx_batch_create_opts(bbx_design* design, int n_chain,
+                          bbx_chain* const* chains, unsigned flags,
+                          bbx_batch** out) {
   if (!out) return fail(BBX_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (!design || !chains) return fail(BBX_ERR_INVALID, "NULL argument");
@@ -670,6 +691,20 @@ int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,
                 "designs with stored values batch at most 2 chains (four valued "
                 "right-hand sides exceed the kernel's register budget)");
   BBX_HIP(hipSetDevice(h->device));
+  if (!(flags & BBX_BATCH_ALLOW_SLOW)) {
+    // a width the library's own cost model prices below single chains is an
+    // error unless the caller asks for it (K = 4 at 1M x 50k ran at 0.975x)
+    double pred = 0.;
+    BBX_TRY(bbx_batch_predict(h, n_chain, &pred));
+    if (pred < 1.) {
+      char msg[256];
+      snprintf(msg, sizeof(msg),
+               "a batch of %d chains on this design is predicted to run at "
+               "%.2fx the throughput of single chains (bbx_batch_predict); "
+               "pass BBX_BATCH_ALLOW_SLOW to build it anyway", n_chain, pred);
+      return fail(BBX_ERR_INVALID, msg);
+    }
+  }
   bbx_batch* b = new (std::nothrow) bbx_batch();
   if (!b) return fail(BBX_ERR_INVALID, "out of host memory");
   b->h = h;
@@ -741,11 +776,15 @@ static int bbx_batch_run_impl(bbx_batch* b, int n_iter, int n_burnin, int thin,
   const int n_sample = (n_iter - n_burnin) / thin;
   for (int c = 0; c < K; ++c) BBX_TRY(chain_begin_run(b->chain[c], n_sample));
   int n_unconverged = 0;
+  for (int c = 0; c < K; ++c) b->n_unconverged[c] = 0;
   for (int it = 1; it <= n_iter; ++it) {
     int ncg[BATCH_MAX] = {}, info[BATCH_MAX] = {};
     BBX_TRY(batch_step(b, maxiter, atol, ncg, info));
     for (int c = 0; c < K; ++c)
-      if (info[c] > 0) ++n_unconverged;
+      if (info[c] > 0) {
+        ++n_unconverged;
+        ++b->n_unconverged[c];
+      }
     if (it <= n_burnin || (it - n_burnin) % thin != 0) continue;
     const int idx = (it - n_burnin) / thin - 1;  // gibbs_util.py:170
     if (idx >= n_sample) continue;
@@ -882,6 +921,12 @@ int bbx_batch_run_host(bbx_batch* b, int n_iter, int n_burnin, int thin,
                           hipMemcpyDeviceToHost));
     return st;
   });
+}
+
+int bbx_batch_unconverged(const bbx_batch* b, int* per_chain) {
+  if (!b || !per_chain) return fail(BBX_ERR_INVALID, "NULL argument");
+  for (int c = 0; c < b->K; ++c) per_chain[c] = b->n_unconverged[c];
+  return BBX_OK;
 }
 
 int bbx_batch_bytes(const bbx_batch* b, int64_t* dot_bytes,

@@ -342,6 +342,8 @@ int build_tiled(bbx_design* h);
 void destroy_tiled(bbx_design* h);
 bool tiled_batch_value_free(const bbx_design* h);  // batches of any width (else pairs only)
 int ensure_tiled_k(bbx_design* h, int K);
+// predicted throughput of a batch of K chains / K single chains (cost model)
+int tiled_batch_predict(const bbx_design* h, int K, double* speedup);
 // Per-chain arguments of a batched launch of the tiled kernels (K > 1).
 struct TiledBatchArgs {
   ChainPtrs rowscale{};   // dot epilogue: Omega of each chain (entries may be null)
@@ -375,6 +377,7 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
                         const double** slab, int* G);
 int dense_batch_bytes(const bbx_design* h, int K, int64_t* dot_bytes,
                       int64_t* tdot_bytes);
+int dense_batch_predict(const bbx_design* h, int K, double* speedup);
 // timed_only: count what the timed kernel of each family moves (tiled Tdot:
 // without the epilogue kernel's slab read and P-vector output)
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,

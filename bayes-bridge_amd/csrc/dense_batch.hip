@@ -87,6 +87,11 @@ constexpr int DK_TDOT_CHUNKS = 8;           // row chunks of the transposed prod
 #ifndef DKT_D2
 #define DKT_D2 6     // ... with two groups of chains (two units per sweep at f32: 12 VGPRs per slot)
 #endif
+#ifndef DKT_D2_F64
+#define DKT_D2_F64 5 // ... and f64 storage: four units per sweep, 20 VGPRs per slot -- at depth 6
+                     // the X V kernel sat at 256 VGPRs and parked 16 loop invariants in AGPRs;
+                     // depths 5-12 run equally fast (tests/test_kernel_resources.py)
+#endif
 
 typedef float dk_f4 __attribute__((ext_vector_type(4)));
 
@@ -253,6 +258,11 @@ struct DkT {
   static constexpr int U = 16 * E;
   typedef T vec __attribute__((ext_vector_type(16 / sizeof(T))));
 };
+// ring depth of one instantiation
+template <typename T, int NG>
+constexpr int dkd_depth() {
+  return NG == 1 ? DKT_D : (sizeof(T) == 8 ? DKT_D2_F64 : DKT_D2);
+}
 constexpr int DKD_IMG = DKD_WAVES * DKD_C * 16 * WAVE * 8;  // 128 KB of LDS at most
 // the fold image of one instantiation: [waves][CW][E][4][64] doubles
 template <typename T, int NG>
@@ -437,8 +447,8 @@ __global__ __launch_bounds__(DKD_WAVES * WAVE) void dense_tdot_kd_kernel(
     for (int c = 0; c < CW; ++c)
 #pragma unroll
       for (int e = 0; e < E; ++e) acc[gq][c][e] = dk_d4{0., 0., 0., 0.};
-  dkd_sweep<T, CW, (NG == 1 ? DKT_D : DKT_D2), NG>(X, ld, col0, r_begin, n_slot, w,
-                                                   lane, acc);
+  dkd_sweep<T, CW, dkd_depth<T, NG>(), NG>(X, ld, col0, r_begin, n_slot, w,
+                                           lane, acc);
   const int i = lane & 15, k = lane >> 4;
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq) {
@@ -483,8 +493,8 @@ __device__ __forceinline__ void dkd_dot_units(
     for (int c = 0; c < CW; ++c)
 #pragma unroll
       for (int e = 0; e < E; ++e) acc[gq][c][e] = dk_d4{0., 0., 0., 0.};
-  dkd_sweep<T, C, (NG == 1 ? DKT_D : DKT_D2), NG>(XT, ldn, unit0 * U, r_begin, n_slot,
-                                                  v, lane, acc);
+  dkd_sweep<T, C, dkd_depth<T, NG>(), NG>(XT, ldn, unit0 * U, r_begin, n_slot,
+                                          v, lane, acc);
   const int i = lane & 15, k = lane >> 4;
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq) {
@@ -685,6 +695,21 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
   BBX_TRY(timer_end(h, 1));
   *slab = h->dense_batch_slab.as<double>();
   *G = DK_TDOT_CHUNKS;
+  return BBX_OK;
+}
+
+// The cost model's view of a dense batch (measured figures): one
+// chain applies the operator in ONE pass over the matrix where the single-pass
+// kernel applies (0.93 ms at 200k x 8k f32, 2.31 ms in f64), a batch needs
+// TWO passes for all its chains together -- stream-bound up to 16 chains
+// (1.05 ms each in f32, 1.97 ms in f64), bound by the f64 matrix cores at 32
+// (1.64 / 2.06 ms).  Two f32 chains therefore run faster one after the other.
+int dense_batch_predict(const bbx_design* h, int K, double* speedup) {
+  const bool f32 = h->dense_dtype == BBX_F32;
+  const double single = dense_fused_applies(h) ? (f32 ? 0.93 : 2.31)
+                                               : (f32 ? 2.0 : 4.4);
+  const double pass = K <= DK_KS ? (f32 ? 1.05 : 1.97) : (f32 ? 1.64 : 2.06);
+  *speedup = (double)K * single / (2. * pass);
   return BBX_OK;
 }
 

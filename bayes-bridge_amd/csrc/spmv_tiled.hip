@@ -1155,6 +1155,36 @@ bool tiled_batch_value_free(const bbx_design* h) {
   return hp && hp->rest_nnz == 0;
 }
 
+// The cost model's view of a batch of K chains on this design (no layout is
+// built): K single-chain products against one K-column product, both
+// orientations, from the geometry search's estimates (tiled_layout.cpp
+// shape_cost: ~4.3 us per tile + ~24 ps per streamed entry, rounds of 256
+// workgroups).  > 1: the batch is predicted to pay.  At 1M x 50k: K = 2 -> 1.08
+// (measured 1.47 on the products, 1.35 on whole iterations), K = 4 -> 0.67
+// (measured 0.99 / 0.975): the model is pessimistic in absolute terms but
+// orders the widths correctly.  Mixed designs are priced on the whole matrix.
+int tiled_batch_predict(const bbx_design* h, int K, double* speedup) {
+  if (!h->sparse || h->format != BBX_FORMAT_TILED)
+    return fail(BBX_ERR_STATE, "batched chains need the tiled format");
+  if (K != 2 && K != 4) return fail(BBX_ERR_INVALID, "K must be 2 or 4");
+  return no_throw([&]() -> int {
+    std::vector<int32_t> xp((size_t)h->n + 1), tp((size_t)h->p + 1);
+    BBX_HIP(hipMemcpy(xp.data(), h->indptr.ptr, sizeof(int32_t) * xp.size(),
+                      hipMemcpyDeviceToHost));
+    BBX_HIP(hipMemcpy(tp.data(), h->t_indptr.ptr, sizeof(int32_t) * tp.size(),
+                      hipMemcpyDeviceToHost));
+    double c1 = 0., ck = 0.;
+    for (int k : {1, K}) {
+      const double cx = tiled_model_cost(h->n, h->p, h->nnz, xp.data(), k);
+      const double ct = tiled_model_cost(h->p, h->n, h->nnz, tp.data(), k);
+      if (cx < 0. || ct < 0.) return fail(BBX_ERR_INVALID, "cost model failed");
+      (k == 1 ? c1 : ck) = cx + ct;
+    }
+    *speedup = ck > 0. ? (double)K * c1 / ck : 0.;
+    return BBX_OK;
+  });
+}
+
 // The layout sized for K right-hand sides (K = 2, 4), built on first use.
 int ensure_tiled_k(bbx_design* h, int K) {
   // (a mixed design's K-layout is the plain valued one of the whole matrix)

@@ -8,9 +8,60 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <thread>
 
+#include <sched.h>
+
 namespace bbx {
+
+// CPUs' worth of time the cgroup grants this process (cgroup v2 `cpu.max`,
+// v1 `cpu.cfs_quota_us`), 0 when unlimited or unreadable.
+static int cgroup_cpu_quota() {
+  {
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    std::string quota;
+    long long period = 0;
+    if (f && (f >> quota >> period) && quota != "max" && period > 0) {
+      const long long q = atoll(quota.c_str());
+      if (q > 0) return (int)std::max<long long>(1, (q + period - 1) / period);
+    }
+  }
+  std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us");
+  std::ifstream fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+  long long q = 0, period = 0;
+  if (fq && fp && (fq >> q) && (fp >> period) && q > 0 && period > 0)
+    return (int)std::max<long long>(1, (q + period - 1) / period);
+  return 0;
+}
+
+// Worker threads the builder may keep busy.  The GPU boxes this runs on show
+// 256 cores and grant 16 (cgroup quota): threads beyond the quota are
+// throttled, not scheduled (measured with the OpenMP baseline: 110 GB/s at 32
+// threads, 0.6 GB/s at 256), and the ranks of a multi-GPU job build their
+// layouts side by side on one host.  So: affinity mask, capped by the quota,
+// shared evenly among the local ranks (LOCAL_WORLD_SIZE of
+// torch.distributed.run), capped by `max_threads`.  BBX_BUILD_THREADS=N
+// overrides all of it (N <= 0: the machine's core count, the old behaviour).
+int builder_threads(int max_threads) {
+  if (const char* e = getenv("BBX_BUILD_THREADS")) {
+    int n = atoi(e);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(n, std::max(1, max_threads)));
+  }
+  int n = 0;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (n < 1) n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  const int quota = cgroup_cpu_quota();
+  if (quota > 0 && quota < n) n = quota;
+  int ranks = 1;
+  if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+  n = std::max(1, n / ranks);
+  return std::max(1, std::min(n, std::max(1, max_threads)));
+}
 
 TiledOptions TiledOptions::from_env(bool transpose) {
   TiledOptions o;
@@ -661,21 +712,18 @@ static void choose_shape(int64_t R, int64_t C, int64_t nnz, int n_block, int W,
   if (cost_out) *cost_out = best;
 }
 
-int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
-                     const int32_t* colidx, const double* vals,
-                     const TiledOptions& opt, TiledHost* out, std::string* err) {
-  TiledHost& m = *out;
-  m = TiledHost();
-  auto fail = [&](const char* msg) {
-    if (err) *err = msg;
-    return -1;
-  };
-  m.R = R;
-  m.C = C;
-  m.nnz = nnz;
-  m.has_vals = vals != nullptr;
+// Geometry of one orientation for K right-hand sides: W, n_block, PR, G, n_panel
+// and the cost model's estimate of one product, in microseconds.  Everything
+// build_tiled_host decides before it touches the entries; also what
+// tiled_model_cost answers from (batch-width decisions need no built layout).
+static int choose_geometry(int64_t R, int64_t C, int64_t nnz,
+                           const int32_t* rowptr, const TiledOptions& opt,
+                           TiledHost& m, const char** why) {
   const int K = opt.chains;
-  if (K != 1 && K != 2 && K != 4) return fail("chains must be 1, 2 or 4");
+  if (K != 1 && K != 2 && K != 4) {
+    *why = "chains must be 1, 2 or 4";
+    return -1;
+  }
   m.K = K;
   auto width_for = [&](int n_block) {
     int64_t w = (C + n_block - 1) / n_block;
@@ -732,6 +780,38 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
     m.G = (m.n_block + bpg - 1) / bpg;
   }
   m.n_panel = (int)((R + m.PR - 1) / m.PR);
+  m.model_cost_us = shape_cost(R, nnz, m.n_block, m.PR, m.G, K);
+  return 0;
+}
+
+double tiled_model_cost(int64_t R, int64_t C, int64_t nnz,
+                        const int32_t* rowptr, int chains) {
+  TiledOptions opt;
+  opt.chains = chains;
+  TiledHost m;
+  const char* why = nullptr;
+  if (choose_geometry(R, C, nnz, rowptr, opt, m, &why) != 0) return -1.;
+  return m.model_cost_us;
+}
+
+int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
+                     const int32_t* colidx, const double* vals,
+                     const TiledOptions& opt, TiledHost* out, std::string* err) {
+  TiledHost& m = *out;
+  m = TiledHost();
+  auto fail = [&](const char* msg) {
+    if (err) *err = msg;
+    return -1;
+  };
+  m.R = R;
+  m.C = C;
+  m.nnz = nnz;
+  m.has_vals = vals != nullptr;
+  const int K = opt.chains;
+  {
+    const char* why = nullptr;
+    if (choose_geometry(R, C, nnz, rowptr, opt, m, &why) != 0) return fail(why);
+  }
   // LDS left after the vector slice and the row accumulators pays for the
   // extra accumulators of split rows (2 KB stay free for static LDS).
   int extra_budget = lds_budget_per_chain(K) - (m.W + 8) - m.PR;
@@ -740,10 +820,7 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   if (opt.extra_budget >= 0) extra_budget = opt.extra_budget;
 
   std::vector<PanelBuild> pbs((size_t)m.n_panel);
-  unsigned n_thr = std::thread::hardware_concurrency();
-  if (n_thr < 1) n_thr = 1;
-  if (n_thr > (unsigned)opt.max_threads) n_thr = (unsigned)opt.max_threads;
-  if (n_thr < 1) n_thr = 1;
+  unsigned n_thr = (unsigned)builder_threads(opt.max_threads);
   if ((unsigned)m.n_panel < n_thr) n_thr = (unsigned)m.n_panel;
   std::vector<std::thread> pool;
   std::vector<int> thread_status(n_thr, 0);
@@ -1104,6 +1181,17 @@ int bbx_layout_emulate(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   }
   if (gather_cycles) *gather_cycles = bbx::tiled_mean_gather_cycles(m);
   return 0;
+}
+
+// worker threads the builder would use now (affinity, cgroup quota, local ranks)
+// the cost model's estimate (us) of one product in the layout for `chains`
+double bbx_layout_model_cost(int64_t R, int64_t C, int64_t nnz,
+                             const int32_t* rowptr, int chains) {
+  return bbx::tiled_model_cost(R, C, nnz, rowptr, chains);
+}
+
+int bbx_layout_builder_threads(int max_threads) {
+  return bbx::builder_threads(max_threads > 0 ? max_threads : 64);
 }
 
 }  // extern "C"

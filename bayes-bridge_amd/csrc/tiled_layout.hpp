@@ -111,6 +111,7 @@ struct TiledHost {
   std::vector<FoldDesc> folds;
   std::vector<int32_t> panel_fold;  // [n_panel + 1]
   std::string stats;                // filled when TiledOptions::stats
+  double model_cost_us = 0.;        // the geometry search's estimate of one product
   int64_t lds_doubles() const {
     return (int64_t)K * ((int64_t)W + 8 + PR + n_extra);
   }
@@ -122,6 +123,16 @@ struct TiledHost {
 int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
                      const int32_t* colidx, const double* vals,
                      const TiledOptions& opt, TiledHost* out, std::string* err);
+
+// The geometry search's cost estimate (microseconds per product) of the layout
+// build_tiled_host would choose for `chains` right-hand sides; no layout is
+// built.  < 0 on bad arguments.
+double tiled_model_cost(int64_t R, int64_t C, int64_t nnz,
+                        const int32_t* rowptr, int chains);
+
+// Worker threads of the builder: affinity mask, capped by the cgroup CPU quota,
+// divided by LOCAL_WORLD_SIZE, capped by max_threads (BBX_BUILD_THREADS overrides).
+int builder_threads(int max_threads);
 
 // CPU emulation of tiled_spmv_kernel's walk over the layout: every workgroup,
 // every wave's schedule, lane-private sums flushed into the panel's

@@ -72,6 +72,10 @@ def parse_args(argv=None):
                          "X; rank 0 at N = 1 only; '0' = skip).  Default: 2,4 "
                          "for the sparse configs, 4,8,16,32 for config4")
     ap.add_argument("--multi-chain-steps", type=int, default=20)
+    ap.add_argument("--repeat", type=int, default=5,
+                    help="how many times the K-step block is run in all for "
+                         "the `repeat` object (the first is the timed region "
+                         "behind `value`; 1 = no extra blocks)")
     return ap.parse_args(argv)
 
 
@@ -231,8 +235,27 @@ def iteration_bytes(mean_ncg, op_bytes, dot_bytes, tdot_bytes, n, P,
     return total + mean_ncg * 15 * 8 * P + 64 * n + 30 * 8 * P
 
 
+def multi_chain_ceiling(k, ms_step, n_apply, op_ms, shared_bytes,
+                        chain_bytes, batch_passes=1.):
+    """What the batched formulation allows at best, to read `vs_k1` against: a
+    batch step = the operator applications of ONE chain with the
+    chain-independent bytes of a product (id stream, row ids, schedules, or
+    the dense matrix) moved once and the per-chain bytes (vectors, slabs) k
+    times, at the single chain's rate, plus k times what is left of a single
+    chain's iteration (Polya-Gamma, scales, normals, vector kernels: per
+    chain).  ceiling = k * ms_step / that.  batch_passes: how often the batch
+    reads the shared bytes per application where one chain reads them once (2
+    for dense designs: K chains' state does not fit a CU, so the single-pass
+    operator becomes two passes)."""
+    t_apply = n_apply * op_ms
+    t_rest = max(ms_step - t_apply, 0.)
+    grow = (batch_passes * shared_bytes + k * chain_bytes) / \
+        (shared_bytes + chain_bytes)
+    return k * ms_step / (t_apply * grow + k * t_rest)
+
+
 def multi_chain_block(design, make_chain, state, widths, steps, warmup,
-                      single_value, dense):
+                      single_value, dense, ceiling_of=None):
     """k chains on one GPU through ONE pass over X per product (csrc/batch.hip)
     -- the reference's answer to "more chains" is more processes, each with
     its own passes (bayesbridge.py:109).  Every batch starts all its chains
@@ -245,7 +268,10 @@ def multi_chain_block(design, make_chain, state, widths, steps, warmup,
     coef, obs, ls, g, mean, square, navg = state
     out = {"what": "k chains per GPU sharing every pass over X (K-column "
                    "products); chain-iterations/s of the whole batch, same "
-                   "start state and stationarity as the single-chain line",
+                   "start state and stationarity as the single-chain line; "
+                   "`ceiling` = the speed-up the formulation allows (matrix "
+                   "bytes once, per-chain bytes and non-CG work k times, at "
+                   "the single chain's rates), `of_ceiling` = vs_k1 / ceiling",
            "k=1": {"chain_iters_per_sec": round(single_value, 2)}}
     for k in widths:
         chains = []
@@ -254,8 +280,10 @@ def multi_chain_block(design, make_chain, state, widths, steps, warmup,
             ch.set_state(coef, obs, ls, g)
             ch.set_summary(mean, square, navg)
             chains.append(ch)
+        predicted = HipChainBatch.predicted_speedup(design, k)
         t0 = time.perf_counter()
-        batch = HipChainBatch(chains)
+        # (allow_slow: the line SHOWS the widths the library refuses by default)
+        batch = HipChainBatch(chains, allow_slow=True)
         build_s = time.perf_counter() - t0
         batch.run_device(warmup)
         design.set_timing(True, every=8)
@@ -273,7 +301,14 @@ def multi_chain_block(design, make_chain, state, widths, steps, warmup,
                  "vs_k1": round(k * steps / dt / single_value, 3),
                  "ms_per_batch_step": round(1e3 * dt / steps, 4),
                  "mean_n_cg_iter": [round(float(v), 1) for v in ncg.mean(1)],
-                 "layout_build_s": round(build_s, 2)}
+                 "layout_build_s": round(build_s, 2),
+                 # bbx_batch_predict: < 1 => bbx_batch_create refuses the width
+                 "predicted_product_speedup": round(predicted, 3),
+                 "refused_by_default": bool(predicted < 1.)}
+        if ceiling_of is not None:
+            ceil = ceiling_of(k)
+            entry["ceiling"] = round(ceil, 3)
+            entry["of_ceiling"] = round(k * steps / dt / single_value / ceil, 3)
         for name, nbytes in (("dot", dot_b), ("tdot", tdot_b)):
             cnt, ms = timing[name]
             if cnt > 0 and ms > 0:
@@ -454,6 +489,37 @@ def main():
     timing = design.get_timing()
     design.set_timing(False)
 
+    # `repeat`: the same K-step block four more times, each bracketed like the
+    # timed region (barrier + synchronize, max over ranks); value/steps/
+    # ms_per_step above are the FIRST block and stay what they were.  Gives the
+    # line a spread: box-to-box and block-to-block noise is +-1.5 %.
+    block_values = [world * K / elapsed]
+    block_ncg = [float(ncg.mean())]
+    for _ in range(max(args.repeat - 1, 0)):
+        chains.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ncg_r = chain.run_device(K, d_coef_ptr=d_coef.data_ptr())[2]
+        chains.gather_chain_samples(d_coef, dst=0)
+        chains.barrier()
+        torch.cuda.synchronize()
+        dt_r = chains.max_over_ranks(time.perf_counter() - t0)
+        block_values.append(world * K / dt_r)
+        block_ncg.append(float(ncg_r.mean()))
+    # set-up cost of EVERY rank (eight generators and eight layout builders
+    # run side by side on one host at config 5)
+    rss_mb = int(__import__("resource").getrusage(
+        __import__("resource").RUSAGE_SELF).ru_maxrss / 1024)
+    per_rank = None
+    if grouped:
+        import torch.distributed as dist
+        box = [None] * world
+        dist.all_gather_object(box, (round(startup_s, 1), rss_mb,
+                                     _lib.builder_threads()))
+        per_rank = {"startup_s": [b[0] for b in box],
+                    "peak_host_rss_mb": [b[1] for b in box],
+                    "builder_threads": [b[2] for b in box]}
+
     if rank == 0:
         assert gathered is not None and gathered.shape[0] == world
         assert bool(torch.isfinite(gathered).all())
@@ -588,22 +654,50 @@ def main():
                 # host-side layout builders side by side): seconds from process
                 # start to a ready chain and this rank's peak host RSS
                 "startup_s": round(startup_s, 1),
-                "peak_host_rss_mb": int(
-                    __import__("resource").getrusage(
-                        __import__("resource").RUSAGE_SELF).ru_maxrss / 1024),
+                "peak_host_rss_mb": rss_mb,
+                # host threads of the layout builder (affinity, cgroup quota,
+                # LOCAL_WORLD_SIZE; csrc/tiled_layout.cpp builder_threads)
+                "builder_threads": _lib.builder_threads(),
+                "per_rank": per_rank,
                 "parallelism": "chains=%d" % world,
                 "devices": min(world, n_dev),
                 "backend": backend,
                 "rccl_ranks": world if backend == "nccl" else 0,
             },
             "roofline": roofline,
+            "repeat": {
+                "what": "the timed K-step block run %d times back to back "
+                        "(block 0 is `value`); Gibbs iters/sec of each and "
+                        "their median" % len(block_values),
+                "values": [round(v, 2) for v in block_values],
+                "median": round(float(np.median(block_values)), 2),
+                "spread_pct": round(100. * (max(block_values)
+                                            - min(block_values))
+                                    / float(np.median(block_values)), 2),
+                "mean_n_cg_iter": [round(v, 2) for v in block_ncg]},
         }
         if state is not None and widths:
             # (an extra block beside the headline: it must never cost the line)
             try:
+                # bytes of one operator application that do not depend on the
+                # chain: everything but the vectors and slabs
+                passes = 1.
+                if dense:
+                    el = 4 if args.dense_storage == "float32" else 8
+                    mat_b = float(n * (-(-P // 8) * 8) * el)
+                    shared_b = mat_b * (1 if fused_b else 2)
+                    passes = 2. if fused_b else 1.
+                else:
+                    shared_b = float(design.storage_bytes)
+                chain_b = max(float(op_bytes) - shared_b, 0.)
+                n_apply = mean_ncg + 1.      # + the initial residual's products
+
+                def ceiling_of(k):
+                    return multi_chain_ceiling(k, ms_step, n_apply, op_avg,
+                                               shared_b, chain_b, passes)
                 line["multi_chain"] = multi_chain_block(
                     design, make_chain, state, widths, args.multi_chain_steps,
-                    5, line["value"], dense)
+                    5, line["value"], dense, ceiling_of)
             except Exception as exc:     # noqa: BLE001
                 line["multi_chain"] = {"error": "%s: %s" % (type(exc).__name__,
                                                             exc)}

@@ -78,6 +78,13 @@ const char* bbx_last_error(void);
 /* Number of visible HIP devices (0 on a CPU-only box; never touches a GPU
  * context beyond counting). */
 int bbx_device_count(int* count);
+/* Host worker threads the layout builder of a sparse design uses in this
+ * process: the affinity mask, capped by the cgroup CPU quota (a box may show
+ * 256 cores and grant 16), shared evenly among the LOCAL_WORLD_SIZE ranks
+ * torch.distributed.run started on this node, at most 64;
+ * BBX_BUILD_THREADS=N overrides.  (The reference builds nothing on extra
+ * threads: SciPy's CSR is used as is, sparse_matrix.py:21-49.) */
+int bbx_builder_threads(int* count);
 
 /* ---------------------------------------------------- design operator (L1) */
 
@@ -420,6 +427,22 @@ int bbx_chain_run_host(bbx_chain* c, int n_iter, int n_burnin, int thin,
  * layout of the design (host pass, ~1 s at 1M x 50k). */
 int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,
                      bbx_batch** out);
+/* What the library's cost model expects of a batch of n_chain chains on this
+ * design: aggregate chain throughput of the batch / of the same chains run one
+ * at a time, at the level of the operator's products (sparse: the geometry
+ * search's per-tile + per-entry estimate of the K-layout against the
+ * single-chain layout, csrc/tiled_layout.cpp; dense: two stream- or
+ * MFMA-bound passes per application against the single-pass kernel).  No
+ * layout is built.  bbx_batch_create REFUSES (BBX_ERR_INVALID) a width priced
+ * below 1.0 -- e.g. 4 chains on the 1M x 50k design (0.67 predicted, 0.975
+ * measured), 2 chains on an f32 dense design; bbx_batch_create_opts with
+ * BBX_BATCH_ALLOW_SLOW builds it anyway (parity tests, measurements).  The
+ * reference has no counterpart: one chain per process (bayesbridge.py:109). */
+#define BBX_BATCH_ALLOW_SLOW 1u
+int bbx_batch_predict(bbx_design* design, int n_chain, double* speedup);
+int bbx_batch_create_opts(bbx_design* design, int n_chain,
+                          bbx_chain* const* chains, unsigned flags,
+                          bbx_batch** out);
 int bbx_batch_destroy(bbx_batch* b);
 /*
  * n_iter Gibbs iterations of every chain (arguments as bbx_chain_run).
@@ -431,6 +454,10 @@ int bbx_batch_destroy(bbx_batch* b);
 int bbx_batch_run(bbx_batch* b, int n_iter, int n_burnin, int thin,
                   int maxiter, double atol, double* const* d_coef,
                   double* gscale, double* logp, double* n_cg_iter);
+/* per_chain[n_chain]: how many CG solves of each chain hit maxiter in the last
+ * bbx_batch_run[_host] (its return value is their sum; the reference warns per
+ * solve, cg_sampler.py:82-87). */
+int bbx_batch_unconverged(const bbx_batch* b, int* per_chain);
 /* Same with a HOST coefficient buffer [n_chain * n_sample * P] (chain-major,
  * sample s of chain c at (c * n_sample + s) * P), copied at the end, or NULL. */
 int bbx_batch_run_host(bbx_batch* b, int n_iter, int n_burnin, int thin,

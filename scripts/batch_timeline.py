@@ -66,6 +66,6 @@ chains = [HipGibbsChain(design, 'logit', y, n_trial=np.ones(n), sd_unshrunk=[np.
 for ch in chains:
     ch.set_state(global_scale=.01)
     ch.init_obs_prec()
-batch = HipChainBatch(chains)
+batch = HipChainBatch(chains, allow_slow=True)
 s, _ = batch.run(iters, save_coef=False)
 print("n_cg", s["n_cg_iter"][:, -5:])

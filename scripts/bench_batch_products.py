@@ -29,7 +29,7 @@ y = prob["n_success"].cpu().numpy()
 chains = [HipGibbsChain(design, 'logit', y, seed=i) for i in range(K)]
 for ch in chains:
     ch.init_obs_prec()
-batch = HipChainBatch(chains)
+batch = HipChainBatch(chains, allow_slow=True)
 rng = np.random.default_rng(1)
 v, w = rng.standard_normal((K, p + 1)), rng.standard_normal((K, n))
 batch.dot(v), batch.Tdot(w)

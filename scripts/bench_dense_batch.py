@@ -29,7 +29,7 @@ design = HipDenseDesignMatrix.from_device_array(
 del X
 y = np.random.default_rng(0).standard_normal(n)
 chains = [HipGibbsChain(design, 'linear', y, seed=i) for i in range(K)]
-batch = HipChainBatch(chains)
+batch = HipChainBatch(chains, allow_slow=True)
 rng = np.random.default_rng(1)
 v, w = rng.standard_normal((K, p + 1)), rng.standard_normal((K, n))
 batch.dot(v), batch.Tdot(w)                       # warm-up

@@ -60,7 +60,7 @@ for label, X in (("all-binary", Xb if valued_frac == 0 else None),
         y = (rng.random(nn) < .3).astype(np.float64)
         chains = [HipGibbsChain(d, 'logit', y, n_trial=np.ones(nn), seed=s_)
                   for s_ in (1, 2)]
-        batch = HipChainBatch(chains)
+        batch = HipChainBatch(chains, allow_slow=True)
         V, W = rng.standard_normal((2, P)), rng.standard_normal((2, nn))
         T = batch.dot(V)
         batch.Tdot(W)

@@ -29,7 +29,7 @@ for t in range(cases):
     chains = [HipGibbsChain(hip, 'linear', y, sd_unshrunk=[np.inf] if icpt else [],
                             bridge_exponent=.5, slab_size=2., seed=s)
               for s in range(K)]
-    batch = HipChainBatch(chains)
+    batch = HipChainBatch(chains, allow_slow=True)
     V, W = rng.standard_normal((K, P)), rng.standard_normal((K, n))
     Xi = np.hstack([np.ones((n, 1)), X]) if icpt else X
     T, G = batch.dot(V), batch.Tdot(W)

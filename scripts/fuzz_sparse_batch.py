@@ -57,7 +57,7 @@ for t in range(cases):
     y = (rng.random(n) < .4).astype(float)
     chains = [HipGibbsChain(hip, 'logit', y, n_trial=np.ones(n), sd_unshrunk=[2.],
                             slab_size=2., seed=s) for s in range(K)]
-    batch = HipChainBatch(chains)
+    batch = HipChainBatch(chains, allow_slow=True)
     V, W = rng.standard_normal((K, P)), rng.standard_normal((K, n))
     T, G = batch.dot(V), batch.Tdot(W)
     e = 0.

@@ -45,7 +45,7 @@ def worker(rank, procs, K, steps, cfg, ready, go, out):
         ch.set_state(coef0, None, np.ones(P - 1) * unit, .01 / unit)
         ch.init_obs_prec()
         chains.append(ch)
-    runner = HipChainBatch(chains) if K > 1 else chains[0]
+    runner = HipChainBatch(chains, allow_slow=True) if K > 1 else chains[0]
     runner.run_device(150)                    # past most of the transient
     ready.put(rank)
     go.wait()

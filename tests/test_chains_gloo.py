@@ -70,6 +70,19 @@ RUN_CHAINS_WORKER = textwrap.dedent("""
             return s, {'_reg_coef_sampling_info':
                        {'n_cg_iter': np.full(ns, float(seed))}, 'seed': seed}
 
+        # the batched route (batch='auto' / batch=2): pairs
+        def batch_width(self, n_left, params_to_save=None, options=None):
+            return 2 if n_left >= 2 else 0
+
+        def gibbs_batch(self, seeds, n_iter, n_burnin, thin, init=None,
+                        params_to_save=None, options=None):
+            out = []
+            for slot, sd in enumerate(seeds):
+                s, info = self.gibbs(n_iter, n_burnin, thin, seed=sd)
+                info['batch'] = {'width': len(seeds), 'slot': slot}
+                out.append((s, info))
+            return out
+
     rank, world, _ = chains.init_process_group_from_env(backend="gloo")
     merged, infos = chains.run_chains(FakeBridge(), %(n_chain)d, 8, n_burnin=2,
                                       thin=2, seed=111)
@@ -82,9 +95,26 @@ RUN_CHAINS_WORKER = textwrap.dedent("""
             assert np.array_equal(merged['coef'][k],
                                   rng.standard_normal((6, 3)))
             assert np.all(merged['n_cg_iter'][k] == 111 + k)
-        print("CHAINS_OK")
     else:
         assert merged is None
+    # default: every chain alone, and the decision is on record
+    assert all(i['batch'] == {'requested': False, 'width': 1, 'slot': 0}
+               for i in infos)
+    # batch='auto' / an explicit width: this rank's chains in pairs, the odd
+    # one alone; same seeds, same output slots
+    for how in ('auto', 2):
+        merged_b, infos_b = chains.run_chains(
+            FakeBridge(), %(n_chain)d, 8, n_burnin=2, thin=2, seed=111,
+            batch=how)
+        mine = chains.split_chains(%(n_chain)d, world, rank)
+        assert [i['chain'] for i in infos_b] == mine
+        widths = [2] * (len(mine) // 2 * 2) + [1] * (len(mine) %% 2)
+        assert [i['batch']['width'] for i in infos_b] == widths
+        assert all(i['batch']['requested'] == how for i in infos_b)
+        if rank == 0:
+            assert np.array_equal(merged_b['coef'], merged['coef'])
+    if rank == 0:
+        print("CHAINS_OK")
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()

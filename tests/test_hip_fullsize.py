@@ -124,7 +124,7 @@ def test_full_size_pair_products_equal_the_single_chain_operator(full_design):
     chains = [HipGibbsChain(hip, 'logit', y, n_trial=np.ones(n),
                             sd_unshrunk=[2.], bridge_exponent=.5, slab_size=2.,
                             seed=s) for s in (1, 2)]
-    batch = HipChainBatch(chains)
+    batch = HipChainBatch(chains, allow_slow=True)
     V, W = rng.standard_normal((2, P)), rng.standard_normal((2, n))
     T, G = batch.dot(V), batch.Tdot(W)
     for c in range(2):

@@ -267,7 +267,7 @@ def test_config4_batched_products_equal_the_single_chain_operator(full_dense, K)
     y = rng.standard_normal(n)
     batch = HipChainBatch([HipGibbsChain(hip, 'linear', y, sd_unshrunk=[np.inf],
                                          bridge_exponent=.5, slab_size=2.,
-                                         seed=s) for s in range(K)])
+                                         seed=s) for s in range(K)], allow_slow=True)
     V, W = rng.standard_normal((K, P)), rng.standard_normal((K, n))
     T, G = batch.dot(V), batch.Tdot(W)
     for c in (0, 7, K - 1):

@@ -101,3 +101,31 @@ def test_builder_under_address_undefined_and_thread_sanitizers():
     assert 'ERROR: AddressSanitizer' not in res.stderr
     assert 'runtime error' not in res.stderr
     assert res.stdout.count('max err') >= 14        # both binaries ran
+
+
+def test_builder_threads_follow_quota_and_local_ranks():
+    """The layout builder's worker count: affinity mask capped by the cgroup
+    CPU quota, shared among the LOCAL_WORLD_SIZE ranks of a node, capped at 64;
+    BBX_BUILD_THREADS overrides.  (Eight ranks with 64 threads each under the
+    GPU boxes' 16-CPU quota is the regime that collapsed in
+    profiles/r03_omp_threads.txt.)"""
+    import sys
+    from oracle.omp_baseline import usable_cores
+    lib = os.path.join(ROOT, 'bayes-bridge_amd', 'libbbx_layout.so')
+    code = ("import ctypes,sys; l=ctypes.CDLL(%r); "
+            "print(l.bbx_layout_builder_threads(int(sys.argv[1])))" % lib)
+
+    def ask(max_threads=0, **env):
+        e = {k: v for k, v in os.environ.items()
+             if k not in ('LOCAL_WORLD_SIZE', 'BBX_BUILD_THREADS')}
+        e.update({k: str(v) for k, v in env.items()})
+        return int(subprocess.check_output(
+            [sys.executable, '-c', code, str(max_threads)], env=e, text=True))
+
+    cores = usable_cores()          # same rule, restated in Python
+    assert ask() == min(64, cores)
+    assert ask(LOCAL_WORLD_SIZE=8) == max(1, min(64, cores // 8))
+    assert ask(LOCAL_WORLD_SIZE=10 ** 6) == 1
+    assert ask(max_threads=3) == min(3, cores)
+    assert ask(BBX_BUILD_THREADS=5, LOCAL_WORLD_SIZE=8) == 5
+    assert ask(BBX_BUILD_THREADS=500) == 64
