@@ -21,6 +21,21 @@ BATCH_ALLOW_SLOW = 1
 STREAM_ETA1, STREAM_ETA2 = 1, 2
 
 _lib = None
+# Set by an atexit hook: objects that are only collected while the interpreter
+# shuts down (frames kept alive by a traceback, module globals) no longer call
+# into the library -- the order in which the HIP runtime, torch and those
+# objects go away is not ours to choose (seen as a segfault at exit after a
+# failed test); the process is ending, the driver reclaims the memory.
+finalizing = False
+
+
+def _mark_finalizing():
+    global finalizing
+    finalizing = True
+
+
+import atexit  # noqa: E402
+atexit.register(_mark_finalizing)
 
 
 class BbxError(RuntimeError):
@@ -61,6 +76,7 @@ def _declare(lib):
         "bbx_design_timed_bytes": (
             [hp, POINTER(c_int64), POINTER(c_int64)], c_int),
         "bbx_design_fused_operator_bytes": ([hp, POINTER(c_int64)], c_int),
+        "bbx_design_cg_launches": ([hp, POINTER(c_int)], c_int),
         "bbx_design_hybrid_info": (
             [hp, POINTER(c_int), POINTER(c_int64), POINTER(c_int64),
              POINTER(c_int64), POINTER(c_int)], c_int),

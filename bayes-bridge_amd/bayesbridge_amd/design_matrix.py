@@ -63,7 +63,7 @@ class HipDesignMatrix():
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and h.value:
+        if h is not None and h.value and not getattr(_lib, "finalizing", True):
             try:
                 self._lib.bbx_design_destroy(h)
             except Exception:
@@ -122,23 +122,38 @@ class HipDesignMatrix():
         return int(a.value), int(b.value)
 
     @property
+    def cg_launches(self):
+        """Kernel launches per CG iteration on this design (3: direction step
+        folded into the X~ v kernel, update into the Tdot epilogue)."""
+        from ctypes import c_int
+        v = c_int()
+        _lib.check(self._lib.bbx_design_cg_launches(self._h, byref(v)))
+        return int(v.value)
+
+    @property
     def fused_operator_bytes(self):
         v = c_int64()
         _lib.check(self._lib.bbx_design_fused_operator_bytes(self._h,
                                                               byref(v)))
         return int(v.value)
 
-    def tiled_info(self):
-        """Geometry of the LDS-tiled layout: {'X': {...}, 'Xt': {...}}."""
+    def tiled_info(self, chains=1):
+        """Geometry of the LDS-tiled layout: {'X': {...}, 'Xt': {...}}; chains =
+        2, 4: the layout sized for that many right-hand sides (once a batch of
+        that width has been built).  'grid' = workgroups of one launch."""
         out = {}
-        for which, name in ((0, 'X'), (1, 'Xt')):
+        base = {1: 0, 2: 2, 4: 4}[int(chains)]
+        n, P = self.shape
+        for which, name in ((base, 'X'), (base + 1, 'Xt')):
             W, nb, PR, G = c_int(), c_int(), c_int(), c_int()
             nq, ns = c_int64(), c_int64()
             _lib.check(self._lib.bbx_design_tiled_info(
                 self._h, which, byref(W), byref(nb), byref(PR), byref(G),
                 byref(nq), byref(ns)))
+            rows = n if name == 'X' else P - int(self.intercept_added)
             out[name] = dict(W=W.value, n_block=nb.value, PR=PR.value,
-                             G=G.value, n_quad=nq.value, n_slice=ns.value)
+                             G=G.value, n_quad=nq.value, n_slice=ns.value,
+                             grid=-(-rows // max(PR.value, 1)) * G.value)
         return out
 
     @property

@@ -57,7 +57,7 @@ class HipGibbsChain():
 
     def close(self):
         c = getattr(self, '_c', None)
-        if c is not None and c.value:
+        if c is not None and c.value and not getattr(_lib, "finalizing", True):
             try:
                 self._lib.bbx_chain_destroy(c)
             except Exception:
@@ -260,7 +260,7 @@ class HipChainBatch():
 
     def close(self):
         b = getattr(self, '_b', None)
-        if b is not None and b.value:
+        if b is not None and b.value and not getattr(_lib, "finalizing", True):
             try:
                 self._lib.bbx_batch_destroy(b)
             except Exception:

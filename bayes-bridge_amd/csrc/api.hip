@@ -900,6 +900,24 @@ int bbx_design_timed_bytes(const bbx_design* h, int64_t* dot_bytes,
   return matvec_bytes_impl(h, true, dot_bytes, tdot_bytes);
 }
 
+int bbx_design_cg_launches(const bbx_design* h, int* per_iteration) {
+  BBX_TRY(check_handle(h));
+  if (!per_iteration) return fail(BBX_ERR_INVALID, "per_iteration is NULL");
+  int n = 5;   // direction, dot, Tdot main, Tdot epilogue, update
+  if (tiled_fold_applies(h)) {
+    n = 3;
+  } else if (!h->sparse && dense_fused_applies(h)) {
+    n = 3;     // direction, single-pass operator, epilogue + update
+  } else if (h->sparse && h->format == BBX_FORMAT_TILED) {
+    int G = 0;
+    if (!h->hybrid && tiled_describe(h, 0, nullptr, nullptr, nullptr, &G,
+                                     nullptr, nullptr) == BBX_OK && G == 1)
+      n = 4;   // <t, Omega t> from the dot kernel: the update rides in the epilogue
+  }
+  *per_iteration = n;
+  return BBX_OK;
+}
+
 int bbx_design_fused_operator_bytes(const bbx_design* h, int64_t* bytes) {
   BBX_TRY(check_handle(h));
   int64_t b = 0;

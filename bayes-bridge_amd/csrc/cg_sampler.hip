@@ -147,6 +147,11 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
   // intercept entry
   double* sp = h->w_P[6].as<double>() + (h->intercept ? 1 : 0);
   CGState* st = h->cg_state.as<CGState>();
+  // Folded direction step (common.hpp DotFold; tiled format, one column group):
+  // s.*p alternates between two buffers, s.*r has its own; same alignment rule
+  const bool fold = tiled_fold_applies(h);
+  double* sp_pair[2] = {sp, h->w_P[7].as<double>() + (h->intercept ? 1 : 0)};
+  double* sr = h->w_P[9].as<double>() + (h->intercept ? 1 : 0);
 
   if (d_eta1 == nullptr) {
     double* e1 = h->w_n[2].as<double>();
@@ -196,6 +201,10 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     ep.phi = d_phi;
     ep.eta2 = d_eta2;
     ep.dot_part = part_slot(h, PS_RR);
+    if (fold) {   // the first X~ v kernel of the loop starts from s.*r
+      ep.fold_sr = sr;
+      ep.fold_cr_part = part_slot(h, PS_C);
+    }
     if (!x0_zero && !h->sparse && dense_fused_applies(h)) {
       // single-pass dense operator: the normal term rides as a row addend
       BBX_TRY(launch_prep_v(h, x, s, sp, part_slot(h, PS_C)));
@@ -257,7 +266,64 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
                                part_slot(h, PS_RR)));
     return BBX_OK;
   };
-  while (!done) {
+  // One CG iteration in THREE launches: the X~ v kernel carries the stop test
+  // and the direction step (DotFold), the Tdot epilogue the update and s.*r.
+  auto folded_iteration = [&](int kk) -> int {
+    h->timer.cur_tag = kk;
+    DotFold fa;
+    fa.st = st;
+    fa.k = kk;
+    fa.intercept = h->intercept;
+    fa.P = h->P;
+    fa.rr_part = part_slot(h, PS_RR);
+    fa.cr_part = part_slot(h, PS_C);
+    fa.sr = sr;
+    fa.sp_old = sp_pair[(kk + 1) & 1];
+    fa.sp_new = sp_pair[kk & 1];
+    fa.r = r;
+    fa.pvec = pvec;
+    fa.d = d;
+    fa.pdp_part = pdp;
+    BBX_TRY(timer_begin(h, 2));
+    BBX_TRY(launch_dot_tiled_fold(h, fa, d_omega, h->w_n[0].as<double>(),
+                                  part_slot(h, PS_SUMW), part_slot(h, PS_TWT)));
+    TdotEpilogue ep;
+    ep.mode = TD_OPER_UPD;
+    ep.s = s;
+    ep.d = d;
+    ep.x = pvec;
+    ep.dot_part = part_slot(h, PS_RR);
+    ep.cg_x = x;
+    ep.cg_r = r;
+    ep.cg_state = st;
+    ep.cg_k = kk;
+    ep.pdp_part = pdp;
+    ep.twt_part = part_slot(h, PS_TWT);
+    ep.fold_sr = sr;
+    ep.fold_cr_part = part_slot(h, PS_C);
+    BBX_TRY(launch_tdot(h, h->w_n[0].as<double>(), part_slot(h, PS_SUMW), ep, q));
+    return timer_end(h, 2);
+  };
+  while (fold && !done) {
+    const int stop = (next_poll < maxiter) ? next_poll : maxiter;
+    for (; k < stop; ++k) BBX_TRY(folded_iteration(k));
+    if (k >= maxiter) break;
+    // iteration k's X~ v kernel runs the stop test of SciPy's loop top; if the
+    // rule fires, its three launches return at entry and x is final
+    BBX_TRY(folded_iteration(k));
+    ++k;
+    BBX_TRY(launch_cg_finish(h, s, x, d_coef));
+    BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,
+                           h->stream));
+    BBX_HIP(hipStreamSynchronize(h->stream));
+    if (host_st->done) {
+      done = true;
+      finished_at_poll = true;
+      break;
+    }
+    next_poll = k + 2;
+  }
+  while (!fold && !done) {
     const int stop = (next_poll < maxiter) ? next_poll : maxiter;
     for (; k < stop; ++k) {
       BBX_TRY(launch_cg_direction(h, k, st, part_slot(h, PS_RR), r, pvec, s, sp,

@@ -142,6 +142,9 @@ struct CGState {
   int done;          // 1 once the stop rule fired; later kernels exit at entry
   int bad;           // 1 if a non-finite or non-positive curvature was seen
   int pad;
+  // folded direction step (DotFold): <offset, (s.*p)[1:]> of iteration k in
+  // slot k&1, carried by the recurrence s.*p_k = s.*r_k + beta_k s.*p_{k-1}
+  double coff[2];
 };
 
 struct KernelTimer {
@@ -295,7 +298,43 @@ struct TdotEpilogue {
   int cg_k = 0;
   const double* pdp_part = nullptr;
   const double* twt_part = nullptr;
+  // TD_OPER_UPD / TD_RESID feeding a folded direction step (DotFold): also
+  // write s.*r and the NPART partials of <offset, (s.*r)[1:]>
+  double* fold_sr = nullptr;
+  double* fold_cr_part = nullptr;
 };
+// The direction step of CG iteration k folded into the tiled X~ v kernel
+// (spmv_tiled.hip tiled_spmv_kernel<.., FOLD = true>; cg_sampler.hip).  Instead
+// of a separate launch that forms p = r + beta p and s.*p (cg_direction_kernel),
+// the Tdot epilogue of iteration k-1 also leaves s.*r and the partials of
+// <offset, (s.*r)[1:]>, and EVERY workgroup of the X~ v kernel
+//   * re-adds the NPART partials of r.r in the fixed order -> rho, the stop
+//     test of SciPy's loop top, beta = rho / rho_prev;
+//   * fills its LDS slices with  s.*p_k = s.*r_k + beta s.*p_{k-1}  (two
+//     coalesced vector reads instead of one: the recurrence is linear in s);
+//   * gets the epilogue constant <offset, (s.*p_k)[1:]> = <offset, (s.*r)[1:]>
+//     + beta <offset, (s.*p_{k-1})[1:]> from two scalars (CGState::coff);
+// and the workgroups, each for its own contiguous share of the P coordinates,
+// write p_k, s.*p_k (into the OTHER of two buffers: the old one is still being
+// read by the other workgroups' slice fills) and the partials of <p, d p>.
+// Three launches per CG iteration instead of four, no grid-wide reduction
+// inside a launch.
+struct DotFold {
+  CGState* st = nullptr;
+  int k = 0;
+  int intercept = 0;
+  int64_t P = 0;
+  const double* rr_part = nullptr;  // NPART partials of r.r
+  const double* cr_part = nullptr;  // NPART partials of <offset, (s.*r)[1:]>
+  const double* sr = nullptr;       // s.*r      (P; [intercept:] 16-byte aligned)
+  const double* sp_old = nullptr;   // s.*p_{k-1} (same layout; unread for k == 0)
+  double* sp_new = nullptr;         // s.*p_k
+  const double* r = nullptr;
+  double* pvec = nullptr;           // p, updated in place
+  const double* d = nullptr;
+  double* pdp_part = nullptr;       // NPART partials of <p, d p>
+};
+
 // out[P] = epilogue([sum w ; X_main^T w - sum(w) offset]).  `sumw_part` holds
 // the NPART partials of sum(w).
 int launch_tdot(bbx_design* h, const double* d_w, const double* d_sumw_part,
@@ -340,6 +379,15 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
 bool dense_fused_applies(const bbx_design* h);
 int build_tiled(bbx_design* h);
 void destroy_tiled(bbx_design* h);
+// Can the CG loop on this design fold its direction step into the X~ v kernel
+// (tiled format, one column group, one partial slot per panel, not a mixed
+// design; BBX_CG_FOLD=0 turns it off)?
+bool tiled_fold_applies(const bbx_design* h);
+// t = rowscale .* (X~ (s.*p_k)) with the direction step of iteration fa.k inside
+// (see DotFold); partials of sum(t) and of <t, Omega t> as launch_dot.
+int launch_dot_tiled_fold(bbx_design* h, const DotFold& fa,
+                          const double* d_rowscale, double* d_t,
+                          double* d_sum_part, double* d_twt_part);
 bool tiled_batch_value_free(const bbx_design* h);  // batches of any width (else pairs only)
 int ensure_tiled_k(bbx_design* h, int K);
 // predicted throughput of a batch of K chains / K single chains (cost model)

@@ -540,6 +540,258 @@ __global__ __launch_bounds__(1024) void dense_fused_ring_kernel(
   if (twt_part && tid == 0) twt_part[blockIdx.x] = twt;
 }
 
+
+// ---- the single pass for f64 STORAGE (the reference's own dtype) -------------
+//
+// Until round 3 f64 storage went through dense_fused_kernel<double, KQ, 2>: a
+// thread owned 4 adjacent doubles per group, i.e. 32 bytes per lane and load --
+// two 16-byte instructions whose lanes are 32 bytes apart (half-used lines per
+// instruction) -- and the LDS-DMA ring had no room for two rows of 8 008
+// doubles: 2.31 ms for 12.8 GB = 0.69 of peak, against 0.87 for f32 storage.
+// Here a thread owns G groups of TWO adjacent doubles (one 16-byte unit per
+// group, units 1024 apart): every load instruction of a wave reads 1 KiB of
+// contiguous bytes, exactly the f32 kernels' access shape, and a ROW of 8 008
+// doubles is what a two-row f32 block is -- 64 KB -- so the ring kernel runs
+// with one row per stage (RB = 1, D = 2: 128 KB of the 160 KB LDS).
+//   dense_fused_f64_kernel       next RB = 2 rows prefetched into registers
+//   dense_fused_f64_ring_kernel  LDS-DMA ring, RB rows per stage, D stages
+// Same arithmetic in both (explicit fma, the same lane-private sums, the same
+// wave / workgroup reduction order): bit-identical results.
+typedef double fused_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fused_d2 stream_load2(const fused_d2* p) {
+  return __builtin_nontemporal_load(p);
+}
+template <int G>
+__device__ __forceinline__ double fused_row_dot2(const fused_d2 (&x)[G],
+                                                 const fused_d2 (&vo)[G]) {
+  double a0 = 0., a1 = 0.;
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    a0 = fma(x[k].x, vo[k].x, a0);
+    a1 = fma(x[k].y, vo[k].y, a1);
+  }
+  return a0 + a1;
+}
+template <int G>
+__device__ __forceinline__ void fused_row_axpy2(const fused_d2 (&x)[G],
+                                                double wi, fused_d2 (&g)[G]) {
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    g[k].x = fma(x[k].x, wi, g[k].x);
+    g[k].y = fma(x[k].y, wi, g[k].y);
+  }
+}
+// this thread's slices of v and g: pairs q = tid + 1024 k of the ld / 2 pairs
+template <int G>
+__device__ __forceinline__ void fused_f64_setup(int tid, int64_t ldp, int64_t P,
+                                                const double* __restrict__ v,
+                                                fused_d2 (&vo)[G],
+                                                fused_d2 (&g)[G], bool (&has)[G]) {
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    const int64_t q = tid + 1024 * k;
+    has[k] = q < ldp;
+    vo[k] = fused_d2{0., 0.};
+    g[k] = fused_d2{0., 0.};
+    if (has[k]) {
+      vo[k].x = (2 * q < P) ? v[2 * q] : 0.;
+      vo[k].y = (2 * q + 1 < P) ? v[2 * q + 1] : 0.;
+    }
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(1024) void dense_fused_f64_kernel(
+    int64_t n, int64_t P, int64_t ld, int64_t rows_per_wg,
+    const double* __restrict__ X, const double* __restrict__ v,
+    const double* __restrict__ rowscale, double* __restrict__ slab,
+    const int* __restrict__ skip_flag, double* __restrict__ twt_part,
+    const double* __restrict__ addend) {
+  if (skip_flag && *skip_flag) return;  // the CG solve has already stopped
+  constexpr int RB = 2;
+  __shared__ double red[2][RB][1024 / WAVE];
+  double twt = 0.;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+  const int64_t ldp = ld / 2;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = (r0 + rows_per_wg < n) ? r0 + rows_per_wg : n;
+  fused_d2 vo[G], g[G];
+  bool has[G];
+  fused_f64_setup<G>(tid, ldp, P, v, vo, g, has);
+  const fused_d2* __restrict__ X2 = reinterpret_cast<const fused_d2*>(X);
+  fused_d2 xc[RB][G], xn[RB][G];
+  double sc[RB], sn[RB], ac[RB], an[RB];
+  auto load_block = [&](int64_t r, fused_d2 (&x)[RB][G], double (&s)[RB],
+                        double (&a)[RB]) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const bool ok = r + i < r1;
+      s[i] = ok ? (rowscale ? rowscale[r + i] : 1.) : 0.;
+      a[i] = (ok && addend) ? addend[r + i] : 0.;
+#pragma unroll
+      for (int k = 0; k < G; ++k)
+        x[i][k] = (ok && has[k]) ? stream_load2(X2 + (r + i) * ldp + tid + 1024 * k)
+                                 : fused_d2{0., 0.};
+    }
+  };
+  load_block(r0, xc, sc, ac);
+  int buf = 0;
+  for (int64_t r = r0; r < r1; r += RB) {
+    load_block(r + RB, xn, sn, an);  // in flight across the reduction below
+    double t[RB];
+    wave_sum_pair(fused_row_dot2<G>(xc[0], vo), fused_row_dot2<G>(xc[1], vo),
+                  t[0], t[1]);
+    if (lane == 0) {
+      red[buf][0][wave] = t[0];
+      red[buf][1][wave] = t[1];
+    }
+    __syncthreads();
+    block_sum_pair(&red[buf][0][0], lane, t[0], t[1]);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const double wi = sc[i] * t[i];
+      twt = fma(wi, t[i], twt);
+      fused_row_axpy2<G>(xc[i], wi + ac[i], g);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      sc[i] = sn[i];
+      ac[i] = an[i];
+#pragma unroll
+      for (int k = 0; k < G; ++k) xc[i][k] = xn[i][k];
+    }
+    buf ^= 1;
+  }
+  fused_d2* __restrict__ dst =
+      reinterpret_cast<fused_d2*>(slab + (int64_t)blockIdx.x * ld);
+#pragma unroll
+  for (int k = 0; k < G; ++k)
+    if (has[k]) dst[tid + 1024 * k] = g[k];
+  if (twt_part && tid == 0) twt_part[blockIdx.x] = twt;
+}
+
+template <int G, int RB, int D>
+__global__ __launch_bounds__(1024) void dense_fused_f64_ring_kernel(
+    int64_t n, int64_t P, int64_t ld, int64_t rows_per_wg,
+    const double* __restrict__ X, const double* __restrict__ v,
+    const double* __restrict__ rowscale, double* __restrict__ slab,
+    const int* __restrict__ skip_flag, double* __restrict__ twt_part,
+    const double* __restrict__ addend) {
+  static_assert(RB == 1 || RB == 2, "rows per ring stage");
+  if (skip_flag && *skip_flag) return;  // the CG solve has already stopped
+  double twt = 0.;
+  constexpr int SLOT_Q = G * 1024;      // 16-byte units per row slot
+  constexpr int NWAVE = 1024 / WAVE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fused_smem[];
+  fused_d2* ring = reinterpret_cast<fused_d2*>(fused_smem);  // [D * RB][SLOT_Q]
+  double* red = reinterpret_cast<double*>(fused_smem + (size_t)D * RB * SLOT_Q * 16);
+  double* rs = red + 2 * 2 * NWAVE;     // [rows_per_wg + 8]
+  double* ad = rs + rows_per_wg + 8;    // [rows_per_wg + 8]
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+  const int64_t ldp = ld / 2;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = (r0 + rows_per_wg < n) ? r0 + rows_per_wg : n;
+  fused_d2 vo[G], g[G];
+  bool has[G];
+  fused_f64_setup<G>(tid, ldp, P, v, vo, g, has);
+  int64_t qs[G];  // source unit of this thread (clamped: every lane issues)
+#pragma unroll
+  for (int k = 0; k < G; ++k) qs[k] = has[k] ? tid + 1024 * k : ldp - 1;
+  fused_d2* __restrict__ dst =
+      reinterpret_cast<fused_d2*>(slab + (int64_t)blockIdx.x * ld);
+  if (r0 >= r1) {  // no rows: a zero slab
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+      if (has[k]) dst[tid + 1024 * k] = g[k];
+    if (twt_part && tid == 0) twt_part[blockIdx.x] = 0.;
+    return;
+  }
+  const int n_rows = (int)(r1 - r0);
+  const int n_blk = (n_rows + RB - 1) / RB;
+  for (int j = tid; j < n_blk * RB; j += 1024) {
+    rs[j] = j < n_rows ? (rowscale ? rowscale[r0 + j] : 1.) : 0.;
+    ad[j] = (j < n_rows && addend) ? addend[r0 + j] : 0.;
+  }
+  if (tid < 2 * 2 * NWAVE) red[tid] = 0.;   // (RB == 1: the second row stays 0)
+  // every compiler-visible load is retired before the counted ring starts
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+  __syncthreads();
+  const fused_d2* __restrict__ X2 = reinterpret_cast<const fused_d2*>(X);
+  const unsigned ring_lds = (unsigned)(uintptr_t)ring;
+  // Rows past the end are clamped to the last row (their scale is 0): every
+  // wave issues exactly RB * G DMA instructions per block (the counted waits)
+  auto issue = [&](int b, int slot) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int64_t row = r0 + (int64_t)b * RB + i;
+      if (row >= r1) row = r1 - 1;
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        const unsigned dst_lds = __builtin_amdgcn_readfirstlane(
+            ring_lds + (unsigned)(((slot * RB + i) * SLOT_Q + k * 1024 + wave * WAVE) * 16));
+        glds16(X2 + row * ldp + qs[k], dst_lds);
+      }
+    }
+  };
+  constexpr int PER_BLOCK = RB * G;
+#pragma unroll
+  for (int b = 0; b < D; ++b)
+    if (b < n_blk) issue(b, b);
+  int slot = 0, buf = 0;
+  for (int b = 0; b < n_blk; ++b) {
+    if (b + D <= n_blk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PER_BLOCK) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    fused_d2 xc[RB][G];
+    double sc[RB], ac[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      sc[i] = rs[b * RB + i];
+      ac[i] = ad[b * RB + i];
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        xc[i][k] = ring[(size_t)(slot * RB + i) * SLOT_Q + k * 1024 + tid];
+        if (!has[k]) xc[i][k] = fused_d2{0., 0.};
+      }
+    }
+    // the slot's bytes are in registers: refill it D blocks ahead
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (b + D < n_blk) issue(b + D, slot);
+    // row sums: the two-row exchange of the register form (RB == 1: its second
+    // row is 0.0 -- the first row's additions are the same ones, in order)
+    double t[2];
+    wave_sum_pair(fused_row_dot2<G>(xc[0], vo),
+                  RB == 2 ? fused_row_dot2<G>(xc[RB - 1], vo) : 0., t[0], t[1]);
+    if (lane == 0) {
+      red[(buf * 2 + 0) * NWAVE + wave] = t[0];
+      if (RB == 2) red[(buf * 2 + 1) * NWAVE + wave] = t[1];
+    }
+    // LDS writes visible, then the barrier; the DMAs in flight are NOT waited for
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    block_sum_pair(red + buf * 2 * NWAVE, lane, t[0], t[1]);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const double wi = sc[i] * t[i];
+      twt = fma(wi, t[i], twt);
+      fused_row_axpy2<G>(xc[i], wi + ac[i], g);
+    }
+    buf ^= 1;
+    slot = (slot + 1 == D) ? 0 : slot + 1;
+  }
+#pragma unroll
+  for (int k = 0; k < G; ++k)
+    if (has[k]) dst[tid + 1024 * k] = g[k];
+  if (twt_part && tid == 0) twt_part[blockIdx.x] = twt;
+}
+
+static size_t fused_f64_ring_lds(int G, int RB, int D, int64_t rows_per_wg) {
+  return (size_t)D * RB * G * 1024 * 16 + sizeof(double) * 2 * 2 * 16 +
+         2 * sizeof(double) * (size_t)(rows_per_wg + 8);
+}
+
 static size_t fused_ring_lds(int KQ, int RB, int D, int64_t rows_per_wg) {
   return (size_t)D * RB * KQ * 1024 * 16 + sizeof(double) * 2 * RB * 16 +
          2 * sizeof(double) * (size_t)(rows_per_wg + 8);
@@ -597,8 +849,35 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
   const bool ring = h->dense_dtype == BBX_F32 && ring_env != 0 &&
                     (ring_env > 0 || rows_per_wg >= 64) &&
                     fused_ring_lds(2, 2, 2, rows_per_wg) <= 160 * 1024;
+  // f64 storage: pairs of doubles per thread and group (see the kernels); a
+  // stage of the ring is one row of <= 8192 doubles or two of <= 4096 (64 KB)
+#define BBX_F64_LAUNCH(GG)                                                     \
+  hipLaunchKernelGGL((dense_fused_f64_kernel<GG>), dim3(wgs), dim3(1024), 0,   \
+                     h->stream, h->n, h->P, h->dense_ld, rows_per_wg,          \
+                     h->dense.as<double>(), d_v, d_rowscale,                   \
+                     h->dense_fused_slab.as<double>(), h->skip_flag,           \
+                     d_twt_part, d_addend)
+#define BBX_F64_RING_LAUNCH(GG, RB, D)                                         \
+  do {                                                                         \
+    const size_t lb = fused_f64_ring_lds(GG, RB, D, rows_per_wg);              \
+    BBX_HIP(hipFuncSetAttribute(                                               \
+        reinterpret_cast<const void*>(&dense_fused_f64_ring_kernel<GG, RB, D>), \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
+    hipLaunchKernelGGL((dense_fused_f64_ring_kernel<GG, RB, D>), dim3(wgs),    \
+                       dim3(1024), lb, h->stream, h->n, h->P, h->dense_ld,     \
+                       rows_per_wg, h->dense.as<double>(), d_v, d_rowscale,    \
+                       h->dense_fused_slab.as<double>(), h->skip_flag,         \
+                       d_twt_part, d_addend);                                  \
+  } while (0)
   if (h->dense_dtype != BBX_F32) {
-    if (kq1) BBX_FUSED_LAUNCH(double, 1, 2); else BBX_FUSED_LAUNCH(double, 2, 2);
+    const bool g2 = h->dense_ld <= 4096;
+    const bool ring64 = ring_env != 0 && (ring_env > 0 || rows_per_wg >= 64) &&
+                        fused_f64_ring_lds(4, 1, 2, rows_per_wg) <= 160 * 1024;
+    if (ring64) {
+      if (g2) BBX_F64_RING_LAUNCH(2, 2, 2); else BBX_F64_RING_LAUNCH(4, 1, 2);
+    } else {
+      if (g2) BBX_F64_LAUNCH(2); else BBX_F64_LAUNCH(4);
+    }
   } else if (ring) {
     if (kq1) BBX_RING_LAUNCH(1, 2, 2); else BBX_RING_LAUNCH(2, 2, 2);
   } else if (kq1) {
@@ -608,6 +887,8 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
   }
 #undef BBX_FUSED_LAUNCH
 #undef BBX_RING_LAUNCH
+#undef BBX_F64_LAUNCH
+#undef BBX_F64_RING_LAUNCH
   BBX_TRY(timer_end(h, 0));
   BBX_HIP(hipGetLastError());
   return launch_tdot_finalize_dense(h, ep, d_out,
@@ -645,7 +926,7 @@ int launch_dot_dense(bbx_design* h, const double* d_v,
   const size_t lds = sizeof(double) * (size_t)h->dense_ld;
   if (lds > 150 * 1024)
     return fail(BBX_ERR_INVALID, "dense operator: more than 19200 columns");
-  // opt-in matrix-core variant (A/B only: DESIGN.md 3.3)
+  // opt-in matrix-core variant (A/B only: LABNOTES.md 3.3)
   static const bool use_mfma =
       getenv("BBX_DENSE_MFMA") && atoi(getenv("BBX_DENSE_MFMA")) == 1;
   BBX_TRY(timer_begin(h, 0));

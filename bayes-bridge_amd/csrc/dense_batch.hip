@@ -3,7 +3,7 @@
 //
 // A GEMV cannot feed v_mfma_f64_16x16x4_f64 (one right-hand side: 15 of the 16
 // columns of B are padding; measured 1.7x SLOWER than the vector ALUs,
-// DESIGN.md 3.3).  K chains that share the pass over X are the shape that can:
+// LABNOTES.md 3.3).  K chains that share the pass over X are the shape that can:
 //   T[n x K] = X[n x P] V[P x K]          (dense_matrix.py:42, K at a time)
 //   G[P x K] = X^T[P x n] W[n x K]        (dense_matrix.py:52, K at a time)
 // with the chains in the 16 columns of B / D (32 chains: two B operands per A
@@ -698,7 +698,7 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
   return BBX_OK;
 }
 
-// The cost model's view of a dense batch (measured figures): one
+// The cost model's view of a dense batch (measured figures, LABNOTES.md 3.6): one
 // chain applies the operator in ONE pass over the matrix where the single-pass
 // kernel applies (0.93 ms at 200k x 8k f32, 2.31 ms in f64), a batch needs
 // TWO passes for all its chains together -- stream-bound up to 16 chains

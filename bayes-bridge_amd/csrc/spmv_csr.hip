@@ -123,7 +123,10 @@ __device__ inline double block_sum_256(double x) {
 // (the epilogue mode is a template parameter: the kernel runs twice per CG
 // iteration and is pure latency, so the branches and loads of the modes it is
 // not in are worth compiling away)
-template <int mode>
+// FOLD (TD_OPER_UPD / TD_RESID): the new residual also goes out scaled, s.*r,
+// with the partials of <offset, (s.*r)[1:]> -- what the folded direction step
+// of the next X~ v kernel starts from (common.hpp DotFold).
+template <int mode, bool FOLD = false>
 __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
     int64_t p, int intercept, const int32_t* __restrict__ row_chunk_ptr,
     const double* __restrict__ partial, const double* __restrict__ gfull,
@@ -136,7 +139,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
     // TD_OPER_UPD (x is the search direction p):
     double* __restrict__ cg_x, double* __restrict__ cg_r,
     CGState* __restrict__ cg_state, int cg_k,
-    const double* __restrict__ pdp_part, const double* __restrict__ twt_part) {
+    const double* __restrict__ pdp_part, const double* __restrict__ twt_part,
+    double* __restrict__ fold_sr, double* __restrict__ fold_cr_part) {
   const int64_t P = p + intercept;
   const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
   const int64_t jj0 = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x;
@@ -208,10 +212,11 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
   __syncthreads();
   const double sumw = s_sumw;
   const double alpha = (mode == TD_OPER_UPD) ? rho / s_pap : 0.;
-  double dacc = 0.;
+  double dacc = 0., cacc = 0.;
   for (int64_t jj = jj0; jj < P; jj += stride) {
     const bool first = jj == jj0;
     double g;
+    double off_j = 0.;   // centring offset of this coordinate (0 for the intercept)
     if (intercept && jj == 0) {
       g = sumw;
     } else {
@@ -240,7 +245,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
         const int32_t cb = row_chunk_ptr[j], ce = row_chunk_ptr[j + 1];
         for (int32_t c = cb; c < ce; ++c) g += partial[c];
       }
-      g -= sumw * (first ? off0 : offset[j]);
+      off_j = first ? off0 : offset[j];
+      g -= sumw * off_j;
     }
     double r;
     if (mode == TD_OPER) {
@@ -254,6 +260,11 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
       r = (first ? e3 : cg_r[jj]) - alpha * q;
       cg_r[jj] = r;
       dacc += r * r;
+      if (FOLD) {
+        const double srj = (first ? e2 : s[jj]) * r;
+        fold_sr[jj] = srj;
+        cacc += off_j * srj;
+      }
       continue;
     } else if (mode == TD_RESID) {
       r = (first ? e3 : s[jj]) *
@@ -261,6 +272,11 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
            ((first ? e1 : phi[jj]) * (first ? e2 : eta2[jj]) - g));
       if (x) r -= d[jj] * x[jj];
       dacc += r * r;
+      if (FOLD) {
+        const double srj = (first ? e3 : s[jj]) * r;
+        fold_sr[jj] = srj;
+        cacc += off_j * srj;
+      }
     } else {
       r = g;
     }
@@ -269,6 +285,10 @@ __global__ __launch_bounds__(VEC_BLOCK) void tdot_finalize_kernel(
   if (dot_part) {
     const double tot = block_sum_256(dacc);
     if (threadIdx.x == 0) dot_part[blockIdx.x] = tot;
+  }
+  if (FOLD) {
+    const double tot = block_sum_256(cacc);
+    if (threadIdx.x == 0) fold_cr_part[blockIdx.x] = tot;
   }
   if (mode == TD_OPER_UPD && blockIdx.x == 0 && threadIdx.x == 0)
     cg_state->n_iter = cg_k + 1;
@@ -323,25 +343,34 @@ int launch_dot_csr(bbx_design* h, const double* d_v, const double* d_rowscale,
 }
 
 #define BBX_FINALIZE_MODES(LAUNCH)                                             \
+  if (ep.fold_sr && ep.mode != TD_OPER_UPD && ep.mode != TD_RESID)             \
+    return fail(BBX_ERR_INVALID, "fold outputs need TD_OPER_UPD or TD_RESID"); \
   switch (ep.mode) {                                                           \
-    case TD_PLAIN: LAUNCH(TD_PLAIN); break;                                    \
-    case TD_OPER: LAUNCH(TD_OPER); break;                                      \
-    case TD_OPER_UPD: LAUNCH(TD_OPER_UPD); break;                              \
-    case TD_RESID: LAUNCH(TD_RESID); break;                                    \
+    case TD_PLAIN: LAUNCH(TD_PLAIN, false); break;                             \
+    case TD_OPER: LAUNCH(TD_OPER, false); break;                               \
+    case TD_OPER_UPD:                                                          \
+      if (ep.fold_sr) LAUNCH(TD_OPER_UPD, true);                               \
+      else LAUNCH(TD_OPER_UPD, false);                                         \
+      break;                                                                   \
+    case TD_RESID:                                                             \
+      if (ep.fold_sr) LAUNCH(TD_RESID, true);                                  \
+      else LAUNCH(TD_RESID, false);                                            \
+      break;                                                                   \
     default: return fail(BBX_ERR_INVALID, "unknown Tdot epilogue mode");       \
   }
 
 int launch_tdot_finalize(bbx_design* h, const double* d_gfull, int n_slab,
                          const double* d_sumw_part, const TdotEpilogue& ep,
                          double* d_out) {
-#define BBX_FIN(MODE)                                                          \
-  hipLaunchKernelGGL(tdot_finalize_kernel<MODE>, dim3(NPART), dim3(VEC_BLOCK), \
-                     0, h->stream, h->p, h->intercept,                         \
+#define BBX_FIN(MODE, FF)                                                      \
+  hipLaunchKernelGGL((tdot_finalize_kernel<MODE, FF>), dim3(NPART),            \
+                     dim3(VEC_BLOCK), 0, h->stream, h->p, h->intercept,        \
                      h->t_row_chunk_ptr.as<int32_t>(),                         \
                      h->t_partial.as<double>(), d_gfull, n_slab, h->p,         \
                      h->offset.as<double>(), d_sumw_part, ep.s, ep.d, ep.x,    \
                      ep.z, ep.phi, ep.eta2, d_out, ep.dot_part, ep.cg_x,       \
-                     ep.cg_r, ep.cg_state, ep.cg_k, ep.pdp_part, ep.twt_part)
+                     ep.cg_r, ep.cg_state, ep.cg_k, ep.pdp_part, ep.twt_part,  \
+                     ep.fold_sr, ep.fold_cr_part)
   BBX_FINALIZE_MODES(BBX_FIN)
 #undef BBX_FIN
   BBX_HIP(hipGetLastError());
@@ -353,15 +382,15 @@ int launch_tdot_finalize(bbx_design* h, const double* d_gfull, int n_slab,
 int launch_tdot_finalize_dense(bbx_design* h, const TdotEpilogue& ep,
                                double* d_out, const double* d_slab,
                                int n_slab) {
-#define BBX_FIN(MODE)                                                          \
-  hipLaunchKernelGGL(tdot_finalize_kernel<MODE>, dim3(NPART), dim3(VEC_BLOCK), \
-                     0, h->stream, h->P, 0, nullptr, nullptr,                  \
+#define BBX_FIN(MODE, FF)                                                      \
+  hipLaunchKernelGGL((tdot_finalize_kernel<MODE, FF>), dim3(NPART),            \
+                     dim3(VEC_BLOCK), 0, h->stream, h->P, 0, nullptr, nullptr, \
                      d_slab ? d_slab : h->dense_slab.as<double>(),             \
                      d_slab ? n_slab : h->dense_chunks, h->dense_ld,           \
                      h->offset.as<double>(), part_slot(h, PS_ZERO), ep.s,      \
                      ep.d, ep.x, ep.z, ep.phi, ep.eta2, d_out, ep.dot_part,    \
                      ep.cg_x, ep.cg_r, ep.cg_state, ep.cg_k, ep.pdp_part,      \
-                     ep.twt_part)
+                     ep.twt_part, ep.fold_sr, ep.fold_cr_part)
   BBX_FINALIZE_MODES(BBX_FIN)
 #undef BBX_FIN
   BBX_HIP(hipGetLastError());

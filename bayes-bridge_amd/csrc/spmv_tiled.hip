@@ -248,7 +248,12 @@ constexpr int FILL_K_PAIRS =
 // NPART-block per chain `part_stride` doubles apart, rowscale_k / out_k are
 // per-chain pointers (out_k.p[c][row * out_stride]: out_stride = K with
 // p[c] = base + c writes an interleaved [R][K] result), slab is [G][R][K].
-template <bool VALS, bool WIDE, int KP>
+//
+// FOLD (KP == 0, WIDE): the direction step of CG iteration fa.k rides in this
+// launch (common.hpp DotFold): x is s.*r, the slices are filled with
+// s.*r + beta s.*p_old, the epilogue constant comes from fa / CGState, and the
+// workgroup writes p, s.*p and <p, d p> for its share of the coordinates.
+template <bool VALS, bool WIDE, int KP, bool FOLD = false>
 __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_kernel(
     int64_t R, int64_t C, int W, int PR, int G, int blocks_per_group,
     const int32_t* __restrict__ wave_desc, int desc_stride,
@@ -264,7 +269,8 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     double* __restrict__ out_sum_part, int twt_off, int ablate,
     unsigned long long* dbg, const int* __restrict__ skip_flag,
     ChainPtrs rowscale_k, ChainOut out_k, int out_stride, int part_stride,
-    const double* __restrict__ addend) {
+    const double* __restrict__ addend, DotFold fa) {
+  static_assert(!FOLD || (KP == 0 && WIDE), "the folded direction step is single-chain");
   constexpr int K = KP > 0 ? 2 * KP : 1;
   // (scalar load, issued first; checked below once the descriptor loads that
   // every launch needs anyway have been issued, so it adds no round trip)
@@ -336,9 +342,92 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   const uint4* __restrict__ desc4 = reinterpret_cast<const uint4*>(descs);
   uint4 dcur = desc4[blk + lane];
   uint4 dnxt = desc4[blk + WAVE + lane];
+  // FOLD: everything the direction step reads goes out with the descriptor
+  // loads -- one round trip for both.  Every WAVE re-adds the partials itself
+  // (2 KB from L2 per wave): no LDS broadcast, no barrier.
+  double f_rr[NPART / WAVE], f_cr[NPART / WAVE];
+  double f_atol = 0., f_rho_prev = 1., f_coff_prev = 0., f_x0r = 0., f_x0p = 0.;
+  double f_r0 = 0., f_p0 = 0., f_d0 = 0., f_sr0 = 0., f_sp0 = 0.;
+  double f_beta = 0., f_c = 0., f_pdp = 0.;
+  int64_t f_j0 = 0, f_j1 = 0;
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int k4 = 0; k4 < NPART / WAVE; ++k4) {
+      f_rr[k4] = fa.rr_part[lane + k4 * WAVE];
+      f_cr[k4] = fa.cr_part[lane + k4 * WAVE];
+    }
+    f_atol = fa.st->atol;
+    if (fa.k > 0) {
+      f_rho_prev = fa.st->rho[(fa.k - 1) & 1];
+      f_coff_prev = fa.st->coff[(fa.k - 1) & 1];
+    }
+    if (fa.intercept) {
+      f_x0r = fa.sr[0];
+      if (fa.k > 0) f_x0p = fa.sp_old[0];
+    }
+    // this workgroup's share of the P coordinates (p, s.*p, <p, d p>)
+    const int64_t chunk = (fa.P + n_wg - 1) / n_wg;
+    f_j0 = (int64_t)bid * chunk;
+    f_j1 = f_j0 + chunk < fa.P ? f_j0 + chunk : fa.P;
+    if (f_j0 + tid < f_j1) {
+      const int64_t j = f_j0 + tid;
+      f_r0 = fa.r[j];
+      f_d0 = fa.d[j];
+      f_sr0 = fa.sr[j];
+      if (fa.k > 0) {
+        f_p0 = fa.pvec[j];
+        f_sp0 = fa.sp_old[j];
+      }
+    }
+  }
   // Retire every compiler-visible load before the ring starts (see ISSUE).
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
   if (skip) return;  // the CG solve this launch belongs to has already stopped
+  if constexpr (FOLD) {
+    // top of SciPy's cg loop (vecops.hip cg_direction_kernel): rho = r.r, the
+    // same adds in the same order in every wave of every workgroup
+    double a = 0., cr = 0.;
+#pragma unroll
+    for (int k4 = 0; k4 < NPART / WAVE; ++k4) {
+      a += f_rr[k4];
+      cr += f_cr[k4];
+    }
+    const double rho = wave_allsum(a);
+    cr = wave_allsum(cr);
+    const bool finite = (rho == rho) && (rho - rho == 0.);
+    if (!finite || sqrt(rho) < f_atol) {   // uniform over the whole grid
+      if (bid == 0 && tid == 0) {
+        fa.st->done = 1;
+        if (!finite) fa.st->bad = 1;
+      }
+      return;
+    }
+    double beta = 0., coff = cr, x0n = f_x0r;
+    if (fa.k > 0) {
+      beta = rho / f_rho_prev;
+      coff = fma(beta, f_coff_prev, cr);
+      x0n = fma(beta, f_x0p, f_x0r);
+    }
+    // wave-uniform scalars
+    f_beta = lane_value(beta, 0);
+    f_c = lane_value(x0n - coff, 0);   // c = v0 - <offset, v[1:]>, v = s.*p
+    if (bid == 0 && tid == 0) {
+      fa.st->rho[fa.k & 1] = rho;
+      fa.st->coff[fa.k & 1] = coff;
+    }
+    for (int64_t j = f_j0 + tid; j < f_j1; j += TILE_THREADS) {
+      const bool first = j == f_j0 + tid;
+      double pj = first ? f_r0 : fa.r[j];
+      double spj = first ? f_sr0 : fa.sr[j];
+      if (fa.k > 0) {
+        pj = fma(f_beta, first ? f_p0 : fa.pvec[j], pj);
+        spj = fma(f_beta, first ? f_sp0 : fa.sp_old[j], spj);
+      }
+      fa.pvec[j] = pj;
+      fa.sp_new[j] = spj;   // the formula of the slice fill, bit for bit
+      f_pdp = fma((first ? f_d0 : fa.d[j]) * pj, pj, f_pdp);
+    }
+  }
   // (Round 2 tried to move the FIRST slice fill up here, next to the descriptor
   // loads, and to enter the loop with the ring primed but not waited for: the
   // kernel then faulted intermittently.  Without the vmcnt(0) of the first
@@ -478,6 +567,10 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
             } else {
               constexpr int FILL_PAIRS = (FILL_UNROLL + 1) / 2;
               v2d fp[FILL_PAIRS];
+              // FOLD: the matching piece of s.*p_old (iteration > 0)
+              v2d fq[FOLD ? FILL_PAIRS : 1];
+              const double* xo = FOLD ? fa.sp_old + fa.intercept : nullptr;
+              const bool two = FOLD && fa.k > 0;
               // (WIDE is chosen by the launcher: x and W * 8 are 16-byte aligned)
               constexpr bool wide = WIDE;
               if (wide) {
@@ -486,9 +579,15 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
                   const int j = 2 * (tid + u * TILE_THREADS);
                   if (j + 1 < cols_here && !(ablate & 2)) {
                     fp[u] = *reinterpret_cast<const v2d*>(x + col0 + j);
+                    if constexpr (FOLD)
+                      if (two) fq[u] = *reinterpret_cast<const v2d*>(xo + col0 + j);
                   } else {
                     fp[u].x = (j < cols_here && !(ablate & 2)) ? x[col0 + j] : 0.;
                     fp[u].y = 0.;
+                    if constexpr (FOLD) {
+                      fq[u].x = (two && j < cols_here) ? xo[col0 + j] : 0.;
+                      fq[u].y = 0.;
+                    }
                   }
                 }
               } else {
@@ -507,6 +606,15 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
               // compiler-visible load is left "maybe pending" inside the loop
               __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
               if (wide) {
+                if constexpr (FOLD) {
+                  if (two) {   // s.*p_k = s.*r_k + beta s.*p_{k-1}
+  #pragma unroll
+                    for (int u = 0; u < FILL_PAIRS; ++u) {
+                      fp[u].x = fma(f_beta, fq[u].x, fp[u].x);
+                      fp[u].y = fma(f_beta, fq[u].y, fp[u].y);
+                    }
+                  }
+                }
   #pragma unroll
                 for (int u = 0; u < FILL_PAIRS; ++u) {
                   const int j = 2 * (tid + u * TILE_THREADS);
@@ -724,10 +832,12 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
         const int r = tid + u * TILE_THREADS;
         rs_pre[u] = (rowscale && r < rows_here) ? rowscale[row0 + r] : 1.;
       }
+      if constexpr (!FOLD) {
   #pragma unroll
-      for (int k = 0; k < NPART / WAVE; ++k)
-        cp_pre[k] = c_part ? c_part[lane + k * WAVE] : 0.;
-      if (x0_ptr) x0_pre = *x0_ptr;
+        for (int k = 0; k < NPART / WAVE; ++k)
+          cp_pre[k] = c_part ? c_part[lane + k * WAVE] : 0.;
+        if (x0_ptr) x0_pre = *x0_ptr;
+      }
     }
     __syncthreads();
     {  // fold the chunk accumulators of split rows, fixed order
@@ -742,17 +852,21 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     }
     if (out) {
       // direct epilogue: c = x0 - sum(c_part), summed once in a fixed order
-      if (tid < WAVE) {
-        double cs = 0.;
-        if (c_part) {
+      // (FOLD: every thread holds it since the direction step)
+      double c = f_c;
+      if constexpr (!FOLD) {
+        if (tid < WAVE) {
+          double cs = 0.;
+          if (c_part) {
   #pragma unroll
-          for (int k = 0; k < NPART / WAVE; ++k) cs += cp_pre[k];
-          cs = wave_allsum(cs);
+            for (int k = 0; k < NPART / WAVE; ++k) cs += cp_pre[k];
+            cs = wave_allsum(cs);
+          }
+          if (tid == 0) xs[0] = x0_pre - cs;
         }
-        if (tid == 0) xs[0] = x0_pre - cs;
+        __syncthreads();
+        c = xs[0];
       }
-      __syncthreads();
-      const double c = xs[0];
       double tsum = 0., t2sum = 0.;
   #pragma unroll
       for (int u = 0; u < EPI_UNROLL; ++u) {
@@ -775,25 +889,30 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
         // twt_off doubles after the sum's slot.
         tsum = wave_allsum(tsum);
         t2sum = wave_allsum(t2sum);
+        if constexpr (FOLD) f_pdp = wave_allsum(f_pdp);
         __syncthreads();
         if (lane == 0) {
           xs[wave] = tsum;
           xs[TILE_WAVES + wave] = t2sum;
+          if constexpr (FOLD) xs[2 * TILE_WAVES + wave] = f_pdp;
         }
         __syncthreads();
         if (tid == 0) {
-          double tot = 0., tot2 = 0.;
+          double tot = 0., tot2 = 0., tot3 = 0.;
           for (int wv = 0; wv < TILE_WAVES; ++wv) {
             tot += xs[wv];
             tot2 += xs[TILE_WAVES + wv];
+            if constexpr (FOLD) tot3 += xs[2 * TILE_WAVES + wv];
           }
           out_sum_part[bid] = tot;
           if (twt_off) out_sum_part[twt_off + bid] = tot2;
+          if constexpr (FOLD) fa.pdp_part[bid] = tot3;   // <p, d p> of this share
         }
         // consumers add NPART slots: the first workgroup clears the unused ones
         if (bid == 0 && (int)gridDim.x + tid < NPART) {
           out_sum_part[gridDim.x + tid] = 0.;
           if (twt_off) out_sum_part[twt_off + (int)gridDim.x + tid] = 0.;
+          if constexpr (FOLD) fa.pdp_part[gridDim.x + tid] = 0.;
         }
       }
     } else {
@@ -1076,17 +1195,18 @@ int build_tiled(bbx_design* h) {
   const int st_h = no_throw([&]() -> int { return build_hybrid(h); });
   if (st_h < 0) return st_h;
   if (st_h != BBX_OK) BBX_TRY(build_tiled_pair(h, 1, &h->tiled));
-#define BBX_TILED_ATTR(VV, WW, KK)                                             \
+#define BBX_TILED_ATTR(VV, WW, KK, FF)                                         \
   BBX_HIP(hipFuncSetAttribute(                                                 \
-      reinterpret_cast<const void*>(&tiled_spmv_kernel<VV, WW, KK>),           \
+      reinterpret_cast<const void*>(&tiled_spmv_kernel<VV, WW, KK, FF>),       \
       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-  BBX_TILED_ATTR(false, false, 0);
-  BBX_TILED_ATTR(false, true, 0);
-  BBX_TILED_ATTR(true, false, 0);
-  BBX_TILED_ATTR(true, true, 0);
-  BBX_TILED_ATTR(false, true, 1);
-  BBX_TILED_ATTR(false, true, 2);
-  BBX_TILED_ATTR(true, true, 1);
+  BBX_TILED_ATTR(false, false, 0, false);
+  BBX_TILED_ATTR(false, true, 0, false);
+  BBX_TILED_ATTR(true, false, 0, false);
+  BBX_TILED_ATTR(true, true, 0, false);
+  BBX_TILED_ATTR(false, true, 1, false);
+  BBX_TILED_ATTR(false, true, 2, false);
+  BBX_TILED_ATTR(true, true, 1, false);
+  BBX_TILED_ATTR(false, true, 0, true);   // folded direction step (CG loop)
 #undef BBX_TILED_ATTR
   // The reference-layout index arrays stay in HBM (0.8 GB at 1M x 50k, next to
   // 288 GB): a layout sized for K batched chains is built from them on first
@@ -1216,7 +1336,8 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                         double* out_sum_part, hipEvent_t ev_begin = nullptr,
                         hipEvent_t ev_end = nullptr, int twt_off = 0,
                         const TiledBatchArgs* ba = nullptr,
-                        const double* addend = nullptr) {
+                        const double* addend = nullptr,
+                        const DotFold* fold = nullptr) {
   const unsigned grid = (unsigned)(m.n_panel * m.G);
   const size_t lb = lds_bytes(m);
   // Instrumented builds only (-DBBX_TILED_INSTRUMENT=1; the product library
@@ -1243,8 +1364,11 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
   }
   static const TiledBatchArgs no_batch{};
   const TiledBatchArgs& bb = ba ? *ba : no_batch;
+  const DotFold fa = fold ? *fold : DotFold{};
 #define BBX_TILED_LAUNCH_W(VV, WW, KK, VALPTR)                                 \
-  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, WW, KK>), dim3(grid),           \
+  BBX_TILED_LAUNCH_F(VV, WW, KK, false, VALPTR)
+#define BBX_TILED_LAUNCH_F(VV, WW, KK, FF, VALPTR)                             \
+  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, WW, KK, FF>), dim3(grid),       \
                      dim3(TILE_THREADS), (unsigned)lb, h->stream, ev_begin,    \
                      ev_end, 0u, m.R, m.C, m.W, m.PR,                          \
                      m.G, (m.n_block + m.G - 1) / m.G,                         \
@@ -1255,7 +1379,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                      m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),       \
                      out_sum_part, twt_off, ablate, dbg, h->skip_flag,         \
                      bb.rowscale, bb.out, bb.out_stride, bb.part_stride,       \
-                     addend)
+                     addend, fa)
 #define BBX_TILED_LAUNCH(VV, VALPTR)                                           \
   do {                                                                         \
     if (m.K == 2) BBX_TILED_LAUNCH_W(VV, true, 1, VALPTR);                \
@@ -1273,7 +1397,17 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
   // 1024-thread workgroup without scratch: valued designs batch two chains)
   if (m.K == 4 && m.has_vals)
     return fail(BBX_ERR_INVALID, "valued designs batch at most 2 chains");
-  if (m.K == 4)
+  if (fold) {
+    // folded direction step: single chain, 16-byte aligned vectors, the direct
+    // epilogue with its partial sums
+    if (m.K != 1 || !wide || m.G != 1 || !out || !out_sum_part || addend)
+      return fail(BBX_ERR_STATE, "folded direction step: unsupported launch");
+    // (with stored values the two fill vectors do not fit next to the value
+    // ring: 16 VGPRs would spill to scratch under an asm-issued ring)
+    if (m.has_vals)
+      return fail(BBX_ERR_STATE, "folded direction step: value-free layout only");
+    BBX_TILED_LAUNCH_F(false, true, 0, true, nullptr);
+  } else if (m.K == 4)
     BBX_TILED_LAUNCH_W(false, true, 2, nullptr);
   else if (m.has_vals)
     BBX_TILED_LAUNCH(true, m.vals.as<double>());
@@ -1281,6 +1415,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
     BBX_TILED_LAUNCH(false, nullptr);
 #undef BBX_TILED_LAUNCH
 #undef BBX_TILED_LAUNCH_W
+#undef BBX_TILED_LAUNCH_F
   BBX_HIP(hipGetLastError());
   if (dbg) {
     BBX_HIP(hipStreamSynchronize(h->stream));
@@ -1598,6 +1733,29 @@ int launch_dot_tiled(bbx_design* h, const double* d_v,
   return BBX_OK;
 }
 
+bool tiled_fold_applies(const bbx_design* h) {
+  static const bool on = !(getenv("BBX_CG_FOLD") && atoi(getenv("BBX_CG_FOLD")) == 0);
+  if (!on || !h->sparse || h->format != BBX_FORMAT_TILED || h->hybrid || !h->tiled)
+    return false;
+  const TiledMatrix& m = static_cast<const TiledPair*>(h->tiled)->x;
+  return m.G == 1 && m.n_panel <= NPART && !m.has_vals;
+}
+
+int launch_dot_tiled_fold(bbx_design* h, const DotFold& fa,
+                          const double* d_rowscale, double* d_t,
+                          double* d_sum_part, double* d_twt_part) {
+  if (!tiled_fold_applies(h))
+    return fail(BBX_ERR_STATE, "folded direction step does not apply");
+  const TiledMatrix& m = static_cast<TiledPair*>(h->tiled)->x;
+  h->n_dot += 1;
+  const int twt_off = d_twt_part ? (int)(d_twt_part - d_sum_part) : 0;
+  hipEvent_t ea, eb;
+  BBX_TRY(timer_arm(h, 0, &ea, &eb));
+  return launch_tiled(h, m, fa.sr + h->intercept, nullptr,
+                      h->intercept ? fa.sr : nullptr, d_rowscale, d_t, nullptr,
+                      d_sum_part, ea, eb, twt_off, nullptr, nullptr, &fa);
+}
+
 int launch_tdot_tiled(bbx_design* h, const double* d_w,
                       const double* d_sumw_part, const TdotEpilogue& ep,
                       double* d_out) {
@@ -1849,6 +2007,10 @@ int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
   // P-vector out) is outside it.
   *dot_bytes = tp->x.stream_bytes() + 8 * (h->P + h->n) +
                (tp->x.G > 1 ? 16 * tp->x.G * h->n : 0);
+  // inside the CG loop the X~ v kernel carries the direction step (DotFold):
+  // a second slice vector (s.*p_old), and per coordinate r, p, d, s.*r, s.*p_old
+  // in, p and s.*p out -- that is the kernel the timers stamp
+  if (timed_only && tiled_fold_applies(h)) *dot_bytes += 8 * 8 * h->P;
   if (timed_only)
     *tdot_bytes = tp->xt.stream_bytes() + 8 * h->n +
                   8 * (int64_t)tp->xt.G * h->p;

@@ -657,7 +657,7 @@ static int lds_budget_per_chain(int K) {
 // Picks (PR, G): row panels x groups of column blocks.  One workgroup runs per
 // CU (it owns the CU's LDS), so the launch should be a single round of <= 256
 // workgroups of equal work.  Cost model fitted on MI355X (profiles/,
-// DESIGN.md): a tile costs ~4.3 us of fixed time (slice refill from L2, two
+// LABNOTES.md 2.1): a tile costs ~4.3 us of fixed time (slice refill from L2, two
 // barriers, pipeline ramp) plus ~24 ps per stored entry streamed.
 static double shape_cost(int64_t R, int64_t nnz, int n_block, int pr, int g,
                          int K) {

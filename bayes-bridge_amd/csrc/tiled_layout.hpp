@@ -12,7 +12,7 @@ namespace bbx {
 
 // Workgroup geometry.  Default: one 1024-thread workgroup owns a CU's LDS.
 // -DBBX_TILE_THREADS=512 -DBBX_TILE_LDS_KB=80 -DBBX_TILE_W_MAX=7168 builds the
-// "two half-width workgroups per CU" variant measured in DESIGN.md 3.1.
+// "two half-width workgroups per CU" variant measured in LABNOTES.md 3.1.
 #ifndef BBX_TILE_THREADS
 #define BBX_TILE_THREADS 1024
 #endif

@@ -213,7 +213,7 @@ def cpu_baselines(prob, state, n_iters, seed):
 
 
 def iteration_bytes(mean_ncg, op_bytes, dot_bytes, tdot_bytes, n, P,
-                    dense_single_pass=False):
+                    dense_single_pass=False, vec_passes=15):
     """Algorithmic bytes of ONE whole Gibbs iteration (`roofline.iteration`):
     n_cg operator applications; for the warm start one more application (dense
     single-pass kernel) or one product with X~ plus ONE with X~^T for the
@@ -222,8 +222,10 @@ def iteration_bytes(mean_ncg, op_bytes, dot_bytes, tdot_bytes, n, P,
     bytes: the product byte counts hold the vector in and out only); 15
     P-vector passes per CG iteration (direction kernel: r, p, s, offset, d in,
     p, s.*p out; Tdot epilogue: offset, p, d, s, x, r in, x, r out -- its slab
-    read is part of tdot_bytes), ~64 bytes per row and ~30 P-vector passes
-    for the eta draws and the chain kernels.  Only bytes that are moved are
+    read is part of tdot_bytes; vec_passes = 17 where the direction step rides
+    in the X~ v kernel: a second slice vector, s.*r written and read), ~64
+    bytes per row and ~30 P-vector passes for the eta draws and the chain
+    kernels.  Only bytes that are moved are
     credited.  Pinned against the PMC counters of a profiled chain: 0.986 of
     the measured HBM traffic (profiles/r03_iteration_traffic.json,
     tests/test_bench_byte_model.py)."""
@@ -232,7 +234,7 @@ def iteration_bytes(mean_ncg, op_bytes, dot_bytes, tdot_bytes, n, P,
     else:
         total = mean_ncg * op_bytes + 2 * dot_bytes + tdot_bytes
     total += (mean_ncg + 1) * 8 * n
-    return total + mean_ncg * 15 * 8 * P + 64 * n + 30 * 8 * P
+    return total + mean_ncg * vec_passes * 8 * P + 64 * n + 30 * 8 * P
 
 
 def multi_chain_ceiling(k, ms_step, n_apply, op_ms, shared_bytes,
@@ -297,7 +299,15 @@ def multi_chain_block(design, make_chain, state, widths, steps, warmup,
         design.set_timing(False)
         assert np.all(np.isfinite(lp)) and np.all(gs > 0)
         dot_b, tdot_b = batch.launch_bytes
+        grids = None
+        if not dense and k in (2, 4):
+            try:
+                grids = {kk: vv["grid"] for kk, vv in
+                         design.tiled_info(chains=k).items()}
+            except Exception:      # noqa: BLE001 (mixed designs: other slots)
+                grids = None
         entry = {"chain_iters_per_sec": round(k * steps / dt, 2),
+                 "launch_grids": grids,
                  "vs_k1": round(k * steps / dt / single_value, 3),
                  "ms_per_batch_step": round(1e3 * dt / steps, 4),
                  "mean_n_cg_iter": [round(float(v), 1) for v in ncg.mean(1)],
@@ -336,8 +346,8 @@ def committed_traffic(design, which, cfg):
     n, P = design.shape
     rows = n if which == "dot" else P - 1
     n_wg = -(-rows // info["PR"]) * info["G"]
-    for name in ("r03_spmv_traffic.json", "r02_spmv_profile.json",
-                 "r01_spmv_profile.json"):
+    for name in ("r04_spmv_profile.json", "r03_spmv_traffic.json",
+                 "r02_spmv_profile.json", "r01_spmv_profile.json"):
         tag = name.split("_")[0]
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
@@ -355,6 +365,14 @@ def committed_traffic(design, which, cfg):
 def main():
     t_proc = time.perf_counter()
     args = parse_args()
+
+    def progress(msg):
+        # milestones of a rank on stderr (multi-rank runs and BENCH_PROGRESS=1):
+        # where the set-up time of an N-rank launch goes
+        if os.environ.get("WORLD_SIZE") or os.environ.get("BENCH_PROGRESS"):
+            sys.stderr.write("[bench rank %s +%.1fs] %s\n" % (
+                os.environ.get("RANK", "0"), time.perf_counter() - t_proc, msg))
+            sys.stderr.flush()
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         # self-launch: nothing here has imported torch or touched HIP yet
@@ -384,6 +402,7 @@ def main():
     rank, world, local_rank = chains.init_process_group_from_env(
         single_rank_group=env_world is not None)
     n_dev = torch.cuda.device_count()
+    progress("process group ready (world %d)" % world)
     backend = None
     grouped = world > 1 or env_world is not None
     if grouped:
@@ -426,6 +445,7 @@ def main():
         prob = build_problem(torch, args.config, args.seed, device)
         n, p, nnz = prob["n"], prob["p"], prob["nnz"]
         torch.cuda.synchronize()
+        progress("design generated in HBM (nnz %d)" % nnz)
         design = HipSparseDesignMatrix.from_device_csr(
             n, p, nnz, prob["indptr"].data_ptr(), prob["indices"].data_ptr(),
             None, prob["offset"].data_ptr(), add_intercept=True,
@@ -448,6 +468,8 @@ def main():
 
     torch.cuda.synchronize()
     startup_s = time.perf_counter() - t_proc   # import, generate, build layout
+    progress("layouts built, chain ready (%d builder threads)"
+             % _lib.builder_threads())
     K, W, B = args.steps, args.warmup, args.burnin
     if B is None:
         B = 10 if dense else 300
@@ -455,6 +477,7 @@ def main():
     t_b = time.perf_counter()
     ncg_b = chain.run_device(B)[2] if B > 0 else np.zeros(0)
     burnin_ms = 1e3 * (time.perf_counter() - t_b) / max(B, 1)
+    progress("burn-in done (%d iterations, %.1f ms each)" % (B, burnin_ms))
     ncg_w = chain.run_device(W)[2] if W > 0 else np.zeros(0)
     # state after warm-up (for the CPU baselines)
     state = None
@@ -486,6 +509,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = chains.max_over_ranks(elapsed)
+    progress("timed region done (%.3f s)" % elapsed)
     timing = design.get_timing()
     design.set_timing(False)
 
@@ -551,8 +575,10 @@ def main():
         else:
             op_bytes = dot_wb + tdot_wb
         op_gbs = op_bytes / op_avg / 1e6 if op_avg > 0 else 0.
-        iter_bytes = iteration_bytes(mean_ncg, op_bytes, dot_wb, tdot_wb, n, P,
-                                     bool(dense and fused_b))
+        cg_launches = design.cg_launches
+        iter_bytes = iteration_bytes(
+            mean_ncg, op_bytes, dot_wb, tdot_wb, n, P, bool(dense and fused_b),
+            vec_passes=17 if (cg_launches == 3 and not dense) else 15)
         iter_gbs = iter_bytes / ms_step / 1e6
         # measured on this box, same size as one launch's algorithmic bytes
         # and at 2 GB: what a plain streaming kernel reaches
@@ -634,6 +660,12 @@ def main():
                     % (args.config, n, p, nnz, CONFIGS[args.config][2],
                        args.seed)),
                 "storage": design.storage_format,
+                "cg_launches_per_iteration": cg_launches,
+                # workgroups per launch of the two product kernels (what the
+                # rocprofv3 traces under profiles/ are keyed by)
+                "launch_grids": {k: v["grid"] for k, v in
+                                 design.tiled_info().items()}
+                if design.storage_format == "tiled" else None,
                 "init": "coef=0 + intercept MLE, global_scale=.01, then %d "
                         "untimed burn-in iterations (in place of the "
                         "reference's L-BFGS mode search)" % B,

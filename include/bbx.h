@@ -163,6 +163,13 @@ int bbx_design_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
  * (the epilogue's slab read and its P-vector output are not counted here). */
 int bbx_design_timed_bytes(const bbx_design* h, int64_t* dot_bytes,
                            int64_t* tdot_bytes);
+/* Kernel launches per CG iteration of bbx_cg_sample / the chains on this design
+ * (the loop of scipy.sparse.linalg.cg called at cg_sampler.py:77-80): 3 where
+ * the direction step rides in the X~ v kernel and the update in the X~^T w
+ * epilogue (tiled value-free layout with one column group), 4 where only the
+ * update is merged, 5 otherwise.  Inside the CG loop the X~ v kernel that
+ * bbx_design_timed_bytes describes then also moves 8 P-vectors. */
+int bbx_design_cg_launches(const bbx_design* h, int* per_iteration);
 /* Algorithmic bytes of the single-pass dense operator kernel X^T(Omega (X v))
  * (dense designs that qualify for it; 0 otherwise): one pass over the stored
  * matrix + v + Omega + the per-workgroup slabs it writes. */

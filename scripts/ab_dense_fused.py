@@ -5,7 +5,8 @@ workgroup on; 0 = register kernel everywhere).  The variants add the same number
 the script prints a SHA-256 of the result next to the time: equal digests =
 bit-identical products.  Run once per variant (the switch is read once per
 process):
-    BBX_DENSE_FUSED_RING=0|22 python scripts/ab_dense_fused.py [n] [p] [reps]
+    BBX_DENSE_FUSED_RING=0|22 python scripts/ab_dense_fused.py [n] [p] [reps] [float32|float64]
+(float64: the pair-layout kernels dense_fused_f64_kernel / _ring_kernel)
 """
 import hashlib
 import os
@@ -21,13 +22,16 @@ from bayesbridge_amd import HipDenseDesignMatrix
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 p = int(sys.argv[2]) if len(sys.argv) > 2 else 8000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+storage = sys.argv[4] if len(sys.argv) > 4 else "float32"
 gen = torch.Generator(device="cuda")
 gen.manual_seed(111)
 X = torch.randn((n, p), generator=gen, device="cuda", dtype=torch.float32)
 offset = X.double().mean(dim=0)
 torch.cuda.synchronize()
 design = HipDenseDesignMatrix.from_device_array(
-    n, p, X.data_ptr(), offset.data_ptr(), add_intercept=True, device=0)
+    n, p, X.data_ptr(), offset.data_ptr(), add_intercept=True, device=0,
+    storage_dtype=storage)
+del X
 P = p + 1
 rng = np.random.default_rng(4)
 v = rng.standard_normal(P)
@@ -43,9 +47,10 @@ for _ in range(reps):
 assert np.array_equal(again, got)
 cnt, ms = design.get_timing()["dot"]       # the fused kernel is stamped as 'dot'
 bytes_ = design.fused_operator_bytes
-print("BBX_DENSE_FUSED_RING=%s  operator %dx%d: %.4f ms  %.0f GB/s (%.1f%% of "
+print("BBX_DENSE_FUSED_RING=%s  operator %dx%d %s: %.4f ms  %.0f GB/s (%.1f%% of "
       "8 TB/s)  launches %d  rel diff vs two products %.1e  sha256 %s" % (
-          os.environ.get("BBX_DENSE_FUSED_RING", "default"), n, p, ms / cnt,
+          os.environ.get("BBX_DENSE_FUSED_RING", "default"), n, p, storage,
+          ms / cnt,
           bytes_ / (ms / cnt) / 1e6, bytes_ / (ms / cnt) / 1e6 / 80., cnt, err,
           hashlib.sha256(got.tobytes()).hexdigest()[:16]))
 assert err < 1e-10

@@ -44,8 +44,10 @@ dot_wb, tdot_wb = design.matvec_bytes
 info = dict(iters=iters, burnin=burnin, n=n, P=P, nnz=nnz,
             n_cg_iter=[int(v) for v in ncg], dot_bytes=int(dot_wb),
             tdot_bytes=int(tdot_wb),
+            cg_launches=design.cg_launches,
             model_bytes_per_iteration=float(bench.iteration_bytes(
-                float(ncg.mean()), dot_wb + tdot_wb, dot_wb, tdot_wb, n, P)))
+                float(ncg.mean()), dot_wb + tdot_wb, dot_wb, tdot_wb, n, P,
+                vec_passes=17 if design.cg_launches == 3 else 15)))
 print("ITERATION_TRAFFIC " + json.dumps(info))
 if out:
     with open(out, "w") as fh:

@@ -131,3 +131,123 @@ def test_full_size_pair_products_equal_the_single_chain_operator(full_design):
         t, g = hip.dot(V[c]), hip.Tdot(W[c])
         assert np.abs(T[c] - t).max() <= 1e-11 * np.abs(t).max()
         assert np.abs(G[c] - g).max() <= 1e-11 * np.abs(g).max()
+
+
+def test_full_size_device_chain_iteration_equals_oracle(full_design):
+    """The benchmarked workload against the oracle ITSELF, not only through
+    properties: the device chain bench.py times (bbx_chain_run, logit, demo
+    prior and init) runs 20 iterations at 1 000 000 x 50 000 so that the CG
+    start is warm and the sd estimate past its first branch; then, for ONE
+    iteration, the state is pulled, the iteration's normals are regenerated
+    from the Philox counters (bbx_chain_eta) and `oracle.cg_sample`
+    (cg_sampler.py:61-94 restated) draws from the same inputs on a SciPy CSR
+    of the same arrays (~30 s of CPU).  Asserted as in test_hip_chain_pin.py:
+    coef <= 1e-6 max(1, |beta|) at equal n_cg (1e-5 otherwise, the reference's
+    tests/gpu_tests/test_gibbs.py:44 bound), n_cg +- 2, the summariser at
+    1e-12, the device log-likelihood / log-posterior at rtol 1e-10 -- which
+    also pins chain_pg_kernel's linear predictor and chain_lscale / gscale
+    state handling at this size (their draws stay distribution-tested)."""
+    import math
+    import scipy.sparse as sparse
+    import torch
+    import oracle
+    from oracle.gibbs import OracleGibbs, loglik
+    from oracle.summarizer import CoefSummarizer, regularized_prior_scale
+    from bayesbridge_amd import HipGibbsChain
+    hip, indptr, indices, offset = full_design
+    n, P = hip.shape
+    nnz = int(indices.numel())
+    alpha, slab = .5, 2.
+    # outcome of the bench (bench.py build_problem): logit of X beta_true
+    beta = torch.zeros(P - 1, dtype=torch.float64, device='cuda')
+    beta[:5], beta[5:10], beta[10:15] = 1.5, 1., .5
+    rows = torch.repeat_interleave(
+        torch.arange(n, device='cuda'), (indptr[1:] - indptr[:-1]).long())
+    eta_true = torch.zeros(n, dtype=torch.float64, device='cuda')
+    eta_true.index_add_(0, rows, beta[indices.long()])
+    del rows
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(1)
+    n_success = (torch.rand(n, generator=gen, device='cuda',
+                            dtype=torch.float64)
+                 < torch.sigmoid(eta_true)).double().cpu().numpy()
+    n_trial = np.ones(n)
+    chain = HipGibbsChain(hip, 'logit', n_success, bridge_exponent=alpha,
+                          slab_size=slab, seed=111)
+    unit = math.gamma(2 / alpha) / math.gamma(1 / alpha)
+    coef0 = np.zeros(P)
+    ph = n_success.mean()
+    coef0[0] = math.log(ph / (1 - ph))
+    chain.set_state(coef0, None, np.ones(P - 1) * unit, .01 / unit)
+    chain.init_obs_prec()
+    gs, lp, ncg, n_unconv = chain.run_device(20)
+    assert n_unconv == 0 and np.all(np.isfinite(lp))
+    it = chain.iteration
+    assert it == 20
+    coef_b, obs_b, ls_b, g_b = chain.get_state()
+    mean_b, square_b, n_avg = chain.get_summary()
+    assert n_avg == 20
+    # ---- the oracle on the same arrays
+    X = sparse.csr_matrix(
+        (np.ones(nnz), indices.cpu().numpy(), indptr.cpu().numpy()),
+        shape=(n, P - 1))
+    ora = OracleGibbs((n_success, n_trial), X, 'logit',
+                      bridge_exponent=alpha, regularizing_slab_size=slab)
+    assert ora.design.shape == (n, P)           # no constant column dropped
+    assert np.array_equal(ora.design.column_offset, offset.cpu().numpy())
+    summ = CoefSummarizer(P, 1, slab)
+    summ.set_state({'mean': mean_b, 'square': square_b, 'n_averaged': n_avg})
+    omega = obs_b
+    z = ora.design.Tdot(n_success - n_trial / 2)   # Omega cancels for logit
+    z_ref = ora.design.Tdot(omega * ((n_success - n_trial / 2) / omega))
+    assert np.abs(z - z_ref).max() <= 1e-9 * np.abs(z_ref).max()
+    prior_sd = np.concatenate((ora.sd_unshrunk,
+                               regularized_prior_scale(g_b, ls_b, slab)))
+    with np.errstate(divide='ignore'):
+        phi = 1 / prior_sd
+    x0 = summ.extrapolate_coef_condmean(g_b, ls_b)
+    sd = summ.estimate_post_sd()
+    assert np.any(x0 != 0.)                      # warm start: TD_RESID path
+    eta1, eta2 = chain.eta(it)
+    atol = 10e-6 * np.sqrt(P)
+    coef_o, info_o = oracle.cg_sample(ora.design, omega, phi, z_ref, x0, sd, 1,
+                                      eta1, eta2, 500, atol)
+    assert info_o['converged']
+    # ---- one device iteration from that state
+    kept, n_unconv = chain.run(1, save=('coef', 'local_scale', 'obs_prec'))
+    assert n_unconv == 0
+    coef_d, n_cg = kept['coef'][0], int(kept['n_cg_iter'][0])
+    assert abs(n_cg - info_o['n_iter']) <= 2, (n_cg, info_o['n_iter'])
+    scale = max(1., np.abs(coef_o).max())
+    tol = 1e-6 if n_cg == info_o['n_iter'] else 1e-5
+    err = np.abs(coef_d - coef_o).max()
+    assert err <= tol * scale, (err, n_cg, info_o['n_iter'])
+    # ---- summariser after the update
+    summ.update(coef_d, g_b, ls_b)
+    mean_a, square_a, n_avg_a = chain.get_summary()
+    assert n_avg_a == n_avg + 1
+    assert np.abs(mean_a - summ.mean).max() <= 1e-12 * max(
+        1., np.abs(summ.mean).max())
+    assert np.abs(square_a - summ.square).max() <= 1e-12 * max(
+        1., np.abs(summ.square).max())
+    # ---- log-likelihood / log-posterior of the new state
+    coef_a, obs_a, ls_a, g_a = chain.get_state()
+    assert np.array_equal(coef_a, coef_d)
+    lp_o = ora.logp(coef_a, g_a, obs_a)
+    lp_d = float(kept['logp'][0])
+    assert abs(lp_d - lp_o) <= 1e-10 * abs(lp_o), (lp_d, lp_o)
+    ll_d, lp_d2 = chain.logp()
+    ll_o = loglik('logit', ora.design, ora.outcome, coef_a, obs_a)
+    assert lp_d2 == lp_d and abs(ll_d - ll_o) <= 1e-10 * abs(ll_o)
+    assert np.all(obs_a > 0) and np.all(np.isfinite(obs_a))
+    assert np.all(ls_a > 0) and np.all(np.isfinite(ls_a)) and g_a > 0
+    # Polya-Gamma draws at n = 1e6 against their closed-form mean given the
+    # linear predictor the ORACLE computes (logistic_model.py:80-87): the
+    # device's psi = X~ beta enters every draw
+    from oracle.gibbs import pg_mean
+    psi_o = ora.design.dot(coef_a)
+    mean_o = pg_mean(n_trial, psi_o)
+    # Var PG(1, c) <= Var PG(1, 0) = 1/24: the sum's z-score under that bound
+    zscore = (obs_a - mean_o).sum() / math.sqrt(n / 24.)
+    assert abs(zscore) < 5., (zscore, obs_a.mean(), mean_o.mean())
+    chain.close()

@@ -210,7 +210,7 @@ def test_config4_scaled_reference_chain_through_f32_storage(golden_dir):
 @pytest.mark.parametrize("shape", [(4097, 801), (20000, 4000), (513, 16)])
 def test_matrix_core_gemv_variant_gives_the_same_product(shape):
     """The opt-in MFMA GEMV (dense_dot_mfma_kernel, BBX_DENSE_MFMA=1; the A/B
-    of DESIGN.md 3.3) against torch f64 on the stored values -- the script
+    of LABNOTES.md 3.3) against torch f64 on the stored values -- the script
     asserts <= 1e-11 relative -- for shapes with ragged row blocks / column
     chunks.  The environment switch is read once per process, hence the
     subprocess."""
@@ -227,14 +227,23 @@ def test_matrix_core_gemv_variant_gives_the_same_product(shape):
         assert "BBX_DENSE_MFMA=%s" % flag in res.stdout
 
 
-@pytest.mark.parametrize("shape", [(20001, 4001), (16500, 5000), (65537, 801)])
+@pytest.mark.parametrize("shape", [(20001, 4001, 'float32'),
+                                   (16500, 5000, 'float32'),
+                                   (65537, 801, 'float32'),
+                                   (20001, 4001, 'float64'),
+                                   (16500, 5000, 'float64'),
+                                   (33001, 8001, 'float64'),
+                                   (65537, 801, 'float64')])
 def test_lds_ring_variant_of_the_single_pass_operator_is_bit_identical(shape):
-    """dense_fused_ring_kernel (LDS-DMA ring, the default for f32 storage from
-    64 rows per workgroup on) against dense_fused_kernel (register prefetch,
+    """dense_fused_ring_kernel (LDS-DMA ring, the default from 64 rows per
+    workgroup on) against dense_fused_kernel (register prefetch,
     BBX_DENSE_FUSED_RING=0): same arithmetic in the same order, so the script's
     SHA-256 of the product must agree; it also checks the product against the
     two separate passes (<= 1e-10).  Ragged row ranges, one and two column
-    groups per thread.  The switch is read once per process: subprocesses."""
+    groups per thread; f64 storage: dense_fused_f64_ring_kernel (one row of up
+    to 8192 doubles, or two of up to 4096, per ring stage) against
+    dense_fused_f64_kernel.  The switch is read once per process:
+    subprocesses."""
     import re
     import subprocess
     import sys
@@ -244,7 +253,7 @@ def test_lds_ring_variant_of_the_single_pass_operator_is_bit_identical(shape):
         env = dict(os.environ, BBX_DENSE_FUSED_RING=flag)
         res = subprocess.run(
             [sys.executable, os.path.join(ROOT, "scripts", "ab_dense_fused.py"),
-             str(shape[0]), str(shape[1]), "3"],
+             str(shape[0]), str(shape[1]), "3", shape[2]],
             env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
         m = re.search(r"BBX_DENSE_FUSED_RING=%s .* sha256 ([0-9a-f]+)" % flag,
@@ -288,8 +297,9 @@ def test_config4_batched_products_equal_the_single_chain_operator(full_dense, K)
 
 @pytest.mark.parametrize("shape", [(9000, 3000), (12345, 5001), (4100, 8100)])
 def test_single_pass_operator_with_f64_storage(shape):
-    """dense_fused_kernel<double, KQ, 2> (one and two column groups per thread:
-    up to 8192 stored columns) against the two separate products and NumPy."""
+    """The single-pass operator with f64 storage (dense_fused_f64_ring_kernel /
+    dense_fused_f64_kernel: two or four pairs of doubles per thread, up to 8192
+    stored columns) against the two separate products and NumPy."""
     from bayesbridge_amd import HipDenseDesignMatrix
     n, p = shape
     rng = np.random.default_rng(31)

@@ -37,10 +37,11 @@ def _resource_table(src, tmp_path):
     return table
 
 
-# (VALS, WIDE, KP) of every tiled_spmv_kernel instantiation in libbbx.so
-TILED_INSTANCES = [("0", "0", "0"), ("0", "1", "0"), ("1", "0", "0"),
-                   ("1", "1", "0"), ("0", "1", "1"), ("0", "1", "2"),
-                   ("1", "1", "1")]
+# (VALS, WIDE, KP, FOLD) of every tiled_spmv_kernel instantiation in libbbx.so
+TILED_INSTANCES = [("0", "0", "0", "0"), ("0", "1", "0", "0"),
+                   ("1", "0", "0", "0"), ("1", "1", "0", "0"),
+                   ("0", "1", "1", "0"), ("0", "1", "2", "0"),
+                   ("1", "1", "1", "0"), ("0", "1", "0", "1")]
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
@@ -50,11 +51,12 @@ def test_tiled_kernels_do_not_spill(tmp_path):
         tmp_path)
     tiled = {k: v for k, v in table.items() if "tiled_spmv_kernel" in k}
     # exactly the instantiations build_tiled sets attributes on:
-    # (VALS, WIDE, KP) -- value-free and valued, 8- and 16-byte slice refills,
-    # and the K-column ones (KP = 1: two chains, KP = 2: four), which sit
-    # closest to the 128-VGPR budget; a dropped or renamed one must be noticed
-    got = sorted(re.search(r"tiled_spmv_kernelILb(\d)ELb(\d)ELi(\d)E", k).groups()
-                 for k in tiled)
+    # (VALS, WIDE, KP, FOLD) -- value-free and valued, 8- and 16-byte slice
+    # refills, the K-column ones (KP = 1: two chains, KP = 2: four) and the one
+    # that carries the CG direction step, which sit closest to the 128-VGPR
+    # budget; a dropped or renamed one must be noticed
+    got = sorted(re.search(r"tiled_spmv_kernelILb(\d)ELb(\d)ELi(\d)ELb(\d)E",
+                           k).groups() for k in tiled)
     assert got == sorted(TILED_INSTANCES), got
     for name, res in tiled.items():
         assert res["VGPRs"] <= 128, (name, res)
@@ -70,8 +72,10 @@ def test_dense_fused_kernels_fit_the_register_budget(tmp_path):
     matrix through scratch memory (measured earlier: 5.6 ms instead of 1.1)."""
     table = _resource_table(
         os.path.join(ROOT, "bayes-bridge_amd", "csrc", "dense.hip"), tmp_path)
-    fused = {k: v for k, v in table.items() if "dense_fused_kernel" in k}
-    assert len(fused) >= 3
+    fused = {k: v for k, v in table.items() if "dense_fused" in k}
+    # f32: register form and LDS-DMA ring, one and two column groups; f64: the
+    # pair-layout kernels, two and four pairs per thread
+    assert len(fused) == 8, sorted(fused)
     for name, res in fused.items():
         assert res["VGPRs"] <= 128, (name, res)
         assert res["VGPRs Spill"] == 0, (name, res)
