@@ -66,11 +66,47 @@ def init_process_group_from_env(backend=None, single_rank_group=False):
             # process -- the chain's second stream makes co-tenants on one GPU
             # time-slice badly (measured 3x slower), see chain.hip chain_step
             os.environ.setdefault("BBX_CHAIN_FORK", "0")
+            # ... and their device-heavy set-up (design generation, the
+            # library's transposition sorts) goes one rank at a time: eight
+            # concurrent 1e8-entry sorts from eight processes do not finish
+            # (setup_turn below; libbbx honours BBX_SETUP_LOCK itself)
+            os.environ.setdefault(
+                "BBX_SETUP_LOCK", "/tmp/bbx_setup_%s.lock"
+                % os.environ.get("MASTER_PORT", "0"))
         if backend == "nccl":
             # RCCL binds a communicator to the current device
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+class setup_turn():
+    """`with chains.setup_turn(): ...` around device-heavy set-up code of a
+    rank: a no-op unless BBX_SETUP_LOCK names a lock file (ranks sharing a
+    GPU, see init_process_group_from_env), then an exclusive flock on it --
+    the same lock libbbx takes around its own device set-up."""
+
+    def __enter__(self):
+        self._fh = None
+        path = os.environ.get("BBX_SETUP_LOCK")
+        if path:
+            import fcntl
+            self._fh = open(path, "a+")
+            fcntl.flock(self._fh, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        if self._fh is not None:
+            import fcntl
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+            except Exception:      # noqa: BLE001
+                pass
+            fcntl.flock(self._fh, fcntl.LOCK_UN)
+            self._fh.close()
+        return False
 
 
 def chain_seed(base_seed, rank):

@@ -130,6 +130,13 @@ class HipDesignMatrix():
         _lib.check(self._lib.bbx_design_cg_launches(self._h, byref(v)))
         return int(v.value)
 
+    def set_cg_fold(self, on):
+        """Direction step of the CG loop inside the X~ v kernel (3 launches per
+        iteration) on / off for this design; None = the process default (off
+        unless BBX_CG_FOLD=1).  Measured slower than the 4-launch form."""
+        _lib.check(self._lib.bbx_design_set_cg_fold(
+            self._h, -1 if on is None else int(bool(on))))
+
     @property
     def fused_operator_bytes(self):
         v = c_int64()

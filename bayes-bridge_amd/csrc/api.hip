@@ -5,6 +5,13 @@
 #include <cstring>
 #include <new>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
+#include <mutex>
+#include <unordered_set>
+
 #include "common.hpp"
 #include "tiled_layout.hpp"
 
@@ -18,6 +25,20 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+static std::mutex g_designs_mutex;
+static std::unordered_set<const bbx_design*> g_designs;
+void design_register(const bbx_design* h) {
+  std::lock_guard<std::mutex> lock(g_designs_mutex);
+  g_designs.insert(h);
+}
+void design_unregister(const bbx_design* h) {
+  std::lock_guard<std::mutex> lock(g_designs_mutex);
+  g_designs.erase(h);
+}
+bool design_alive(const bbx_design* h) {
+  std::lock_guard<std::mutex> lock(g_designs_mutex);
+  return g_designs.count(h) != 0;
+}
 int DevMem::alloc(size_t nbytes) {
   release();
   if (nbytes == 0) nbytes = 8;
@@ -260,7 +281,35 @@ static int validate_csr(bbx_design* h) {
 }
 
 // Common tail of the two CSR constructors: the device CSR arrays are in place.
+// Processes that SHARE one GPU (dry runs of an N-rank job on a small box; more
+// ranks than devices) must not run their device-heavy set-up side by side:
+// eight concurrent 1e8-entry radix sorts of eight processes did not finish
+// within 15 minutes on one MI355X (profiles/r04_8rank.txt), one after the
+// other they take 8 x 0.3 s.  BBX_SETUP_LOCK=<file> makes the library hold an
+// exclusive flock on that file around the device part of a design's set-up
+// (validation, values check, transposition); the host-side layout builders
+// then run concurrently.  chains.py sets it when ranks outnumber devices.
+struct SetupLock {
+  int fd = -1;
+  SetupLock() {
+    const char* path = getenv("BBX_SETUP_LOCK");
+    if (path && *path) {
+      fd = open(path, O_CREAT | O_RDWR, 0600);
+      if (fd >= 0) (void)flock(fd, LOCK_EX);
+    }
+  }
+  void release() {
+    if (fd >= 0) {
+      (void)flock(fd, LOCK_UN);
+      (void)close(fd);
+      fd = -1;
+    }
+  }
+  ~SetupLock() { release(); }
+};
+
 static int finish_csr(bbx_design* h, int format) {
+  SetupLock lock;
   BBX_TRY(validate_csr(h));
   // Values that are all exactly 1.0 are dropped (binary designs,
   // simulate_data.py:100-117): the kernels then read indices only.
@@ -282,6 +331,8 @@ static int finish_csr(bbx_design* h, int format) {
     h->binary = true;
   }
   BBX_TRY(build_transpose_csr(h));
+  BBX_HIP(hipDeviceSynchronize());
+  lock.release();   // the host-side builders of several processes run side by side
   const bool automatic = (format == BBX_FORMAT_AUTO);
   if (automatic) format = BBX_FORMAT_TILED;
   h->format = format;
@@ -309,9 +360,11 @@ static int create_csr_common(int64_t n, int64_t p, int64_t nnz,
       format != BBX_FORMAT_TILED)
     return fail(BBX_ERR_INVALID, "unknown storage format");
   bbx_design* h = new (std::nothrow) bbx_design();
+  if (h) design_register(h);
   if (!h) return fail(BBX_ERR_INVALID, "out of host memory");
   int st = open_device(device, h);
   if (st < 0) {
+    design_unregister(h);
     delete h;
     return st;
   }
@@ -505,6 +558,7 @@ int bbx_design_create_csr_dev(int64_t n, int64_t p, int64_t nnz,
 
 int bbx_design_destroy(bbx_design* h) {
   if (!h) return BBX_OK;
+  design_unregister(h);
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (int which = 0; which < KernelTimer::FAMILIES; ++which)
@@ -898,6 +952,12 @@ int bbx_design_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
 int bbx_design_timed_bytes(const bbx_design* h, int64_t* dot_bytes,
                            int64_t* tdot_bytes) {
   return matvec_bytes_impl(h, true, dot_bytes, tdot_bytes);
+}
+
+int bbx_design_set_cg_fold(bbx_design* h, int on) {
+  BBX_TRY(check_handle(h));
+  h->cg_fold = on < 0 ? -1 : (on ? 1 : 0);
+  return BBX_OK;
 }
 
 int bbx_design_cg_launches(const bbx_design* h, int* per_iteration) {

@@ -752,7 +752,7 @@ int bbx_batch_create_opts(bbx_design* design, int n_chain,
 
 int bbx_batch_destroy(bbx_batch* b) {
   if (!b) return BBX_OK;
-  if (b->h) {
+  if (b->h && design_alive(b->h)) {   // (see bbx_chain_destroy)
     (void)hipSetDevice(b->h->device);
     (void)hipStreamSynchronize(b->h->stream);
   }

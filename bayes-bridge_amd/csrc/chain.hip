@@ -815,7 +815,9 @@ int bbx_chain_create(bbx_design* design, int model, const double* outcome,
 
 int bbx_chain_destroy(bbx_chain* c) {
   if (!c) return BBX_OK;
-  if (c->h) {
+  // (the design may have been destroyed first -- a garbage collector finalises
+  // in any order -- and its stream with it: nothing of the chain is in flight)
+  if (c->h && design_alive(c->h)) {
     (void)hipSetDevice(c->h->device);
     (void)hipStreamSynchronize(c->h->stream);
   }

@@ -227,6 +227,9 @@ struct bbx_design {
 
   int64_t n_dot = 0, n_tdot = 0;
   int last_cg_iter = 0;  // iterations of the previous solve (poll scheduling)
+  // direction step folded into the X~ v kernel (DotFold): -1 = the process
+  // default (off; BBX_CG_FOLD=1 turns it on), 0 / 1 = bbx_design_set_cg_fold
+  int cg_fold = -1;
   // Set around the CG loop: device address of CGState::done.  The host
   // enqueues operator applications ahead of the stop test; once the rule has
   // fired the big kernels see the flag and exit at entry instead of streaming
@@ -355,6 +358,13 @@ int launch_sqrt_scale(bbx_design* h, const double* d_omega,
                       const double* d_minus = nullptr, bool negate = false);
 
 int design_alloc_work(bbx_design* h);
+// Registry of live design handles.  Chains and batches borrow their design; a
+// garbage-collected host language may finalise a design BEFORE the chains bound
+// to it (Python's cycle collector runs __del__ in arbitrary order): their
+// destroy calls must then not touch the design's device or stream.
+void design_register(const bbx_design* h);
+void design_unregister(const bbx_design* h);
+bool design_alive(const bbx_design* h);
 int build_transpose_csr(bbx_design* h);
 int launch_dot_csr(bbx_design* h, const double* d_v, const double* d_rowscale,
                    double* d_t);
@@ -379,9 +389,11 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
 bool dense_fused_applies(const bbx_design* h);
 int build_tiled(bbx_design* h);
 void destroy_tiled(bbx_design* h);
-// Can the CG loop on this design fold its direction step into the X~ v kernel
-// (tiled format, one column group, one partial slot per panel, not a mixed
-// design; BBX_CG_FOLD=0 turns it off)?
+// Does the CG loop on this design fold its direction step into the X~ v kernel?
+// Possible on the tiled value-free layout with one column group and one
+// partial slot per panel (not a mixed design); OFF by default -- measured
+// slower than the separate direction kernel (LABNOTES.md, round 4) -- and
+// switched on per design (bbx_design_set_cg_fold) or per process (BBX_CG_FOLD=1).
 bool tiled_fold_applies(const bbx_design* h);
 // t = rowscale .* (X~ (s.*p_k)) with the direction step of iteration fa.k inside
 // (see DotFold); partials of sum(t) and of <t, Omega t> as launch_dot.

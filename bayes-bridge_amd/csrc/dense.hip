@@ -554,7 +554,9 @@ __global__ __launch_bounds__(1024) void dense_fused_ring_kernel(
 // doubles is what a two-row f32 block is -- 64 KB -- so the ring kernel runs
 // with one row per stage (RB = 1, D = 2: 128 KB of the 160 KB LDS).
 //   dense_fused_f64_kernel       next RB = 2 rows prefetched into registers
+//                                (default: 1.85 ms = 0.87 of peak at 200k x 8k)
 //   dense_fused_f64_ring_kernel  LDS-DMA ring, RB rows per stage, D stages
+//                                (opt-in: 1.91 ms = 0.84; a barrier per row)
 // Same arithmetic in both (explicit fma, the same lane-private sums, the same
 // wave / workgroup reduction order): bit-identical results.
 typedef double fused_d2 __attribute__((ext_vector_type(2)));
@@ -871,7 +873,11 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
   } while (0)
   if (h->dense_dtype != BBX_F32) {
     const bool g2 = h->dense_ld <= 4096;
-    const bool ring64 = ring_env != 0 && (ring_env > 0 || rows_per_wg >= 64) &&
+    // measured at 200k x 8k (profiles/r04_ab_dense_fused.txt): register form
+    // 1.85 ms = 0.87 of peak, ring 1.91 ms = 0.84 -- with 16-byte lane loads the
+    // register prefetch already streams at the f32 ring's rate, and one row per
+    // stage means a barrier per row; the ring is opt-in (BBX_DENSE_FUSED_RING=22)
+    const bool ring64 = ring_env > 0 &&
                         fused_f64_ring_lds(4, 1, 2, rows_per_wg) <= 160 * 1024;
     if (ring64) {
       if (g2) BBX_F64_RING_LAUNCH(2, 2, 2); else BBX_F64_RING_LAUNCH(4, 1, 2);
@@ -990,14 +996,17 @@ static int create_dense_common(int64_t n, int64_t p, const void* X,
       (storage_dtype != BBX_F32 && storage_dtype != BBX_F64))
     return fail(BBX_ERR_INVALID, "unknown dtype");
   bbx_design* h = new (std::nothrow) bbx_design();
+  if (h) design_register(h);
   if (!h) return fail(BBX_ERR_INVALID, "out of host memory");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    design_unregister(h);
     delete h;
     return fail(BBX_ERR_NODEVICE,
                 "no HIP device visible (libbbx has no CPU fallback)");
   }
   if (device < 0 || device >= count) {
+    design_unregister(h);
     delete h;
     return fail(BBX_ERR_INVALID, "device index out of range");
   }

@@ -1734,7 +1734,8 @@ int launch_dot_tiled(bbx_design* h, const double* d_v,
 }
 
 bool tiled_fold_applies(const bbx_design* h) {
-  static const bool on = !(getenv("BBX_CG_FOLD") && atoi(getenv("BBX_CG_FOLD")) == 0);
+  static const bool env_on = getenv("BBX_CG_FOLD") && atoi(getenv("BBX_CG_FOLD")) == 1;
+  const bool on = h->cg_fold >= 0 ? h->cg_fold != 0 : env_on;
   if (!on || !h->sparse || h->format != BBX_FORMAT_TILED || h->hybrid || !h->tiled)
     return false;
   const TiledMatrix& m = static_cast<const TiledPair*>(h->tiled)->x;

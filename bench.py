@@ -72,6 +72,10 @@ def parse_args(argv=None):
                          "X; rank 0 at N = 1 only; '0' = skip).  Default: 2,4 "
                          "for the sparse configs, 4,8,16,32 for config4")
     ap.add_argument("--multi-chain-steps", type=int, default=20)
+    ap.add_argument("--cg-fold", action="store_true",
+                    help="A/B: the opt-in 3-launch CG iteration (direction "
+                         "step inside the X~ v kernel, bbx_design_set_cg_fold); "
+                         "measured slower, off by default")
     ap.add_argument("--repeat", type=int, default=5,
                     help="how many times the K-step block is run in all for "
                          "the `repeat` object (the first is the timed region "
@@ -426,7 +430,8 @@ def main():
     unit = math.gamma(2 / ALPHA) / math.gamma(1 / ALPHA)   # prior.py:163-167
     seed_k = chains.chain_seed(args.seed, rank)
     if dense:
-        prob = build_dense_problem(torch, args.config, args.seed, device)
+        with chains.setup_turn():      # (one rank at a time on a shared GPU)
+            prob = build_dense_problem(torch, args.config, args.seed, device)
         n, p, nnz = prob["n"], prob["p"], prob["nnz"]
         torch.cuda.synchronize()
         design = HipDenseDesignMatrix.from_device_array(
@@ -442,14 +447,17 @@ def main():
         chain = make_chain(seed_k)
         intercept0 = outcome.mean()
     else:
-        prob = build_problem(torch, args.config, args.seed, device)
+        with chains.setup_turn():      # (one rank at a time on a shared GPU)
+            prob = build_problem(torch, args.config, args.seed, device)
+            torch.cuda.synchronize()
         n, p, nnz = prob["n"], prob["p"], prob["nnz"]
-        torch.cuda.synchronize()
         progress("design generated in HBM (nnz %d)" % nnz)
         design = HipSparseDesignMatrix.from_device_csr(
             n, p, nnz, prob["indptr"].data_ptr(), prob["indices"].data_ptr(),
             None, prob["offset"].data_ptr(), add_intercept=True,
             device=dev_index, storage=args.storage)
+        if args.cg_fold:
+            design.set_cg_fold(True)
         # chain: prior and init of the reference demo (demo.ipynb cells 7, 9)
         n_success = prob["n_success"].cpu().numpy()
         def make_chain(seed):

@@ -12,12 +12,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "bayes-bridge_amd"))
+# (scripts/fold_phase_timers.sh points this at a private, instrumented build)
+sys.path.insert(0, os.environ.get("BBX_PACKAGE_DIR",
+                                  os.path.join(ROOT, "bayes-bridge_amd")))
 import numpy as np
 import torch
 
-import bench
 from bayesbridge_amd import HipGibbsChain, HipSparseDesignMatrix
+import bench
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 burnin = int(sys.argv[2]) if len(sys.argv) > 2 else 300

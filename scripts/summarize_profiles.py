@@ -182,9 +182,8 @@ out = dict(tag=tag, kernel_trace=trace, pmc=counters, hbm_traffic=traffic,
                "scripts/iteration_traffic.py 5 60 (the CG loop's kernels inside "
                "a chain) and scripts/bench_batch_products.py config3 2 10")
 # bench.py's `traffic` lookup (committed_traffic) reads hbm_traffic["grid=N"]
-# (the CG loop's X~ v kernel -- the one with the folded direction step -- first)
-for marker in ("tiled_spmv_kernel<false, true, 0, true>",
-               "tiled_spmv_kernel<false, true, 0, false>"):
+for marker in ("tiled_spmv_kernel<false, true, 0, false>",
+               "tiled_spmv_kernel<false, true, 0, true>"):
     for key, val in list(traffic.items()):
         if marker in key:
             out["hbm_traffic"].setdefault(key.split(" ")[-1], val)

@@ -225,3 +225,77 @@ def test_cg_sample_wide_design_with_column_groups_in_the_dot():
     n, P = X.shape[0], X.shape[1] + 1
     out = _run_both(X, cg_inputs(n, P, seed=2, lam_log_sd=.3), storage='tiled')
     _assert_close(*out)
+
+
+@pytest.mark.parametrize("shape", [(6000, 900, .05), (9000, 20000, .004),
+                                   (20000, 1000, .02)])
+def test_folded_direction_step_is_the_same_solve(shape):
+    """bbx_design_set_cg_fold(h, 1): three launches per CG iteration -- the
+    stop test, beta and s.*p = s.*r + beta s.*p_old inside the X~ v kernel
+    (csrc/common.hpp DotFold; one and several column blocks, i.e. one and
+    several slice fills per workgroup) -- against the oracle and against the
+    default four-launch loop on the same design: same iteration count, same
+    draw to rounding; bitwise reproducible; warm and cold start; a solve cut
+    off at maxiter reports what the default loop reports."""
+    from bayesbridge_amd import HipCGSampler, HipSparseDesignMatrix, simulate
+    n, p, f = shape
+    X = simulate.simulate_binary_csr_fast(n, p, f, seed=21)
+    hip = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
+                                storage='tiled')
+    ora = oracle.OracleSparseDesign(X, center_predictor=True,
+                                    add_intercept=True)
+    P = p + 1
+    atol = 10e-6 * np.sqrt(P)
+    assert hip.cg_launches == 4
+    for seed, cold in ((3, False), (4, True)):
+        inp = cg_inputs(n, P, seed=seed)
+        if cold:
+            inp['coef_cg_init'] = np.zeros(P)
+        c_o, i_o = oracle.cg_sample(
+            ora, inp['obs_prec'], inp['prior_prec_sqrt'], inp['z'],
+            inp['coef_cg_init'], inp['coef_scaled_sd'], 1, inp['randn_n'],
+            inp['randn_P'], 500, atol)
+
+        def draw(maxiter=500):
+            class _Replay:
+                def __init__(self, vecs): self.vecs = list(vecs)
+                def __call__(self, size): return self.vecs.pop(0)
+            orig = np.random.randn
+            np.random.randn = _Replay([inp['randn_n'], inp['randn_P']])
+            try:
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    return HipCGSampler(1).sample(
+                        hip, inp['obs_prec'], inp['prior_prec_sqrt'], inp['z'],
+                        coef_cg_init=inp['coef_cg_init'], precond_by='prior',
+                        coef_scaled_sd=inp['coef_scaled_sd'], maxiter=maxiter,
+                        atol=atol)
+            finally:
+                np.random.randn = orig
+        hip.set_cg_fold(False)
+        c4, i4 = draw()
+        c4_cut, i4_cut = draw(maxiter=3)
+        hip.set_cg_fold(True)
+        assert hip.cg_launches == 3
+        hip.reset_matvec_count()
+        c3, i3 = draw()
+        counts = hip.get_dot_count()
+        c3_again, i3_again = draw()
+        c3_cut, i3_cut = draw(maxiter=3)
+        hip.set_cg_fold(None)
+        _assert_close(c3, i3, c_o, i_o)
+        _assert_close(c4, i4, c_o, i_o)
+        assert abs(i3['n_iter'] - i4['n_iter']) <= 1
+        scale = max(1., np.abs(c4).max())
+        tol = 1e-7 if i3['n_iter'] == i4['n_iter'] else 1e-5
+        assert np.abs(c3 - c4).max() <= tol * scale
+        assert np.array_equal(c3, c3_again) and i3 == i3_again
+        # products that ran: n_iter applications, X~ (s x0) for a warm start,
+        # one transposed product for the initial residual
+        warm = 0 if cold else 1
+        assert counts == (i3['n_iter'] + warm, i3['n_iter'] + 1)
+        assert i3_cut['n_iter'] == i4_cut['n_iter'] == 3
+        assert not i3_cut['converged'] and not i4_cut['converged']
+        assert np.abs(c3_cut - c4_cut).max() <= 1e-9 * max(
+            1., np.abs(c4_cut).max())

@@ -31,7 +31,7 @@ pytestmark = pytest.mark.gpu
 ALPHA, SLAB = .5, 2.
 
 
-def _problem(family, kind, n=3000, p=200, seed=3):
+def _problem(family, kind, n=3000, p=200, seed=3, binary=False):
     from bayesbridge_amd import simulate
     if kind == 'dense':
         rng = np.random.default_rng(seed)
@@ -39,7 +39,8 @@ def _problem(family, kind, n=3000, p=200, seed=3):
         if family == 'linear':
             X = X.astype(np.float32).astype(np.float64)   # f32-representable
     else:
-        X = simulate.simulate_design_csr(n, p, binary_frac=.8,
+        X = simulate.simulate_design_csr(n, p,
+                                         binary_frac=1. if binary else .8,
                                          binary_pred_freq=.1, seed=seed)
     beta = np.zeros(p)
     beta[:5], beta[5:10] = 1.5, -1.
@@ -54,11 +55,18 @@ def _designs(X, kind, storage):
                                    add_intercept=True, storage_dtype=storage)
     else:
         hip = HipSparseDesignMatrix(X, center_predictor=True,
-                                    add_intercept=True, storage=storage)
+                                    add_intercept=True,
+                                    storage=storage.split('+')[0])
+        if storage.endswith('+fold'):
+            # the opt-in 3-launch CG iteration (direction step inside the
+            # X~ v kernel, csrc/common.hpp DotFold): same recurrence
+            hip.set_cg_fold(True)
+            assert hip.cg_launches == 3
     return hip
 
 
 CASES = [('logit', 'sparse', 'tiled'), ('logit', 'sparse', 'csr'),
+         ('logit', 'sparse', 'tiled+fold'), ('linear', 'sparse', 'tiled+fold'),
          ('linear', 'dense', 'float64'), ('linear', 'dense', 'float32'),
          ('linear', 'sparse', 'tiled'), ('logit', 'dense', 'float64')]
 
@@ -69,7 +77,8 @@ def test_device_chain_iteration_equals_oracle(family, kind, storage):
     oracle started from the device state before it (so n_averaged = 0..3
     exercises both branches of the sd estimate and the cold/warm CG start)."""
     from bayesbridge_amd.device_chain import HipGibbsChain
-    X, y = _problem(family, kind)
+    # (the folded direction step applies to value-free layouts: binary design)
+    X, y = _problem(family, kind, binary=storage.endswith('+fold'))
     hip = _designs(X, kind, storage)
     if family == 'logit':
         n_success, n_trial = y
