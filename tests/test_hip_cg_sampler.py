@@ -228,7 +228,8 @@ def test_cg_sample_wide_design_with_column_groups_in_the_dot():
 
 
 @pytest.mark.parametrize("shape", [(6000, 900, .05), (9000, 20000, .004),
-                                   (20000, 1000, .02)])
+                                   (20000, 1000, .02),
+                                   (200000, 30000, .002)])
 def test_folded_direction_step_is_the_same_solve(shape):
     """bbx_design_set_cg_fold(h, 1): three launches per CG iteration -- the
     stop test, beta and s.*p = s.*r + beta s.*p_old inside the X~ v kernel
@@ -246,6 +247,14 @@ def test_folded_direction_step_is_the_same_solve(shape):
                                     add_intercept=True)
     P = p + 1
     atol = 10e-6 * np.sqrt(P)
+    if hip.tiled_info()['X']['G'] != 1:
+        # several column groups per panel: the X~ v product is two kernels and
+        # the request changes nothing (5 launches: direction, dot + its
+        # finalize ... the update stays separate)
+        before = hip.cg_launches
+        hip.set_cg_fold(True)
+        assert hip.cg_launches == before == 5
+        return
     assert hip.cg_launches == 4
     for seed, cold in ((3, False), (4, True)):
         inp = cg_inputs(n, P, seed=seed)
@@ -287,8 +296,11 @@ def test_folded_direction_step_is_the_same_solve(shape):
         _assert_close(c3, i3, c_o, i_o)
         _assert_close(c4, i4, c_o, i_o)
         assert abs(i3['n_iter'] - i4['n_iter']) <= 1
+        # (each is within 1e-6 of the oracle at equal counts: s.*p is formed as
+        # s.*r + beta s.*p_old instead of s.*(r + beta p), a rounding-level
+        # change that the recurrence carries along)
         scale = max(1., np.abs(c4).max())
-        tol = 1e-7 if i3['n_iter'] == i4['n_iter'] else 1e-5
+        tol = 2e-6 if i3['n_iter'] == i4['n_iter'] else 1e-5
         assert np.abs(c3 - c4).max() <= tol * scale
         assert np.array_equal(c3, c3_again) and i3 == i3_again
         # products that ran: n_iter applications, X~ (s x0) for a warm start,
