@@ -180,7 +180,12 @@ out = dict(tag=tag, kernel_trace=trace, pmc=counters, hbm_traffic=traffic,
                "multi_chain blocks; the K = 2 kernels are its k=2 block); pmc: "
                "separate --pmc FETCH_SIZE / WRITE_SIZE passes of "
                "scripts/iteration_traffic.py 5 60 (the CG loop's kernels inside "
-               "a chain) and scripts/bench_batch_products.py config3 2 10")
+               "a chain) and scripts/bench_batch_products.py config3 2 10"
+               "; the X~ v kernel inside the CG loop also reads the row scale "
+               "Omega (8 n = 8.0 MB at n = 1e6), which `algorithmic_bytes` "
+               "(format bytes + vector in + vector out, bbx_design_timed_bytes) "
+               "does not count: 246.4 MB measured / (234.7 + 8.0) MB = 1.015; "
+               "bench.iteration_bytes credits Omega separately")
 # bench.py's `traffic` lookup (committed_traffic) reads hbm_traffic["grid=N"]
 for marker in ("tiled_spmv_kernel<false, true, 0, false>",
                "tiled_spmv_kernel<false, true, 0, true>"):

@@ -9,10 +9,14 @@ import os
 from conftest import ROOT
 
 
-def test_iteration_byte_model_is_within_3_percent_of_the_pmc_counters():
+import pytest
+
+
+@pytest.mark.parametrize("name", ["r03_iteration_traffic.json",
+                                  "r04_iteration_traffic.json"])
+def test_iteration_byte_model_is_within_3_percent_of_the_pmc_counters(name):
     import bench
-    with open(os.path.join(ROOT, "profiles",
-                           "r03_iteration_traffic.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", name)) as fh:
         prof = json.load(fh)
     assert prof["iters"] == len(prof["n_cg_iter"]) >= 5
     ncg = sum(prof["n_cg_iter"]) / len(prof["n_cg_iter"])

@@ -194,10 +194,11 @@ def test_full_size_device_chain_iteration_equals_oracle(full_design):
     ora = OracleGibbs((n_success, n_trial), X, 'logit',
                       bridge_exponent=alpha, regularizing_slab_size=slab)
     assert ora.design.shape == (n, P)           # no constant column dropped
-    # identical inputs: the device design was given torch's count / n, SciPy's
-    # X.mean() multiplies by a reciprocal -- the same numbers to an ulp
+    # identical inputs: the device design was given torch's count / n; SciPy's
+    # X.mean() sums entries pre-multiplied by 1 / n (rounding grows with the
+    # column's count) -- the oracle takes the device's numbers
     off_dev = offset.cpu().numpy()
-    assert np.allclose(ora.design.column_offset, off_dev, rtol=4e-16, atol=0.)
+    assert np.allclose(ora.design.column_offset, off_dev, rtol=1e-10, atol=0.)
     ora.design.column_offset = off_dev
     summ = CoefSummarizer(P, 1, slab)
     summ.set_state({'mean': mean_b, 'square': square_b, 'n_averaged': n_avg})
