@@ -141,9 +141,10 @@ def test_full_size_device_chain_iteration_equals_oracle(full_design):
     iteration, the state is pulled, the iteration's normals are regenerated
     from the Philox counters (bbx_chain_eta) and `oracle.cg_sample`
     (cg_sampler.py:61-94 restated) draws from the same inputs on a SciPy CSR
-    of the same arrays (~30 s of CPU).  Asserted as in test_hip_chain_pin.py:
-    coef <= 1e-6 max(1, |beta|) at equal n_cg (1e-5 otherwise, the reference's
-    tests/gpu_tests/test_gibbs.py:44 bound), n_cg +- 2, the summariser at
+    of the same arrays (~30 s of CPU, twice).  Asserted: n_cg +- 2; coef within
+    the reference's tests/gpu_tests/test_gibbs.py:44 bound (1e-5 max(1, |beta|))
+    AND within 20 x the distance the oracle itself moves under a 1e-15
+    perturbation of Omega (measured: 2.8e-6 at equal n_cg = 40); the summariser at
     1e-12, the device log-likelihood / log-posterior at rtol 1e-10 -- which
     also pins chain_pg_kernel's linear predictor and chain_lscale / gscale
     state handling at this size (their draws stay distribution-tested)."""
@@ -224,9 +225,27 @@ def test_full_size_device_chain_iteration_equals_oracle(full_design):
     coef_d, n_cg = kept['coef'][0], int(kept['n_cg_iter'][0])
     assert abs(n_cg - info_o['n_iter']) <= 2, (n_cg, info_o['n_iter'])
     scale = max(1., np.abs(coef_o).max())
-    tol = 1e-6 if n_cg == info_o['n_iter'] else 1e-5
     err = np.abs(coef_d - coef_o).max()
-    assert err <= tol * scale, (err, n_cg, info_o['n_iter'])
+    # How far do two CORRECT evaluations of this draw lie apart?  The oracle
+    # again with Omega perturbed by one part in 1e15 (a rounding-level change of
+    # its input: the sums over 1e6 rows / 1e8 entries then round differently all
+    # along the 40-iteration recurrence).  The small designs of
+    # test_hip_chain_pin.py keep device and oracle within 1e-6 max(1, |beta|);
+    # here the problem's own sensitivity sets the scale.
+    rng = np.random.default_rng(0)
+    omega_p = omega * (1. + 1e-15 * rng.standard_normal(n))
+    coef_p, info_p = oracle.cg_sample(ora.design, omega_p, phi, z_ref, x0, sd,
+                                      1, eta1, eta2, 500, atol)
+    sens = np.abs(coef_p - coef_o).max()
+    print("full-size pin: |device - oracle| = %.2e, |oracle(Omega(1 + 1e-15 e)) - "
+          "oracle| = %.2e, max|beta| = %.3f, n_cg device / oracle / perturbed "
+          "oracle = %d / %d / %d" % (err, sens, scale, n_cg, info_o['n_iter'],
+                                     info_p['n_iter']))
+    # the reference's own CPU-vs-GPU bound (tests/gpu_tests/test_gibbs.py:44),
+    # and no further from the oracle than 20 x what a 1e-15 input perturbation
+    # moves the oracle itself (or 1e-6, whichever is larger)
+    assert err <= 1e-5 * scale, (err, n_cg, info_o['n_iter'])
+    assert err <= max(1e-6 * scale, 20. * sens), (err, sens)
     # ---- summariser after the update
     summ.update(coef_d, g_b, ls_b)
     mean_a, square_a, n_avg_a = chain.get_summary()
