@@ -209,18 +209,6 @@ __device__ __forceinline__ void step_accumulate_k(const v2d* __restrict__ xs2,
 #ifndef BBX_IDS_MOD
 #define BBX_IDS_MOD " nt"
 #endif
-// EXPERIMENT (-DBBX_TILED_PF=N, default 0 = off): waves that reach a tile switch
-// early touch the id lines of their next N steps (one dword per lane and 1 KiB
-// step: all eight lines) while they wait for the slowest wave, so that HBM
-// keeps streaming during the barrier and the steps after the switch hit L2.
-// The last BBX_TILED_PF_LATE arrivers skip it (their wait for the slice values
-// would also wait for the prefetches).  Never read: timing-only effect.
-#ifndef BBX_TILED_PF
-#define BBX_TILED_PF 0
-#endif
-#ifndef BBX_TILED_PF_LATE
-#define BBX_TILED_PF_LATE 4
-#endif
 #ifndef BBX_VALS_MOD
 #define BBX_VALS_MOD ""
 #endif
@@ -294,12 +282,6 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   v2d* xs2 = reinterpret_cast<v2d*>(lds);
   v2d* acc2 = xs2 + KP * (W + 8);
   const int xplane = W + 8;
-#if BBX_TILED_PF > 0
-  __shared__ int s_arrive;       // waves arrived at tile switches so far (16 per switch)
-  int pf_switches = 0;           // switches this wave has passed
-  unsigned pf_dummy = 0;
-  if (threadIdx.x == 0) s_arrive = 0;
-#endif
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
@@ -617,37 +599,12 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
                   fp[u].y = (j1 < cols_here && !(ablate & 2)) ? x[col0 + j1] : 0.;
                 }
               }
-#if BBX_TILED_PF > 0
-              if (pf_switches > 0) {   // (the first switch orders s_arrive's reset)
-                int rank = 0;
-                if (lane == 0) rank = atomicAdd(&s_arrive, 1) - TILE_WAVES * (pf_switches - 1);
-                rank = __builtin_amdgcn_readfirstlane(rank);
-                if (rank < TILE_WAVES - BBX_TILED_PF_LATE) {
-#pragma unroll
-                  for (int i = 0; i < BBX_TILED_PF; ++i) {
-                    if (pos + i < WAVE) {
-                      const unsigned pq = (unsigned)__builtin_amdgcn_readlane((int)dcur.x, pos + i);
-                      const unsigned pinf = (unsigned)__builtin_amdgcn_readlane((int)dcur.z, pos + i);
-                      if ((pinf & 15u) > 0 && !(pinf & BD_END))
-                        asm volatile("global_load_dword %0, %1, %2"
-                                     : "=v"(pf_dummy)
-                                     : "v"((pq * WAVE + lane) * 16u), "s"(ids)
-                                     : "memory");
-                    }
-                  }
-                }
-              }
-              ++pf_switches;
-#endif
               if (!(ablate & 4))
                 __syncthreads();  // every wave is done with the previous slice
               if (dbg) t_skew += (unsigned)__builtin_amdgcn_s_memtime() - t_sw0;
               // one explicit wait for the slice values on every path, so that no
               // compiler-visible load is left "maybe pending" inside the loop
               __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
-#if BBX_TILED_PF > 0
-              asm volatile("" : "+v"(pf_dummy));  // allocated until the prefetches landed
-#endif
               if (wide) {
                 if constexpr (FOLD) {
                   if (two) {   // s.*p_k = s.*r_k + beta s.*p_{k-1}
@@ -1241,8 +1198,7 @@ int build_tiled(bbx_design* h) {
 #define BBX_TILED_ATTR(VV, WW, KK, FF)                                         \
   BBX_HIP(hipFuncSetAttribute(                                                 \
       reinterpret_cast<const void*>(&tiled_spmv_kernel<VV, WW, KK, FF>),       \
-      hipFuncAttributeMaxDynamicSharedMemorySize,                              \
-      160 * 1024 - (BBX_TILED_PF > 0 ? 64 : 0) /* static LDS of the experiment */))
+      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
   BBX_TILED_ATTR(false, false, 0, false);
   BBX_TILED_ATTR(false, true, 0, false);
   BBX_TILED_ATTR(true, false, 0, false);
