@@ -683,6 +683,12 @@ static int gram_matvec_device(bbx_design* h, const double* d_obs_prec,
   }
   BBX_TRY(launch_prep_v(h, d_v, nullptr, nullptr, part_slot(h, PS_C)));
   double* t = h->w_n[0].as<double>();
+  // one operator application: t goes into the transposed product unchanged
+  struct OperatorScope {
+    bbx_design* h;
+    ~OperatorScope() { h->in_operator = false; }
+  } op_scope{h};
+  h->in_operator = true;
   BBX_TRY(launch_dot(h, d_v, d_obs_prec, t, part_slot(h, PS_SUMW)));
   return launch_tdot(h, t, part_slot(h, PS_SUMW), ep, d_out);
 }

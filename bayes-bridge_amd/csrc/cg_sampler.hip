@@ -104,6 +104,12 @@ static int apply_operator(bbx_design* h, const double* d_omega,
     *upd->merged = true;
   };
   if (upd) *upd->merged = false;
+  // (dot and Tdot below belong to ONE application: t feeds the Tdot unchanged)
+  struct OperatorScope {
+    bbx_design* h;
+    ~OperatorScope() { h->in_operator = false; }
+  } op_scope{h};
+  h->in_operator = true;
   BBX_TRY(timer_begin(h, 2));  // family 2: the whole application (sampled)
   if (!h->sparse && dense_fused_applies(h)) {
     // f32 dense designs: both products in one pass over the matrix

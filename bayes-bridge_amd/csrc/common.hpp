@@ -227,6 +227,11 @@ struct bbx_design {
 
   int64_t n_dot = 0, n_tdot = 0;
   int last_cg_iter = 0;  // iterations of the previous solve (poll scheduling)
+  // Set around the dot + Tdot of ONE operator application (apply_operator,
+  // gram_matvec): the Tdot's input is the dot's scaled output, so a mixed
+  // design's dense block can ride in the dot kernel's epilogue for both
+  // products (spmv_tiled.hip DenseEpi) instead of three kernels of its own.
+  bool in_operator = false;
   // direction step folded into the X~ v kernel (DotFold): -1 = the process
   // default (off; BBX_CG_FOLD=1 turns it on), 0 / 1 = bbx_design_set_cg_fold
   int cg_fold = -1;
@@ -336,6 +341,21 @@ struct DotFold {
   double* pvec = nullptr;           // p, updated in place
   const double* d = nullptr;
   double* pdp_part = nullptr;       // NPART partials of <p, d p>
+};
+
+// The dense block D (kd continuous columns, column-major [kd][n]) of a mixed
+// design inside the value-free X~ v kernel's epilogue: t_r += sum_j D[j][r] v_j,
+// and -- the output w = rowscale .* t being the input of the operator's
+// transposed product -- part[workgroup][j] = sum over its rows of D[j][r] w_r.
+// D is read once per operator application instead of twice, and the addend /
+// dense-Tdot kernels (three launches) disappear from the CG iteration.
+constexpr int DENSE_EPI_MAX = 16;   // dense columns the epilogue handles
+struct DenseEpi {
+  const double* D = nullptr;
+  const int32_t* cols = nullptr;   // column of X (without intercept) of each D row
+  int kd = 0;
+  int64_t n = 0;
+  double* part = nullptr;          // [workgroups][kd]
 };
 
 // out[P] = epilogue([sum w ; X_main^T w - sum(w) offset]).  `sumw_part` holds

@@ -125,6 +125,11 @@ struct HybridParts {
   DevMem D;              // double[kd][n], column-major
   DevMem addend;         // double[n]
   DevMem d_part;         // double[HYB_TDOT_CHUNKS][kd]: partial sums of D^T w
+  // operator applications (bbx_design::in_operator): D^T (Omega t) partials
+  // left by the X~ v kernel's epilogue, one row of kd per workgroup
+  DevMem dw_part;        // double[NPART][kd]
+  const double* dw_for = nullptr;  // the t they belong to (consumed by the next Tdot)
+  int dw_chunks = 0;
   DevMem slab;           // double[(G_B + G_S + 1)][p]
   int n_slab = 0;
   // batches (K = 2, 4 right-hand sides) of a design WITHOUT a valued rest keep
@@ -253,7 +258,10 @@ constexpr int FILL_K_PAIRS =
 // launch (common.hpp DotFold): x is s.*r, the slices are filled with
 // s.*r + beta s.*p_old, the epilogue constant comes from fa / CGState, and the
 // workgroup writes p, s.*p and <p, d p> for its share of the coordinates.
-template <bool VALS, bool WIDE, int KP, bool FOLD = false>
+//
+// DENSEP (KP == 0, direct epilogue): the dense block of a mixed design rides in
+// the epilogue (common.hpp DenseEpi).
+template <bool VALS, bool WIDE, int KP, bool FOLD = false, bool DENSEP = false>
 __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_kernel(
     int64_t R, int64_t C, int W, int PR, int G, int blocks_per_group,
     const int32_t* __restrict__ wave_desc, int desc_stride,
@@ -269,8 +277,9 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     double* __restrict__ out_sum_part, int twt_off, int ablate,
     unsigned long long* dbg, const int* __restrict__ skip_flag,
     ChainPtrs rowscale_k, ChainOut out_k, int out_stride, int part_stride,
-    const double* __restrict__ addend, DotFold fa) {
+    const double* __restrict__ addend, DotFold fa, DenseEpi de) {
   static_assert(!FOLD || (KP == 0 && WIDE), "the folded direction step is single-chain");
+  static_assert(!DENSEP || (KP == 0 && !FOLD), "dense epilogue: single chain, plain loop");
   constexpr int K = KP > 0 ? 2 * KP : 1;
   // (scalar load, issued first; checked below once the descriptor loads that
   // every launch needs anyway have been issued, so it adds no round trip)
@@ -868,6 +877,57 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
         c = xs[0];
       }
       double tsum = 0., t2sum = 0.;
+      if constexpr (DENSEP) {
+        // mixed design: t_r = c + (B v)_r + sum_j D[j][r] v_j, w_r = Omega_r t_r,
+        // then this workgroup's part of D^T w (fixed order: rows of a thread,
+        // lanes, waves) -- D comes from HBM once and from L2 the second time
+        __shared__ double s_dw[DENSE_EPI_MAX * TILE_WAVES];
+        double tt[EPI_UNROLL], ww[EPI_UNROLL];
+  #pragma unroll
+        for (int u = 0; u < EPI_UNROLL; ++u) {
+          const int r = tid + u * TILE_THREADS;
+          tt[u] = r < rows_here ? c + acc[r] : 0.;
+        }
+        for (int j = 0; j < de.kd; ++j) {
+          const double vj = x[de.cols[j]];
+          const double* __restrict__ Dj = de.D + (int64_t)j * de.n + row0;
+  #pragma unroll
+          for (int u = 0; u < EPI_UNROLL; ++u) {
+            const int r = tid + u * TILE_THREADS;
+            if (r < rows_here) tt[u] = fma(Dj[r], vj, tt[u]);
+          }
+        }
+  #pragma unroll
+        for (int u = 0; u < EPI_UNROLL; ++u) {
+          const int r = tid + u * TILE_THREADS;
+          ww[u] = 0.;
+          if (r < rows_here) {
+            double v = tt[u];
+            if (rowscale) v *= rs_pre[u];
+            out[row0 + r] = v;
+            tsum += v;
+            t2sum += v * tt[u];
+            ww[u] = v;
+          }
+        }
+        for (int j = 0; j < de.kd; ++j) {
+          const double* __restrict__ Dj = de.D + (int64_t)j * de.n + row0;
+          double a = 0.;
+  #pragma unroll
+          for (int u = 0; u < EPI_UNROLL; ++u) {
+            const int r = tid + u * TILE_THREADS;
+            if (r < rows_here) a = fma(Dj[r], ww[u], a);
+          }
+          a = wave_allsum(a);
+          if (lane == 0) s_dw[j * TILE_WAVES + wave] = a;
+        }
+        __syncthreads();
+        if (tid < de.kd) {
+          double tot = 0.;
+          for (int wv = 0; wv < TILE_WAVES; ++wv) tot += s_dw[tid * TILE_WAVES + wv];
+          de.part[(int64_t)bid * de.kd + tid] = tot;
+        }
+      } else {
   #pragma unroll
       for (int u = 0; u < EPI_UNROLL; ++u) {
         const int r = tid + u * TILE_THREADS;
@@ -880,6 +940,7 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
           tsum += v;
           t2sum += v * t;
         }
+      }
       }
       if (out_sum_part) {
         // partial sum of this panel's outputs (feeds the intercept / centring
@@ -1199,6 +1260,12 @@ int build_tiled(bbx_design* h) {
   BBX_HIP(hipFuncSetAttribute(                                                 \
       reinterpret_cast<const void*>(&tiled_spmv_kernel<VV, WW, KK, FF>),       \
       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+  // (the dense-epilogue instantiation holds 2 KB of static LDS: the layouts
+  // leave exactly that free, lds_budget_per_chain)
+  BBX_HIP(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(
+          &tiled_spmv_kernel<false, true, 0, false, true>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
   BBX_TILED_ATTR(false, false, 0, false);
   BBX_TILED_ATTR(false, true, 0, false);
   BBX_TILED_ATTR(true, false, 0, false);
@@ -1337,7 +1404,8 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                         hipEvent_t ev_end = nullptr, int twt_off = 0,
                         const TiledBatchArgs* ba = nullptr,
                         const double* addend = nullptr,
-                        const DotFold* fold = nullptr) {
+                        const DotFold* fold = nullptr,
+                        const DenseEpi* dense = nullptr) {
   const unsigned grid = (unsigned)(m.n_panel * m.G);
   const size_t lb = lds_bytes(m);
   // Instrumented builds only (-DBBX_TILED_INSTRUMENT=1; the product library
@@ -1365,10 +1433,13 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
   static const TiledBatchArgs no_batch{};
   const TiledBatchArgs& bb = ba ? *ba : no_batch;
   const DotFold fa = fold ? *fold : DotFold{};
+  const DenseEpi de = dense ? *dense : DenseEpi{};
 #define BBX_TILED_LAUNCH_W(VV, WW, KK, VALPTR)                                 \
   BBX_TILED_LAUNCH_F(VV, WW, KK, false, VALPTR)
 #define BBX_TILED_LAUNCH_F(VV, WW, KK, FF, VALPTR)                             \
-  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, WW, KK, FF>), dim3(grid),       \
+  BBX_TILED_LAUNCH_D(VV, WW, KK, FF, false, VALPTR)
+#define BBX_TILED_LAUNCH_D(VV, WW, KK, FF, DD, VALPTR)                         \
+  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, WW, KK, FF, DD>), dim3(grid),   \
                      dim3(TILE_THREADS), (unsigned)lb, h->stream, ev_begin,    \
                      ev_end, 0u, m.R, m.C, m.W, m.PR,                          \
                      m.G, (m.n_block + m.G - 1) / m.G,                         \
@@ -1379,7 +1450,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                      m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),       \
                      out_sum_part, twt_off, ablate, dbg, h->skip_flag,         \
                      bb.rowscale, bb.out, bb.out_stride, bb.part_stride,       \
-                     addend, fa)
+                     addend, fa, de)
 #define BBX_TILED_LAUNCH(VV, VALPTR)                                           \
   do {                                                                         \
     if (m.K == 2) BBX_TILED_LAUNCH_W(VV, true, 1, VALPTR);                \
@@ -1397,7 +1468,14 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
   // 1024-thread workgroup without scratch: valued designs batch two chains)
   if (m.K == 4 && m.has_vals)
     return fail(BBX_ERR_INVALID, "valued designs batch at most 2 chains");
-  if (fold) {
+  if (dense) {
+    // mixed design inside an operator application: the dense block in the
+    // value-free kernel's epilogue (single chain, direct epilogue)
+    if (m.K != 1 || !wide || m.G != 1 || !out || m.has_vals || addend || fold ||
+        dense->kd < 1 || dense->kd > DENSE_EPI_MAX)
+      return fail(BBX_ERR_STATE, "dense epilogue: unsupported launch");
+    BBX_TILED_LAUNCH_D(false, true, 0, false, true, nullptr);
+  } else if (fold) {
     // folded direction step: single chain, 16-byte aligned vectors, the direct
     // epilogue with its partial sums
     if (m.K != 1 || !wide || m.G != 1 || !out || !out_sum_part || addend)
@@ -1416,6 +1494,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
 #undef BBX_TILED_LAUNCH
 #undef BBX_TILED_LAUNCH_W
 #undef BBX_TILED_LAUNCH_F
+#undef BBX_TILED_LAUNCH_D
   BBX_HIP(hipGetLastError());
   if (dbg) {
     BBX_HIP(hipStreamSynchronize(h->stream));
@@ -1606,6 +1685,40 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
   HybridParts* hp = static_cast<HybridParts*>(h->hybrid);
   const double* x = d_v + h->intercept;
   const double* x0 = h->intercept ? d_v : nullptr;
+  hp->dw_for = nullptr;
+  // Inside an operator application the dense block rides in the value-free
+  // kernel's epilogue (DenseEpi): no addend kernel, and the partials of
+  // D^T (Omega t) for the transposed product that follows.
+  {
+    const TiledMatrix& mb = hp->ones.x;
+    const bool wide = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+    if (h->in_operator && d_rowscale && hp->rest_nnz == 0 && hp->kd > 0 &&
+        hp->kd <= DENSE_EPI_MAX && mb.G == 1 && mb.n_panel <= NPART && wide &&
+        d_sum_part) {
+      if (!hp->dw_part.ptr)
+        BBX_TRY(hp->dw_part.alloc(sizeof(double) * NPART * (size_t)hp->kd));
+      DenseEpi de;
+      de.D = hp->D.as<double>();
+      de.cols = hp->dense_cols.as<int32_t>();
+      de.kd = hp->kd;
+      de.n = h->n;
+      de.part = hp->dw_part.as<double>();
+      int twt_off = 0;
+      if (sum_done) *sum_done = 1;
+      if (d_twt_part && twt_done && d_twt_part != d_sum_part) {
+        twt_off = (int)(d_twt_part - d_sum_part);
+        *twt_done = 1;
+      }
+      hipEvent_t ea, eb;
+      BBX_TRY(timer_arm(h, 0, &ea, &eb));
+      BBX_TRY(launch_tiled(h, mb, x, part_slot(h, PS_C), x0, d_rowscale, d_t,
+                           nullptr, d_sum_part, ea, eb, twt_off, nullptr,
+                           nullptr, nullptr, &de));
+      hp->dw_for = d_t;
+      hp->dw_chunks = mb.n_panel * mb.G;
+      return BBX_OK;
+    }
+  }
   BBX_TRY(timer_begin(h, 0));
   const double* rest_slab = nullptr;
   int G_rest = 0;
@@ -1670,7 +1783,16 @@ static int launch_tdot_hybrid(bbx_design* h, const double* d_w,
                          slab + (size_t)at * (size_t)h->p, nullptr));
     at += ms.G;
   }
-  if (hp->kd > 0) {
+  if (hp->kd > 0 && hp->dw_for == d_w) {
+    // the preceding X~ v kernel of this operator application left the partials
+    // of D^T w, one row per workgroup: only the fixed-order sum is left to do
+    hipLaunchKernelGGL(hyb_dense_scatter_kernel, dim3((unsigned)hp->kd),
+                       dim3(WAVE), 0, h->stream, hp->kd, hp->dw_chunks,
+                       hp->dense_cols.as<int32_t>(), hp->dw_part.as<double>(),
+                       slab + (size_t)at * (size_t)h->p, h->skip_flag);
+    BBX_HIP(hipGetLastError());
+    at += 1;
+  } else if (hp->kd > 0) {
     const int64_t n_task = (int64_t)hp->kd * HYB_TDOT_CHUNKS;
     hipLaunchKernelGGL(hyb_dense_tdot_kernel,
                        dim3((unsigned)((n_task + 3) / 4)), dim3(256), 0,
@@ -1684,6 +1806,7 @@ static int launch_tdot_hybrid(bbx_design* h, const double* d_w,
     BBX_HIP(hipGetLastError());
     at += 1;
   }
+  hp->dw_for = nullptr;
   BBX_TRY(timer_end(h, 1));
   // the epilogue kernel adds the slabs in this order: B, S, D
   return launch_tdot_finalize(h, slab, at, d_sumw_part, ep, d_out);

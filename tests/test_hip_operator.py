@@ -347,6 +347,73 @@ def test_mixed_design_of_the_reference_helper_is_stored_split():
     assert np.abs(c_h - c_o).max() <= tol * max(1., np.abs(c_o).max())
 
 
+@pytest.mark.parametrize("n_dense", [1, 5, 16, 20])
+def test_dense_columns_ride_in_the_dot_epilogue_of_an_operator_application(n_dense):
+    """Binary covariates plus a few continuous ones (the OHDSI shape).  Inside
+    ONE operator application X~^T (Omega (X~ v)) -- bbx_design_gram_matvec and
+    the CG loop -- up to 16 dense columns are handled by the value-free X~ v
+    kernel's epilogue (csrc/common.hpp DenseEpi: t += D v_D, and the partials of
+    D^T (Omega t) for the transposed product), instead of three kernels of their
+    own; more than 16 take the separate kernels.  Against the two separate
+    products (which never use the fused epilogue) and NumPy; a CG draw against
+    the oracle; bitwise repeatable."""
+    import scipy.sparse as sparse
+    import oracle
+    from bayesbridge_amd import HipCGSampler, HipSparseDesignMatrix, simulate
+    from helpers import cg_inputs
+    n, p = 30000, 2500
+    rng = np.random.default_rng(40 + n_dense)
+    Xb = simulate.simulate_binary_csr_fast(n, p, .01, seed=9)
+    dense_block = rng.standard_normal((n, n_dense))
+    # the last n_dense binary columns are replaced by continuous covariates
+    X = sparse.hstack([Xb[:, :p - n_dense],
+                       sparse.csr_matrix(dense_block)]).tocsr()
+    X.sort_indices()
+    p = X.shape[1]
+    hip = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
+                                storage='tiled')
+    info = hip.hybrid_info
+    assert info is not None and info['dense_cols'] == n_dense
+    assert info['rest_nnz'] == 0
+    P = p + 1
+    v, omega = rng.standard_normal(P), rng.gamma(2., .2, n)
+    fused = hip.gram_matvec(omega, v)
+    again = hip.gram_matvec(omega, v)
+    assert np.array_equal(fused, again)
+    two = hip.Tdot(omega * hip.dot(v))          # separate kernels
+    assert np.abs(fused - two).max() <= 1e-11 * np.abs(two).max()
+    off = np.asarray(X.mean(axis=0)).ravel()
+    t = v[0] + X @ v[1:] - off @ v[1:]
+    wv = omega * t
+    ref = np.concatenate(([wv.sum()], X.T @ wv - wv.sum() * off))
+    assert np.abs(fused - ref).max() <= 1e-10 * np.abs(ref).max()
+    # a CG draw through the same operator
+    inp = cg_inputs(n, P, seed=6, lam_log_sd=.3)
+    ora = oracle.OracleSparseDesign(X, center_predictor=True, add_intercept=True)
+    atol = 10e-6 * np.sqrt(P)
+    c_o, i_o = oracle.cg_sample(
+        ora, inp['obs_prec'], inp['prior_prec_sqrt'], inp['z'],
+        inp['coef_cg_init'], inp['coef_scaled_sd'], inp['n_unshrunk'],
+        inp['randn_n'], inp['randn_P'], 500, atol)
+
+    class _Replay:
+        def __init__(self, vecs): self.vecs = list(vecs)
+        def __call__(self, size): return self.vecs.pop(0)
+    orig = np.random.randn
+    np.random.randn = _Replay([inp['randn_n'], inp['randn_P']])
+    try:
+        c_h, i_h = HipCGSampler(inp['n_unshrunk']).sample(
+            hip, inp['obs_prec'], inp['prior_prec_sqrt'], inp['z'],
+            coef_cg_init=inp['coef_cg_init'], precond_by='prior',
+            coef_scaled_sd=inp['coef_scaled_sd'], maxiter=500, atol=atol)
+    finally:
+        np.random.randn = orig
+    assert i_h['converged']
+    assert abs(i_h['n_iter'] - i_o['n_iter']) <= max(2, i_o['n_iter'] // 25)
+    tol = 1e-6 if i_h['n_iter'] == i_o['n_iter'] else 1e-5
+    assert np.abs(c_h - c_o).max() <= tol * max(1., np.abs(c_o).max())
+
+
 @pytest.mark.parametrize("shape", [(9000, 20000, .004), (700, 40000, .003),
                                    (20000, 1000, .02)])
 def test_kernel_equals_cpu_emulator_bitwise(shape):
