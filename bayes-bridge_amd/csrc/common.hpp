@@ -349,7 +349,11 @@ struct DotFold {
 // transposed product -- part[workgroup][j] = sum over its rows of D[j][r] w_r.
 // D is read once per operator application instead of twice, and the addend /
 // dense-Tdot kernels (three launches) disappear from the CG iteration.
-constexpr int DENSE_EPI_MAX = 16;   // dense columns the epilogue handles
+// Dense columns the epilogue handles.  Its D stream runs at the kernel's tail,
+// after the id stream: measured against the separate kernels at 1M x 50k
+// (profiles/r04_mixed.txt) one chain runs +11 % / +9 % / +3 % faster with 2 / 5 /
+// 8 continuous columns and -1 % / -2.5 % slower with 12 / 16.
+constexpr int DENSE_EPI_MAX = 8;
 struct DenseEpi {
   const double* D = nullptr;
   const int32_t* cols = nullptr;   // column of X (without intercept) of each D row

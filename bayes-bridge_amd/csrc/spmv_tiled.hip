@@ -1692,8 +1692,11 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
   {
     const TiledMatrix& mb = hp->ones.x;
     const bool wide = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+    // (A/B: BBX_DENSE_EPI_MAX=0 keeps the separate kernels)
+    static const int epi_max = getenv("BBX_DENSE_EPI_MAX")
+        ? std::min(atoi(getenv("BBX_DENSE_EPI_MAX")), DENSE_EPI_MAX) : DENSE_EPI_MAX;
     if (h->in_operator && d_rowscale && hp->rest_nnz == 0 && hp->kd > 0 &&
-        hp->kd <= DENSE_EPI_MAX && mb.G == 1 && mb.n_panel <= NPART && wide &&
+        hp->kd <= epi_max && mb.G == 1 && mb.n_panel <= NPART && wide &&
         d_sum_part) {
       if (!hp->dw_part.ptr)
         BBX_TRY(hp->dw_part.alloc(sizeof(double) * NPART * (size_t)hp->kd));
