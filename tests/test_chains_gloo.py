@@ -172,3 +172,38 @@ def test_single_process_helpers_need_no_group():
     assert got.shape == (1, 2, 3) and torch.equal(got[0], x)
     assert chains.max_over_ranks(3.5) == 3.5
     assert chains.chain_seed(111, 7) == 118      # BASELINE config 5 seeds
+
+
+def test_setup_turn_serialises_processes_that_share_a_lock_file(tmp_path):
+    """chains.setup_turn(): ranks that share a GPU run their device-heavy set-up
+    one at a time (BBX_SETUP_LOCK; libbbx takes the same flock around its own
+    device set-up).  Three processes, each holding the turn for 0.4 s: their
+    intervals must not overlap.  Without the variable it is a no-op."""
+    import time
+    code = textwrap.dedent("""
+        import os, sys, time
+        sys.path.insert(0, os.path.join(%r, "bayes-bridge_amd"))
+        from bayesbridge_amd import chains
+        with chains.setup_turn():
+            t0 = time.time()
+            time.sleep(.4)
+            t1 = time.time()
+        print("TURN %%.3f %%.3f" %% (t0, t1))
+    """ % ROOT)
+    env = dict(os.environ, BBX_SETUP_LOCK=str(tmp_path / "setup.lock"))
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=env,
+                              stdout=subprocess.PIPE, text=True)
+             for _ in range(3)]
+    spans = []
+    for pr in procs:
+        out = pr.communicate(timeout=120)[0]
+        assert pr.returncode == 0
+        spans.append(tuple(float(v) for v in out.split()[1:3]))
+    spans.sort()
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert b0 >= a1 - 1e-3, spans
+    env.pop("BBX_SETUP_LOCK")
+    t = time.time()
+    out = subprocess.run([sys.executable, "-c", code], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "TURN" in out.stdout

@@ -129,3 +129,41 @@ def test_builder_threads_follow_quota_and_local_ranks():
     assert ask(max_threads=3) == min(3, cores)
     assert ask(BBX_BUILD_THREADS=5, LOCAL_WORLD_SIZE=8) == 5
     assert ask(BBX_BUILD_THREADS=500) == 64
+
+
+def test_cost_model_orders_the_batch_widths_like_the_measurements():
+    """bbx_batch_predict (csrc/spmv_tiled.hip tiled_batch_predict) prices a batch
+    of K chains as K x the single-chain layouts' model cost over the K-layouts'
+    (csrc/tiled_layout.cpp shape_cost); bbx_batch_create refuses a width priced
+    below 1.  Without a GPU: the same arithmetic on row-pointer arrays with the
+    headline design's statistics (1M x 50k, column frequencies
+    0.5 Beta(.5, .5 (.5 / f - 1)), ~100 entries per row).  Measured on the
+    MI355X (profiles/r04_bench.json): pairs 1.38x, fours 0.98x at this size;
+    fours 1.54x at 100k x 10k."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, 'bayes-bridge_amd',
+                                   'libbbx_layout.so'))
+    lib.bbx_layout_model_cost.restype = ctypes.c_double
+    lib.bbx_layout_model_cost.argtypes = [ctypes.c_int64] * 3 + [
+        ctypes.c_void_p, ctypes.c_int]
+
+    def predicted(n, p, f, K, seed=0):
+        rng = np.random.default_rng(seed)
+        freq = .5 * rng.beta(.5, .5 * (.5 / f - 1), p)
+        col_n = np.ceil(n * freq).astype(np.int64)
+        nnz = int(col_n.sum())
+        t_ptr = np.concatenate([[0], np.cumsum(col_n)]).astype(np.int32)
+        row_n = rng.poisson(nnz / n, n)
+        row_n[-1] += nnz - row_n.sum()
+        x_ptr = np.concatenate([[0], np.cumsum(row_n)]).astype(np.int32)
+        cost = {}
+        for k in (1, K):
+            cost[k] = lib.bbx_layout_model_cost(n, p, nnz, x_ptr.ctypes.data, k) \
+                + lib.bbx_layout_model_cost(p, n, nnz, t_ptr.ctypes.data, k)
+            assert cost[k] > 0
+        return K * cost[1] / cost[K]
+    big2, big4 = predicted(1000000, 50000, .002, 2), predicted(1000000, 50000, .002, 4)
+    assert big2 > 1. > big4, (big2, big4)          # pairs accepted, fours refused
+    small2, small4 = predicted(100000, 10000, .01, 2), predicted(100000, 10000, .01, 4)
+    assert small4 > small2 > 1., (small2, small4)  # both pay on the small design
+    assert lib.bbx_layout_model_cost(10, 10, 10, None, 3) < 0   # K = 3: no layout
