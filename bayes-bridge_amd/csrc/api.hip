@@ -841,6 +841,17 @@ int bbx_design_set_timing(bbx_design* h, int enabled) {
   if (!enabled && h->timer.enabled) BBX_TRY(timer_collect(h));
   h->timer.enabled = enabled != 0;
   h->timer.period = enabled > 1 ? enabled : 1;
+  // event pairs are created HERE, not inside the region that is being timed
+  // (a sampled launch takes its pair from the pool)
+  if (enabled) {
+    while (h->timer.pool.size() < 512) {
+      KernelTimer::Pair pr;
+      pr.tag = -1;
+      BBX_HIP(hipEventCreate(&pr.a));
+      BBX_HIP(hipEventCreate(&pr.b));
+      h->timer.pool.push_back(pr);
+    }
+  }
   for (auto& v : h->timer.seen) v = 0;
   // whole-operator brackets sample other launches than the kernel stamps
   h->timer.seen[2] = h->timer.period / 2;
