@@ -113,21 +113,32 @@ def test_full_size_cg_draw_solves_the_perturbed_system(full_design):
     assert np.array_equal(coef, coef2)
 
 
-def test_full_size_pair_products_equal_the_single_chain_operator(full_design):
-    """K = 2 tiled products (the layout sized for two right-hand sides, one pass
-    over the id stream) at full size against the single-chain kernels."""
-    from bayesbridge_amd import HipChainBatch, HipGibbsChain
+@pytest.mark.parametrize("K", [2, 4])
+def test_full_size_pair_products_equal_the_single_chain_operator(full_design, K):
+    """K = 2 and K = 4 tiled products (the layouts sized for two / four
+    right-hand sides, one pass over the id stream; four chains take two rounds
+    of workgroups at this size and are refused by default -- the cost model
+    prices them below single chains -- hence allow_slow) at full size against
+    the single-chain kernels."""
+    from bayesbridge_amd import BbxError, HipChainBatch, HipGibbsChain
     hip, *_ = full_design
     n, P = hip.shape
     rng = np.random.default_rng(23)
     y = (rng.random(n) < .3).astype(np.float64)
     chains = [HipGibbsChain(hip, 'logit', y, n_trial=np.ones(n),
                             sd_unshrunk=[2.], bridge_exponent=.5, slab_size=2.,
-                            seed=s) for s in (1, 2)]
+                            seed=s) for s in range(1, K + 1)]
+    pred = HipChainBatch.predicted_speedup(hip, K)
+    if K == 4:
+        assert pred < 1.
+        with pytest.raises(BbxError, match='predicted'):
+            HipChainBatch(chains)
+    else:
+        assert pred > 1.
     batch = HipChainBatch(chains, allow_slow=True)
-    V, W = rng.standard_normal((2, P)), rng.standard_normal((2, n))
+    V, W = rng.standard_normal((K, P)), rng.standard_normal((K, n))
     T, G = batch.dot(V), batch.Tdot(W)
-    for c in range(2):
+    for c in range(K):
         t, g = hip.dot(V[c]), hip.Tdot(W[c])
         assert np.abs(T[c] - t).max() <= 1e-11 * np.abs(t).max()
         assert np.abs(G[c] - g).max() <= 1e-11 * np.abs(g).max()
