@@ -154,10 +154,11 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
   double* sp = h->w_P[6].as<double>() + (h->intercept ? 1 : 0);
   CGState* st = h->cg_state.as<CGState>();
   // Folded direction step (common.hpp DotFold; tiled format, one column group):
-  // s.*p alternates between two buffers, s.*r has its own; same alignment rule
+  // s.*r has its own buffer (same alignment rule as s.*p), the unscaled t of
+  // the recurrence t_k = X~(s.*r_k) + beta t_{k-1} lives in the spare n-vector
   const bool fold = tiled_fold_applies(h);
-  double* sp_pair[2] = {sp, h->w_P[7].as<double>() + (h->intercept ? 1 : 0)};
   double* sr = h->w_P[9].as<double>() + (h->intercept ? 1 : 0);
+  double* tu = h->w_n[2].as<double>();   // (eta1's buffer: consumed before the loop)
 
   if (d_eta1 == nullptr) {
     double* e1 = h->w_n[2].as<double>();
@@ -284,8 +285,7 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     fa.rr_part = part_slot(h, PS_RR);
     fa.cr_part = part_slot(h, PS_C);
     fa.sr = sr;
-    fa.sp_old = sp_pair[(kk + 1) & 1];
-    fa.sp_new = sp_pair[kk & 1];
+    fa.tu = tu;
     fa.r = r;
     fa.pvec = pvec;
     fa.d = d;

@@ -142,9 +142,6 @@ struct CGState {
   int done;          // 1 once the stop rule fired; later kernels exit at entry
   int bad;           // 1 if a non-finite or non-positive curvature was seen
   int pad;
-  // folded direction step (DotFold): <offset, (s.*p)[1:]> of iteration k in
-  // slot k&1, carried by the recurrence s.*p_k = s.*r_k + beta_k s.*p_{k-1}
-  double coff[2];
 };
 
 struct KernelTimer {
@@ -318,15 +315,17 @@ struct TdotEpilogue {
 // <offset, (s.*r)[1:]>, and EVERY workgroup of the X~ v kernel
 //   * re-adds the NPART partials of r.r in the fixed order -> rho, the stop
 //     test of SciPy's loop top, beta = rho / rho_prev;
-//   * fills its LDS slices with  s.*p_k = s.*r_k + beta s.*p_{k-1}  (two
-//     coalesced vector reads instead of one: the recurrence is linear in s);
-//   * gets the epilogue constant <offset, (s.*p_k)[1:]> = <offset, (s.*r)[1:]>
-//     + beta <offset, (s.*p_{k-1})[1:]> from two scalars (CGState::coff);
+//   * streams  u = X~ (s.*r_k)  -- its LDS slices hold s.*r, ONE vector that
+//     does not depend on beta -- and forms in its epilogue
+//         t_k = u + beta t_{k-1}     ( = X~ (s.*p_k): X~ is linear and
+//                                        s.*p_k = s.*r_k + beta s.*p_{k-1} )
+//     from the previous iteration's unscaled t (an n-vector, updated in place);
 // and the workgroups, each for its own contiguous share of the P coordinates,
-// write p_k, s.*p_k (into the OTHER of two buffers: the old one is still being
-// read by the other workgroups' slice fills) and the partials of <p, d p>.
-// Three launches per CG iteration instead of four, no grid-wide reduction
-// inside a launch.
+// write p_k = r_k + beta p_{k-1} and the partials of <p, d p>.  s.*p is never
+// formed.  Three launches per CG iteration instead of four, no grid-wide
+// reduction inside a launch.  (Round 4's first form filled the slices with
+// s.*r + beta s.*p_old -- two vector reads per slice -- and lost 7 us in the
+// X~ v kernel for the 6.6 us it saved: LABNOTES.md R4.1.)
 struct DotFold {
   CGState* st = nullptr;
   int k = 0;
@@ -335,8 +334,7 @@ struct DotFold {
   const double* rr_part = nullptr;  // NPART partials of r.r
   const double* cr_part = nullptr;  // NPART partials of <offset, (s.*r)[1:]>
   const double* sr = nullptr;       // s.*r      (P; [intercept:] 16-byte aligned)
-  const double* sp_old = nullptr;   // s.*p_{k-1} (same layout; unread for k == 0)
-  double* sp_new = nullptr;         // s.*p_k
+  double* tu = nullptr;             // unscaled t = X~ (s.*p), n; read for k > 0
   const double* r = nullptr;
   double* pvec = nullptr;           // p, updated in place
   const double* d = nullptr;

@@ -255,9 +255,10 @@ constexpr int FILL_K_PAIRS =
 // p[c] = base + c writes an interleaved [R][K] result), slab is [G][R][K].
 //
 // FOLD (KP == 0, WIDE): the direction step of CG iteration fa.k rides in this
-// launch (common.hpp DotFold): x is s.*r, the slices are filled with
-// s.*r + beta s.*p_old, the epilogue constant comes from fa / CGState, and the
-// workgroup writes p, s.*p and <p, d p> for its share of the coordinates.
+// launch (common.hpp DotFold): x is s.*r (ONE vector: the slices do not depend
+// on beta), the epilogue forms t_k = X~(s.*r_k) + beta t_{k-1} (the product is
+// linear in its input), and the workgroup writes p and <p, d p> for its share
+// of the coordinates.
 //
 // DENSEP (KP == 0, direct epilogue): the dense block of a mixed design rides in
 // the epilogue (common.hpp DenseEpi).
@@ -355,8 +356,8 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   // loads -- one round trip for both.  Every WAVE re-adds the partials itself
   // (2 KB from L2 per wave): no LDS broadcast, no barrier.
   double f_rr[NPART / WAVE], f_cr[NPART / WAVE];
-  double f_atol = 0., f_rho_prev = 1., f_coff_prev = 0., f_x0r = 0., f_x0p = 0.;
-  double f_r0 = 0., f_p0 = 0., f_d0 = 0., f_sr0 = 0., f_sp0 = 0.;
+  double f_atol = 0., f_rho_prev = 1., f_x0r = 0.;
+  double f_r0 = 0., f_p0 = 0., f_d0 = 0.;
   double f_beta = 0., f_c = 0., f_pdp = 0.;
   int64_t f_j0 = 0, f_j1 = 0;
   if constexpr (FOLD) {
@@ -366,15 +367,9 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
       f_cr[k4] = fa.cr_part[lane + k4 * WAVE];
     }
     f_atol = fa.st->atol;
-    if (fa.k > 0) {
-      f_rho_prev = fa.st->rho[(fa.k - 1) & 1];
-      f_coff_prev = fa.st->coff[(fa.k - 1) & 1];
-    }
-    if (fa.intercept) {
-      f_x0r = fa.sr[0];
-      if (fa.k > 0) f_x0p = fa.sp_old[0];
-    }
-    // this workgroup's share of the P coordinates (p, s.*p, <p, d p>)
+    if (fa.k > 0) f_rho_prev = fa.st->rho[(fa.k - 1) & 1];
+    if (fa.intercept) f_x0r = fa.sr[0];
+    // this workgroup's share of the P coordinates (p and <p, d p>)
     const int64_t chunk = (fa.P + n_wg - 1) / n_wg;
     f_j0 = (int64_t)bid * chunk;
     f_j1 = f_j0 + chunk < fa.P ? f_j0 + chunk : fa.P;
@@ -382,11 +377,7 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
       const int64_t j = f_j0 + tid;
       f_r0 = fa.r[j];
       f_d0 = fa.d[j];
-      f_sr0 = fa.sr[j];
-      if (fa.k > 0) {
-        f_p0 = fa.pvec[j];
-        f_sp0 = fa.sp_old[j];
-      }
+      if (fa.k > 0) f_p0 = fa.pvec[j];
     }
   }
   // Retire every compiler-visible load before the ring starts (see ISSUE).
@@ -411,29 +402,16 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
       }
       return;
     }
-    double beta = 0., coff = cr, x0n = f_x0r;
-    if (fa.k > 0) {
-      beta = rho / f_rho_prev;
-      coff = fma(beta, f_coff_prev, cr);
-      x0n = fma(beta, f_x0p, f_x0r);
-    }
-    // wave-uniform scalars
+    const double beta = fa.k > 0 ? rho / f_rho_prev : 0.;
+    // wave-uniform scalars; c = v0 - <offset, v[1:]> of v = s.*r
     f_beta = lane_value(beta, 0);
-    f_c = lane_value(x0n - coff, 0);   // c = v0 - <offset, v[1:]>, v = s.*p
-    if (bid == 0 && tid == 0) {
-      fa.st->rho[fa.k & 1] = rho;
-      fa.st->coff[fa.k & 1] = coff;
-    }
+    f_c = lane_value(f_x0r - cr, 0);
+    if (bid == 0 && tid == 0) fa.st->rho[fa.k & 1] = rho;
     for (int64_t j = f_j0 + tid; j < f_j1; j += TILE_THREADS) {
       const bool first = j == f_j0 + tid;
       double pj = first ? f_r0 : fa.r[j];
-      double spj = first ? f_sr0 : fa.sr[j];
-      if (fa.k > 0) {
-        pj = fma(f_beta, first ? f_p0 : fa.pvec[j], pj);
-        spj = fma(f_beta, first ? f_sp0 : fa.sp_old[j], spj);
-      }
+      if (fa.k > 0) pj = fma(f_beta, first ? f_p0 : fa.pvec[j], pj);
       fa.pvec[j] = pj;
-      fa.sp_new[j] = spj;   // the formula of the slice fill, bit for bit
       f_pdp = fma((first ? f_d0 : fa.d[j]) * pj, pj, f_pdp);
     }
   }
@@ -576,10 +554,6 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
             } else {
               constexpr int FILL_PAIRS = (FILL_UNROLL + 1) / 2;
               v2d fp[FILL_PAIRS];
-              // FOLD: the matching piece of s.*p_old (iteration > 0)
-              v2d fq[FOLD ? FILL_PAIRS : 1];
-              const double* xo = FOLD ? fa.sp_old + fa.intercept : nullptr;
-              const bool two = FOLD && fa.k > 0;
               // (WIDE is chosen by the launcher: x and W * 8 are 16-byte aligned)
               constexpr bool wide = WIDE;
               if (wide) {
@@ -588,15 +562,9 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
                   const int j = 2 * (tid + u * TILE_THREADS);
                   if (j + 1 < cols_here && !(ablate & 2)) {
                     fp[u] = *reinterpret_cast<const v2d*>(x + col0 + j);
-                    if constexpr (FOLD)
-                      if (two) fq[u] = *reinterpret_cast<const v2d*>(xo + col0 + j);
                   } else {
                     fp[u].x = (j < cols_here && !(ablate & 2)) ? x[col0 + j] : 0.;
                     fp[u].y = 0.;
-                    if constexpr (FOLD) {
-                      fq[u].x = (two && j < cols_here) ? xo[col0 + j] : 0.;
-                      fq[u].y = 0.;
-                    }
                   }
                 }
               } else {
@@ -615,15 +583,6 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
               // compiler-visible load is left "maybe pending" inside the loop
               __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
               if (wide) {
-                if constexpr (FOLD) {
-                  if (two) {   // s.*p_k = s.*r_k + beta s.*p_{k-1}
-  #pragma unroll
-                    for (int u = 0; u < FILL_PAIRS; ++u) {
-                      fp[u].x = fma(f_beta, fq[u].x, fp[u].x);
-                      fp[u].y = fma(f_beta, fq[u].y, fp[u].y);
-                    }
-                  }
-                }
   #pragma unroll
                 for (int u = 0; u < FILL_PAIRS; ++u) {
                   const int j = 2 * (tid + u * TILE_THREADS);
@@ -833,6 +792,7 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     // wait for the slowest wave instead of following it.
     constexpr int EPI_UNROLL = TILE_PR_MAX / TILE_THREADS;
     double rs_pre[EPI_UNROLL];
+    double tu_pre[FOLD ? EPI_UNROLL : 1];   // FOLD: the previous iteration's t
     double cp_pre[NPART / WAVE];
     double x0_pre = 0.;
     if (out) {
@@ -840,6 +800,8 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
       for (int u = 0; u < EPI_UNROLL; ++u) {
         const int r = tid + u * TILE_THREADS;
         rs_pre[u] = (rowscale && r < rows_here) ? rowscale[row0 + r] : 1.;
+        if constexpr (FOLD)
+          tu_pre[u] = (fa.k > 0 && r < rows_here) ? fa.tu[row0 + r] : 0.;
       }
       if constexpr (!FOLD) {
   #pragma unroll
@@ -934,6 +896,12 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
         if (r < rows_here) {
           double t = c + acc[r];
           if (addend) t += addend[row0 + r];
+          if constexpr (FOLD) {
+            // t_k = X~ (s.*r_k) + beta t_{k-1}  ( = X~ (s.*p_k): the product is
+            // linear and s.*p_k = s.*r_k + beta s.*p_{k-1} ), kept unscaled
+            if (fa.k > 0) t = fma(f_beta, tu_pre[u], t);
+            fa.tu[row0 + r] = t;
+          }
           double v = t;
           if (rowscale) v *= rs_pre[u];
           out[row0 + r] = v;
@@ -2135,9 +2103,9 @@ int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
   *dot_bytes = tp->x.stream_bytes() + 8 * (h->P + h->n) +
                (tp->x.G > 1 ? 16 * tp->x.G * h->n : 0);
   // inside the CG loop the X~ v kernel carries the direction step (DotFold):
-  // a second slice vector (s.*p_old), and per coordinate r, p, d, s.*r, s.*p_old
-  // in, p and s.*p out -- that is the kernel the timers stamp
-  if (timed_only && tiled_fold_applies(h)) *dot_bytes += 8 * 8 * h->P;
+  // the previous t in and the new unscaled t out (n-vectors), per coordinate
+  // r, p, d in and p out -- that is the kernel the timers stamp
+  if (timed_only && tiled_fold_applies(h)) *dot_bytes += 16 * h->n + 4 * 8 * h->P;
   if (timed_only)
     *tdot_bytes = tp->xt.stream_bytes() + 8 * h->n +
                   8 * (int64_t)tp->xt.G * h->p;

@@ -152,7 +152,6 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_setup_kernel(
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // the solve's scalars start here, on the device: nothing to upload
     st->rho[0] = st->rho[1] = 0.;
-    st->coff[0] = st->coff[1] = 0.;
     st->atol = atol;
     st->bnorm2 = 0.;
     st->n_iter = 0;
