@@ -132,8 +132,9 @@ class HipDesignMatrix():
 
     def set_cg_fold(self, on):
         """Direction step of the CG loop inside the X~ v kernel (3 launches per
-        iteration) on / off for this design; None = the process default (off
-        unless BBX_CG_FOLD=1).  Measured slower than the 4-launch form."""
+        iteration) on / off for this design; None = the default (on for tiled
+        value-free designs of up to 250 000 rows, where it measures faster;
+        BBX_CG_FOLD=0|1 for the process)."""
         _lib.check(self._lib.bbx_design_set_cg_fold(
             self._h, -1 if on is None else int(bool(on))))
 

@@ -229,8 +229,8 @@ struct bbx_design {
   // design's dense block can ride in the dot kernel's epilogue for both
   // products (spmv_tiled.hip DenseEpi) instead of three kernels of its own.
   bool in_operator = false;
-  // direction step folded into the X~ v kernel (DotFold): -1 = the process
-  // default (off; BBX_CG_FOLD=1 turns it on), 0 / 1 = bbx_design_set_cg_fold
+  // direction step folded into the X~ v kernel (DotFold): -1 = the default
+  // (by size; BBX_CG_FOLD=0|1 for the process), 0 / 1 = bbx_design_set_cg_fold
   int cg_fold = -1;
   // Set around the CG loop: device address of CGState::done.  The host
   // enqueues operator applications ahead of the stop test; once the rule has
@@ -413,9 +413,9 @@ int build_tiled(bbx_design* h);
 void destroy_tiled(bbx_design* h);
 // Does the CG loop on this design fold its direction step into the X~ v kernel?
 // Possible on the tiled value-free layout with one column group and one
-// partial slot per panel (not a mixed design); OFF by default -- measured
-// slower than the separate direction kernel (LABNOTES.md, round 4) -- and
-// switched on per design (bbx_design_set_cg_fold) or per process (BBX_CG_FOLD=1).
+// partial slot per panel (not a mixed design); by default on for designs of up
+// to 250 000 rows, where it measures faster (LABNOTES.md, round 4); per design
+// bbx_design_set_cg_fold, per process BBX_CG_FOLD=0|1.
 bool tiled_fold_applies(const bbx_design* h);
 // t = rowscale .* (X~ (s.*p_k)) with the direction step of iteration fa.k inside
 // (see DotFold); partials of sum(t) and of <t, Omega t> as launch_dot.

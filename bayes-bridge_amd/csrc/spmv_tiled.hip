@@ -1828,8 +1828,17 @@ int launch_dot_tiled(bbx_design* h, const double* d_v,
 }
 
 bool tiled_fold_applies(const bbx_design* h) {
-  static const bool env_on = getenv("BBX_CG_FOLD") && atoi(getenv("BBX_CG_FOLD")) == 1;
-  const bool on = h->cg_fold >= 0 ? h->cg_fold != 0 : env_on;
+  // Default: on for designs of up to FOLD_MAX_ROWS rows.  The folded step costs
+  // the X~ v kernel two n-vector passes (previous t in, new t out) plus the
+  // direction work in front of its ring, and saves a P-vector launch with its
+  // boundary: measured +3.5 % Gibbs it/s at 100k x 10k (935-974 against 895-950),
+  // -1 % at 1M x 50k (LABNOTES.md R4.1).  BBX_CG_FOLD=0|1 and
+  // bbx_design_set_cg_fold override.
+  constexpr int64_t FOLD_MAX_ROWS = 250000;
+  static const int env_on = getenv("BBX_CG_FOLD") ? atoi(getenv("BBX_CG_FOLD")) : -1;
+  const bool on = h->cg_fold >= 0 ? h->cg_fold != 0
+                  : env_on >= 0   ? env_on != 0
+                                  : h->n <= FOLD_MAX_ROWS;
   if (!on || !h->sparse || h->format != BBX_FORMAT_TILED || h->hybrid || !h->tiled)
     return false;
   const TiledMatrix& m = static_cast<const TiledPair*>(h->tiled)->x;

@@ -36,6 +36,8 @@ CONFIGS = {
     "config4": (200000, 8000, None),
     # small smoke configuration (launcher dry runs, tests)
     "tiny": (20000, 1000, .02),
+    # between configs 2 and 3 (A/Bs of size-dependent choices)
+    "mid": (400000, 20000, .005),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALPHA, SLAB = .5, 2.   # demo.ipynb cell 7 prior
@@ -72,10 +74,11 @@ def parse_args(argv=None):
                          "X; rank 0 at N = 1 only; '0' = skip).  Default: 2,4 "
                          "for the sparse configs, 4,8,16,32 for config4")
     ap.add_argument("--multi-chain-steps", type=int, default=20)
-    ap.add_argument("--cg-fold", action="store_true",
-                    help="A/B: the opt-in 3-launch CG iteration (direction "
-                         "step inside the X~ v kernel, bbx_design_set_cg_fold); "
-                         "measured slower, off by default")
+    ap.add_argument("--cg-fold", type=int, default=None, choices=[0, 1],
+                    help="A/B: force the 3-launch CG iteration (direction step "
+                         "inside the X~ v kernel, bbx_design_set_cg_fold) on / "
+                         "off; default: the library's rule (on up to 250 000 "
+                         "rows)")
     ap.add_argument("--repeat", type=int, default=5,
                     help="how many times the K-step block is run in all for "
                          "the `repeat` object (the first is the timed region "
@@ -456,8 +459,8 @@ def main():
             n, p, nnz, prob["indptr"].data_ptr(), prob["indices"].data_ptr(),
             None, prob["offset"].data_ptr(), add_intercept=True,
             device=dev_index, storage=args.storage)
-        if args.cg_fold:
-            design.set_cg_fold(True)
+        if args.cg_fold is not None:
+            design.set_cg_fold(bool(args.cg_fold))
         # chain: prior and init of the reference demo (demo.ipynb cells 7, 9)
         n_success = prob["n_success"].cpu().numpy()
         def make_chain(seed):

@@ -170,13 +170,15 @@ int bbx_design_timed_bytes(const bbx_design* h, int64_t* dot_bytes,
  * update is merged, 5 otherwise.  Inside the CG loop the X~ v kernel that
  * bbx_design_timed_bytes describes then also moves 8 P-vectors. */
 int bbx_design_cg_launches(const bbx_design* h, int* per_iteration);
-/* The 3-launch form (direction step inside the X~ v kernel: every workgroup
- * re-adds the r.r partials, fills its slices with s.*r + beta s.*p_old) is
- * OFF by default: the second slice vector costs the X~ v kernel more than the
- * removed launch saves (1M x 50k: 46.6 -> 52.6 us per launch, 283-300 -> 273-291
- * Gibbs it/s; 100k x 10k: 894-948 -> 867-916).  on = 1 / 0 switches it for this
- * design where it applies, -1 restores the process default (BBX_CG_FOLD=1).
- * Same recurrence (scipy.sparse.linalg.cg, cg_sampler.py:77-80) either way. */
+/* The 3-launch form: the direction step inside the X~ v kernel -- every
+ * workgroup re-adds the r.r partials (rho, stop test, beta), the kernel streams
+ * X~ (s.*r) and its epilogue forms t_k = X~ (s.*r_k) + beta t_{k-1}, which is
+ * X~ (s.*p_k) by linearity.  Costs the X~ v kernel two n-vector passes, saves a
+ * P-vector launch: +3.5 % Gibbs it/s at 100k x 10k, -1 % at 1M x 50k, hence ON by
+ * default for designs of up to 250 000 rows where it applies.  on = 1 / 0
+ * switches it for this design, -1 restores the default (BBX_CG_FOLD=0|1 sets
+ * it for the process).  Same recurrence as scipy.sparse.linalg.cg
+ * (cg_sampler.py:77-80) either way, to rounding. */
 int bbx_design_set_cg_fold(bbx_design* h, int on);
 /* Algorithmic bytes of the single-pass dense operator kernel X^T(Omega (X v))
  * (dense designs that qualify for it; 0 otherwise): one pass over the stored

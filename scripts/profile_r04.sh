@@ -10,9 +10,9 @@ mkdir -p $O/r04p
 # ---- plain bench lines
 python3 bench.py > $O/r04_bench.json 2> $O/r04_bench.err
 python3 bench.py --steps 20 --warmup 5 > $O/r04_bench_driverflags.json 2>> $O/r04_bench.err
-python3 bench.py --cg-fold --multi-chain 0 --cpu-baseline-iters 0 > $O/r04_bench_cgfold.json 2>> $O/r04_bench.err
+python3 bench.py --cg-fold 1 --multi-chain 0 --cpu-baseline-iters 0 > $O/r04_bench_cgfold.json 2>> $O/r04_bench.err
 python3 bench.py --config config2 > $O/r04_bench_config2.json 2>> $O/r04_bench.err
-python3 bench.py --config config2 --cg-fold --multi-chain 0 --cpu-baseline-iters 0 > $O/r04_bench_config2_cgfold.json 2>> $O/r04_bench.err
+python3 bench.py --config config2 --cg-fold 0 --multi-chain 0 --cpu-baseline-iters 0 > $O/r04_bench_config2_nofold.json 2>> $O/r04_bench.err
 python3 bench.py --config config4 --steps 10 --warmup 3 --multi-chain-steps 6 > $O/r04_bench_config4.json 2>> $O/r04_bench.err
 python3 bench.py --config config4 --dense-storage float64 --steps 10 --warmup 3 --multi-chain-steps 6 > $O/r04_bench_config4_f64.json 2>> $O/r04_bench.err
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-baseline-iters 0 > $O/r04_bench_1rank_rccl.json 2>> $O/r04_bench.err

@@ -143,7 +143,9 @@ def test_a_chain_does_not_depend_on_its_batch(family, K):
     # (the bounds of test_hip_cg_sampler.py against the oracle)
     tol = 1e-6 if same_count else 1e-5
     assert np.abs(kept['coef'][0] - s1['coef'][0][0]).max() <= tol * scale
-    assert abs(kept['n_cg_iter'][0] - s1['n_cg_iter'][0][0]) <= 2
+    # (long solves sit on a flat stretch of the residual curve: 4 % there)
+    assert abs(kept['n_cg_iter'][0] - s1['n_cg_iter'][0][0]) <= max(
+        2, kept['n_cg_iter'][0] // 25)
     assert abs(kept['logp'][0] - s1['logp'][0][0]) <= 1e-6 * abs(kept['logp'][0])
     # reruns are bitwise reproducible
     b3 = HipChainBatch(_chains(hip, y, family, seeds_1), allow_slow=True)

@@ -232,10 +232,9 @@ def test_cg_sample_wide_design_with_column_groups_in_the_dot():
                                    (200000, 30000, .002)])
 def test_folded_direction_step_is_the_same_solve(shape):
     """bbx_design_set_cg_fold(h, 1): three launches per CG iteration -- the
-    stop test, beta and s.*p = s.*r + beta s.*p_old inside the X~ v kernel
-    (csrc/common.hpp DotFold; one and several column blocks, i.e. one and
-    several slice fills per workgroup) -- against the oracle and against the
-    default four-launch loop on the same design: same iteration count, same
+    stop test, beta and t_k = X~ (s.*r_k) + beta t_{k-1} inside the X~ v kernel
+    (csrc/common.hpp DotFold; one and several column blocks) -- against the
+    oracle and against the four-launch loop on the same design: same iteration count, same
     draw to rounding; bitwise reproducible; warm and cold start; a solve cut
     off at maxiter reports what the default loop reports."""
     from bayesbridge_amd import HipCGSampler, HipSparseDesignMatrix, simulate
@@ -255,6 +254,9 @@ def test_folded_direction_step_is_the_same_solve(shape):
         hip.set_cg_fold(True)
         assert hip.cg_launches == before == 5
         return
+    # default: folded up to 250 000 rows (where it measures faster)
+    assert hip.cg_launches == (3 if n <= 250000 else 4)
+    hip.set_cg_fold(False)
     assert hip.cg_launches == 4
     for seed, cold in ((3, False), (4, True)):
         inp = cg_inputs(n, P, seed=seed)
