@@ -83,7 +83,8 @@ def _declare(lib):
              POINTER(c_int64), POINTER(c_int)], c_int),
         "bbx_design_tiled_info": (
             [hp, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int),
-             POINTER(c_int), POINTER(c_int64), POINTER(c_int64)], c_int),
+             POINTER(c_int), POINTER(c_int64), POINTER(c_int64),
+             POINTER(c_int)], c_int),
         "bbx_design_dot": ([hp, c_void_p, c_void_p], c_int),
         "bbx_design_tdot": ([hp, c_void_p, c_void_p], c_int),
         "bbx_design_dot_dev": ([hp, c_void_p, c_void_p], c_int),

@@ -148,20 +148,23 @@ class HipDesignMatrix():
     def tiled_info(self, chains=1):
         """Geometry of the LDS-tiled layout: {'X': {...}, 'Xt': {...}}; chains =
         2, 4: the layout sized for that many right-hand sides (once a batch of
-        that width has been built).  'grid' = workgroups of one launch."""
+        that width has been built).  'grid' = workgroups of one launch;
+        'packed' = value-free ids stored as groups of five (csrc/
+        tiled_layout.hpp) instead of four 16-bit ids per eight bytes."""
         out = {}
         base = {1: 0, 2: 2, 4: 4}[int(chains)]
         n, P = self.shape
         for which, name in ((base, 'X'), (base + 1, 'Xt')):
             W, nb, PR, G = c_int(), c_int(), c_int(), c_int()
             nq, ns = c_int64(), c_int64()
+            pk = c_int()
             _lib.check(self._lib.bbx_design_tiled_info(
                 self._h, which, byref(W), byref(nb), byref(PR), byref(G),
-                byref(nq), byref(ns)))
+                byref(nq), byref(ns), byref(pk)))
             rows = n if name == 'X' else P - int(self.intercept_added)
             out[name] = dict(W=W.value, n_block=nb.value, PR=PR.value,
                              G=G.value, n_quad=nq.value, n_slice=ns.value,
-                             grid=-(-rows // max(PR.value, 1)) * G.value)
+                             packed=bool(pk.value), grid=-(-rows // max(PR.value, 1)) * G.value)
         return out
 
     @property

@@ -911,11 +911,11 @@ int bbx_design_storage_bytes(const bbx_design* h, int64_t* bytes) {
 
 int bbx_design_tiled_info(const bbx_design* h, int which, int* W,
                           int* n_block, int* PR, int* G, int64_t* n_quad,
-                          int64_t* n_slice) {
+                          int64_t* n_slice, int* packed) {
   BBX_TRY(check_handle(h));
   if (!h->sparse || h->format != BBX_FORMAT_TILED)
     return fail(BBX_ERR_STATE, "operator is not in the tiled format");
-  return tiled_describe(h, which, W, n_block, PR, G, n_quad, n_slice);
+  return tiled_describe(h, which, W, n_block, PR, G, n_quad, n_slice, packed);
 }
 
 int bbx_design_hybrid_info(const bbx_design* h, int* is_hybrid,

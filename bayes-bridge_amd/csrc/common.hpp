@@ -469,7 +469,8 @@ int64_t tiled_storage_bytes(const bbx_design* h);
 int tiled_hybrid_info(const bbx_design* h, int64_t* ones_nnz,
                       int64_t* rest_nnz, int64_t* dense_nnz, int* kd);
 int tiled_describe(const bbx_design* h, int which, int* W, int* n_block,
-                   int* PR, int* G, int64_t* n_quad, int64_t* n_slice);
+                   int* PR, int* G, int64_t* n_quad, int64_t* n_slice,
+                   int* packed = nullptr);
 int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,
                        uint64_t stream, double* d_out);
 

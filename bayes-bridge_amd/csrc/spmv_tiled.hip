@@ -73,6 +73,8 @@ struct TiledMatrix {
   int W = 0, n_block = 0, PR = 0, n_panel = 0, G = 0;
   int K = 1;  // right-hand sides the geometry was sized for
   bool has_vals = false;
+  bool packed = false;  // steps hold one 5-entry group per row (tiled_layout.hpp)
+  int Wl = 0;           // slots of one vector slice in LDS (W, or packed_slots(W))
   int64_t n_slice = 0, n_quad = 0, n_tile = 0;
   DevMem ids;        // uint4[n_quad * 64]
   DevMem vals;       // double[n_quad * 64 * 8] when has_vals
@@ -165,6 +167,46 @@ __device__ __forceinline__ void step_accumulate(const double* __restrict__ xs,
     b0 += xs[e.z & 0xFFFFu] + xs[e.w & 0xFFFFu];
     b1 += xs[e.z >> 16] + xs[e.w >> 16];
   }
+}
+
+// The packed step (tiled_layout.hpp, packed_slot): e.x | e.y << 32 is row A's
+// group, e.z | e.w << 32 row B's -- the slice slot of the first entry in bits
+// 0-13, then four 12-bit forward deltas.  All five slots are gathered always
+// (short groups end on a zero slot of the slice), so the decode is shifts and
+// adds only: 11 VALU operations for five entries, against 8 for four plain ids.
+__device__ __forceinline__ unsigned lshl3_add(unsigned d, unsigned o) {
+  // o + 8 d in one operation; written in C the compiler turns the field
+  // extraction and this into shift, and, add (15 operations per group for 11)
+  unsigned r;
+  asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(r) : "v"(d), "v"(o));
+  return r;
+}
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+__device__ __forceinline__ unsigned lds_address(const double* p) {
+  return (unsigned)(uintptr_t)(lds_cdouble*)p;  // p points into LDS
+}
+__device__ __forceinline__ double lds_read(unsigned addr) {
+  return *(lds_cdouble*)(uintptr_t)addr;
+}
+// xs_addr = lds_address(xs): the slice's LDS byte address, added once per
+// group instead of once per gather.
+__device__ __forceinline__ void packed_group(unsigned xs_addr, unsigned lo,
+                                             unsigned hi, double& s0,
+                                             double& s1) {
+  // byte addresses of the five slots: o_{k+1} = o_k + 8 d_k
+  const unsigned o0 = lshl3_add(lo & 0x3FFFu, xs_addr);
+  const unsigned o1 = lshl3_add(__builtin_amdgcn_ubfe(lo, 14, 12), o0);
+  const unsigned o2 =
+      lshl3_add(__builtin_amdgcn_alignbit(hi, lo, 26) & 0xFFFu, o1);
+  const unsigned o3 = lshl3_add(__builtin_amdgcn_ubfe(hi, 6, 12), o2);
+  const unsigned o4 = lshl3_add(hi >> 18, o3);  // bits 62-63 of a group are 0
+  s0 += (lds_read(o0) + lds_read(o2)) + lds_read(o4);
+  s1 += lds_read(o1) + lds_read(o3);
+}
+__device__ __forceinline__ void step_accumulate_packed(
+    unsigned xs_addr, v4u e, double& a0, double& a1, double& b0, double& b1) {
+  packed_group(xs_addr, e.x, e.y, a0, a1);
+  packed_group(xs_addr, e.z, e.w, b0, b1);
 }
 
 // The same step for K = 2 KP right-hand sides (batched chains).  The vector
@@ -262,7 +304,8 @@ constexpr int FILL_K_PAIRS =
 //
 // DENSEP (KP == 0, direct epilogue): the dense block of a mixed design rides in
 // the epilogue (common.hpp DenseEpi).
-template <bool VALS, bool WIDE, int KP, bool FOLD = false, bool DENSEP = false>
+template <bool VALS, bool WIDE, int KP, bool FOLD = false, bool DENSEP = false,
+          bool PACK = false>
 __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_kernel(
     int64_t R, int64_t C, int W, int PR, int G, int blocks_per_group,
     const int32_t* __restrict__ wave_desc, int desc_stride,
@@ -281,13 +324,18 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     const double* __restrict__ addend, DotFold fa, DenseEpi de) {
   static_assert(!FOLD || (KP == 0 && WIDE), "the folded direction step is single-chain");
   static_assert(!DENSEP || (KP == 0 && !FOLD), "dense epilogue: single chain, plain loop");
+  static_assert(!PACK || (KP == 0 && !VALS), "packed groups: value-free, one right-hand side");
   constexpr int K = KP > 0 ? 2 * KP : 1;
   // (scalar load, issued first; checked below once the descriptor loads that
   // every launch needs anyway have been issued, so it adds no round trip)
   const int skip = skip_flag ? *skip_flag : 0;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* xs = lds;               // W + 8 doubles; xs[W] == 0 (padding target)
-  double* acc = lds + (W + 8);    // n_acc = PR + extra doubles
+  // slice slots: one per column, plus (PACK) a zero slot after every 4095
+  // columns; xs[Wl .. Wl + 8) == 0 (padding target / terminal zero slot)
+  const int Wl = PACK ? W + (W - 1) / PACK_PERIOD : W;
+  double* xs = lds;               // Wl + 8 doubles
+  const unsigned xs_addr = lds_address(xs);
+  double* acc = lds + (Wl + 8);   // n_acc = PR + extra doubles
   // batched: KP planes of (W + 8) pairs, then KP planes of n_acc pairs
   v2d* xs2 = reinterpret_cast<v2d*>(lds);
   v2d* acc2 = xs2 + KP * (W + 8);
@@ -320,7 +368,12 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     if (tid < 8 * KP) xs2[(tid >> 3) * xplane + W + (tid & 7)] = zero2;
   } else {
     for (int r = tid; r < n_acc; r += TILE_THREADS) acc[r] = 0.;
-    if (tid < 8) xs[W + tid] = 0.;
+    if (tid < 8) xs[Wl + tid] = 0.;
+    if constexpr (PACK) {
+      // the slice fills never touch the zero slots: written once
+      const int z = (tid - 8) * (PACK_PERIOD + 1) + PACK_PERIOD;
+      if (tid >= 8 && z < Wl) xs[z] = 0.;
+    }
   }
 
   constexpr int BATCH = VALS ? BATCH_VAL : BATCH_BIN;  // steps per ring slot
@@ -586,15 +639,23 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   #pragma unroll
                 for (int u = 0; u < FILL_PAIRS; ++u) {
                   const int j = 2 * (tid + u * TILE_THREADS);
-                  if (j < W) *reinterpret_cast<v2d*>(xs + j) = fp[u];  // W even
+                  if constexpr (PACK) {
+                    // (a pair may straddle a zero slot: two 8-byte stores)
+                    if (j < W) {
+                      xs[j + j / PACK_PERIOD] = fp[u].x;
+                      xs[j + 1 + (j + 1) / PACK_PERIOD] = fp[u].y;  // W even
+                    }
+                  } else {
+                    if (j < W) *reinterpret_cast<v2d*>(xs + j) = fp[u];  // W even
+                  }
                 }
               } else {
   #pragma unroll
                 for (int u = 0; u < FILL_PAIRS; ++u) {
                   const int j0 = tid + (2 * u) * TILE_THREADS;
                   const int j1 = tid + (2 * u + 1) * TILE_THREADS;
-                  if (j0 < W) xs[j0] = fp[u].x;
-                  if (j1 < W) xs[j1] = fp[u].y;
+                  if (j0 < W) xs[PACK ? j0 + j0 / PACK_PERIOD : j0] = fp[u].x;
+                  if (j1 < W) xs[PACK ? j1 + j1 / PACK_PERIOD : j1] = fp[u].y;
                 }
               }
             }
@@ -612,6 +673,8 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
                 else if constexpr (KP > 0)
                   step_accumulate_k<VALS, KP>(xs2, xplane, e[k][u], ev[k][u],
                                               A0, A1, B0, B1);
+                else if constexpr (PACK)
+                  step_accumulate_packed(xs_addr, e[k][u], a0, a1, b0, b1);
                 else
                   step_accumulate<VALS>(xs, e[k][u], ev[k][u], a0, a1, b0, b1);
               }
@@ -1010,6 +1073,8 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
   m.n_panel = host.n_panel;
   m.G = host.G;
   m.has_vals = host.has_vals;
+  m.packed = host.packed;
+  m.Wl = host.Wl;
   m.n_slice = host.n_slice;
   m.n_quad = host.n_quad;
   m.n_tile = host.n_tile;
@@ -1035,7 +1100,7 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
 
 static size_t lds_bytes(const TiledMatrix& m) {
   return sizeof(double) * (size_t)m.K *
-         ((size_t)m.W + 8 + (size_t)m.PR + (size_t)m.n_extra);
+         ((size_t)m.Wl + 8 + (size_t)m.PR + (size_t)m.n_extra);
 }
 
 void destroy_tiled(bbx_design* h) {
@@ -1224,24 +1289,33 @@ int build_tiled(bbx_design* h) {
   const int st_h = no_throw([&]() -> int { return build_hybrid(h); });
   if (st_h < 0) return st_h;
   if (st_h != BBX_OK) BBX_TRY(build_tiled_pair(h, 1, &h->tiled));
-#define BBX_TILED_ATTR(VV, WW, KK, FF)                                         \
+#define BBX_TILED_ATTR(VV, WW, KK, FF, PP)                                     \
   BBX_HIP(hipFuncSetAttribute(                                                 \
-      reinterpret_cast<const void*>(&tiled_spmv_kernel<VV, WW, KK, FF>),       \
+      reinterpret_cast<const void*>(                                           \
+          &tiled_spmv_kernel<VV, WW, KK, FF, false, PP>),                      \
       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-  // (the dense-epilogue instantiation holds 2 KB of static LDS: the layouts
+  // (the dense-epilogue instantiations hold 2 KB of static LDS: the layouts
   // leave exactly that free, lds_budget_per_chain)
   BBX_HIP(hipFuncSetAttribute(
       reinterpret_cast<const void*>(
-          &tiled_spmv_kernel<false, true, 0, false, true>),
+          &tiled_spmv_kernel<false, true, 0, false, true, false>),
       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-  BBX_TILED_ATTR(false, false, 0, false);
-  BBX_TILED_ATTR(false, true, 0, false);
-  BBX_TILED_ATTR(true, false, 0, false);
-  BBX_TILED_ATTR(true, true, 0, false);
-  BBX_TILED_ATTR(false, true, 1, false);
-  BBX_TILED_ATTR(false, true, 2, false);
-  BBX_TILED_ATTR(true, true, 1, false);
-  BBX_TILED_ATTR(false, true, 0, true);   // folded direction step (CG loop)
+  BBX_HIP(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(
+          &tiled_spmv_kernel<false, true, 0, false, true, true>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+  BBX_TILED_ATTR(false, false, 0, false, false);
+  BBX_TILED_ATTR(false, true, 0, false, false);
+  BBX_TILED_ATTR(true, false, 0, false, false);
+  BBX_TILED_ATTR(true, true, 0, false, false);
+  BBX_TILED_ATTR(false, true, 1, false, false);
+  BBX_TILED_ATTR(false, true, 2, false, false);
+  BBX_TILED_ATTR(true, true, 1, false, false);
+  BBX_TILED_ATTR(false, true, 0, true, false);   // folded direction step (CG loop)
+  // value-free, one right-hand side, ids packed in groups of five
+  BBX_TILED_ATTR(false, false, 0, false, true);
+  BBX_TILED_ATTR(false, true, 0, false, true);
+  BBX_TILED_ATTR(false, true, 0, true, true);
 #undef BBX_TILED_ATTR
   // The reference-layout index arrays stay in HBM (0.8 GB at 1M x 50k, next to
   // 288 GB): a layout sized for K batched chains is built from them on first
@@ -1403,11 +1477,10 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
   const DotFold fa = fold ? *fold : DotFold{};
   const DenseEpi de = dense ? *dense : DenseEpi{};
 #define BBX_TILED_LAUNCH_W(VV, WW, KK, VALPTR)                                 \
-  BBX_TILED_LAUNCH_F(VV, WW, KK, false, VALPTR)
-#define BBX_TILED_LAUNCH_F(VV, WW, KK, FF, VALPTR)                             \
-  BBX_TILED_LAUNCH_D(VV, WW, KK, FF, false, VALPTR)
-#define BBX_TILED_LAUNCH_D(VV, WW, KK, FF, DD, VALPTR)                         \
-  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, WW, KK, FF, DD>), dim3(grid),   \
+  BBX_TILED_LAUNCH_D(VV, WW, KK, false, false, false, VALPTR)
+#define BBX_TILED_LAUNCH_D(VV, WW, KK, FF, DD, PP, VALPTR)                     \
+  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, WW, KK, FF, DD, PP>),           \
+                     dim3(grid),                                               \
                      dim3(TILE_THREADS), (unsigned)lb, h->stream, ev_begin,    \
                      ev_end, 0u, m.R, m.C, m.W, m.PR,                          \
                      m.G, (m.n_block + m.G - 1) / m.G,                         \
@@ -1419,11 +1492,11 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                      out_sum_part, twt_off, ablate, dbg, h->skip_flag,         \
                      bb.rowscale, bb.out, bb.out_stride, bb.part_stride,       \
                      addend, fa, de)
-#define BBX_TILED_LAUNCH(VV, VALPTR)                                           \
+// value-free, one right-hand side: plain ids or packed groups (m.packed)
+#define BBX_TILED_LAUNCH_P(WW, FF, DD)                                         \
   do {                                                                         \
-    if (m.K == 2) BBX_TILED_LAUNCH_W(VV, true, 1, VALPTR);                \
-    else if (wide) BBX_TILED_LAUNCH_W(VV, true, 0, VALPTR);                    \
-    else BBX_TILED_LAUNCH_W(VV, false, 0, VALPTR);                             \
+    if (m.packed) BBX_TILED_LAUNCH_D(false, WW, 0, FF, DD, true, nullptr);     \
+    else BBX_TILED_LAUNCH_D(false, WW, 0, FF, DD, false, nullptr);             \
   } while (0)
   // 16-byte slice loads need every slice start 16-byte aligned: W is a multiple
   // of 64 doubles, so it is the alignment of x itself that decides (inside the
@@ -1442,7 +1515,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
     if (m.K != 1 || !wide || m.G != 1 || !out || m.has_vals || addend || fold ||
         dense->kd < 1 || dense->kd > DENSE_EPI_MAX)
       return fail(BBX_ERR_STATE, "dense epilogue: unsupported launch");
-    BBX_TILED_LAUNCH_D(false, true, 0, false, true, nullptr);
+    BBX_TILED_LAUNCH_P(true, false, true);
   } else if (fold) {
     // folded direction step: single chain, 16-byte aligned vectors, the direct
     // epilogue with its partial sums
@@ -1452,16 +1525,21 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
     // ring: 16 VGPRs would spill to scratch under an asm-issued ring)
     if (m.has_vals)
       return fail(BBX_ERR_STATE, "folded direction step: value-free layout only");
-    BBX_TILED_LAUNCH_F(false, true, 0, true, nullptr);
+    BBX_TILED_LAUNCH_P(true, true, false);
   } else if (m.K == 4)
     BBX_TILED_LAUNCH_W(false, true, 2, nullptr);
-  else if (m.has_vals)
-    BBX_TILED_LAUNCH(true, m.vals.as<double>());
+  else if (m.has_vals) {
+    if (m.K == 2) BBX_TILED_LAUNCH_W(true, true, 1, m.vals.as<double>());
+    else if (wide) BBX_TILED_LAUNCH_W(true, true, 0, m.vals.as<double>());
+    else BBX_TILED_LAUNCH_W(true, false, 0, m.vals.as<double>());
+  } else if (m.K == 2)
+    BBX_TILED_LAUNCH_W(false, true, 1, nullptr);
+  else if (wide)
+    BBX_TILED_LAUNCH_P(true, false, false);
   else
-    BBX_TILED_LAUNCH(false, nullptr);
-#undef BBX_TILED_LAUNCH
+    BBX_TILED_LAUNCH_P(false, false, false);
 #undef BBX_TILED_LAUNCH_W
-#undef BBX_TILED_LAUNCH_F
+#undef BBX_TILED_LAUNCH_P
 #undef BBX_TILED_LAUNCH_D
   BBX_HIP(hipGetLastError());
   if (dbg) {
@@ -2149,7 +2227,8 @@ int64_t tiled_storage_bytes(const bbx_design* h) {
 }
 
 int tiled_describe(const bbx_design* h, int which, int* W, int* n_block,
-                   int* PR, int* G, int64_t* n_quad, int64_t* n_slice) {
+                   int* PR, int* G, int64_t* n_quad, int64_t* n_slice,
+                   int* packed) {
   const TiledPair* tp = static_cast<const TiledPair*>(h->tiled);
   // mixed designs: the value-free part (0, 1) and the valued rest (6, 7)
   if (h->hybrid) {
@@ -2169,6 +2248,7 @@ int tiled_describe(const bbx_design* h, int which, int* W, int* n_block,
   if (G) *G = m.G;
   if (n_quad) *n_quad = m.n_quad;
   if (n_slice) *n_slice = m.n_slice;
+  if (packed) *packed = m.packed ? 1 : 0;
   return BBX_OK;
 }
 

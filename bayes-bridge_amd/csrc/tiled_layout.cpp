@@ -73,6 +73,7 @@ TiledOptions TiledOptions::from_env(bool transpose) {
   };
   geti("BBX_TILED_PR", &o.force_PR);
   geti("BBX_TILED_G", &o.force_G);
+  geti("BBX_TILED_PACK", &o.packed);  // 0 / 1: plain ids / groups of five forced
   if (getenv("BBX_TILED_STATS")) o.stats = true;
   return o;
 }
@@ -226,7 +227,39 @@ struct VRow {
   int32_t len;
   uint16_t slot;  // accumulator slot in LDS (row, or extra slot of a chunk)
   int32_t steps = 0;    // steps this row needs (sort key)
+  int32_t g_begin = 0;  // packed layout: first group in the tile's group list
 };
+
+// Groups of one (chunk of a) row in the packed layout (tiled_layout.hpp,
+// packed_slot): appended to *out when given; returns their number.  `Wl` is
+// the terminal zero slot of the slice.
+static int pack_groups(const int32_t* colidx, int32_t begin, int32_t len,
+                       int64_t col0, int Wl, std::vector<uint64_t>* out) {
+  int n = 0;
+  int32_t i = 0;
+  while (i < len) {
+    int32_t prev = packed_slot((int)(colidx[begin + i] - col0));
+    uint64_t g = (uint64_t)prev;
+    int k = 1;
+    while (k < 5 && i + k < len) {
+      const int32_t cur = packed_slot((int)(colidx[begin + i + k] - col0));
+      const int32_t d = cur - prev;
+      if (d < 0 || d > 4095) break;  // far apart (or unsorted): new group
+      g |= (uint64_t)d << (14 + 12 * (k - 1));
+      prev = cur;
+      ++k;
+    }
+    if (k < 5) {  // step onto the next zero slot and stay there
+      int32_t z = prev | 4095;
+      if (z > Wl) z = Wl;
+      g |= (uint64_t)(z - prev) << (14 + 12 * (k - 1));
+    }
+    if (out) out->push_back(g);
+    i += k;
+    ++n;
+  }
+  return n;
+}
 
 // Bank-aware entry order of one 32-lane half of a slice.
 //
@@ -376,8 +409,10 @@ static void bank_aware_order(const HalfRow* rows, int n_rows, int64_t col0,
 static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
                         const int32_t* colidx, const double* vals, int W,
                         int n_block, int PR, int G, int extra_budget,
-                        int panel, const TiledOptions& opt,
+                        int panel, bool packed, const TiledOptions& opt,
                         PanelBuild& pb) {
+  const int Wl = packed_slots(W);  // packed: terminal zero slot of a slice
+  std::vector<uint64_t> groups;    // packed: groups of the tile's rows
   const int64_t row0 = (int64_t)panel * PR;
   const int rows_here = (int)std::min<int64_t>(PR, R - row0);
   // pass 1: segment of every row in every column block
@@ -460,9 +495,11 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
       }
       const int64_t want_rows = 2 * TILE_WAVES * SLICE_ROWS;
       if (densest_rows < (3 * TILE_WAVES * SLICE_ROWS) / 2 && !t_env) {
+        // (whole steps: 4 entries, or a packed group of 5)
+        const int gran = packed ? 5 : 4;
         int t_par = (int)((densest_entries + want_rows - 1) / want_rows);
-        t_par = (t_par + 3) / 4 * 4;
-        if (t_par < 8) t_par = 8;
+        t_par = (t_par + gran - 1) / gran * gran;
+        if (t_par < 2 * gran) t_par = 2 * gran;
         if (t_par < t_min) t_min = t_par;
       }
     }
@@ -532,7 +569,7 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
         max_len = std::max(max_len, len);
       }
     }
-    if (opt.bank_aware) {
+    if (opt.bank_aware && !packed) {
       // columns present in >= 1/16 of the tile's rows: likely to appear twice
       // among the 32 rows a gather instruction serves
       col_rows.assign((size_t)W + 1, 0);
@@ -545,10 +582,16 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
       const size_t thresh = std::max<size_t>(2, vrows.size() / 256);
       for (int j = 0; j <= W; ++j) hot[(size_t)j] = col_rows[(size_t)j] >= thresh;
     }
-    // sort key: steps the row needs (4 entries per step)
+    // sort key: steps the row needs (4 entries, or one packed group, per step)
     int max_key = 0;
+    groups.clear();
     for (VRow& v : vrows) {
-      v.steps = (v.len + 3) / 4;
+      if (packed) {
+        v.g_begin = (int32_t)groups.size();
+        v.steps = pack_groups(colidx, v.begin, v.len, col0, Wl, &groups);
+      } else {
+        v.steps = (v.len + 3) / 4;
+      }
       max_key = std::max(max_key, v.steps);
     }
     // by decreasing step count (counting sort, stable)
@@ -574,7 +617,8 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
       if (vals) pb.vals.resize((id0 + (size_t)nq * LANES) * 8, 0.);
       // entry order inside the rows (see bank_aware_order): one problem per
       // (row A | row B) x (lanes 0-31 | lanes 32-63)
-      const bool reorder = opt.bank_aware;
+      // (a packed group holds its entries in ascending order: no dealing)
+      const bool reorder = opt.bank_aware && !packed;
       if (reorder) {
         slice_perm.resize(SLICE_ROWS);
         // lanes whose gathers are served in the same LDS cycle(s): the two
@@ -613,7 +657,22 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
         if (LANES + l < rows_in) vr[1] = &sorted[base + LANES + l];
         pb.rowids.push_back((uint32_t)(vr[0] ? vr[0]->slot : NO_ROW) |
                             ((uint32_t)(vr[1] ? vr[1]->slot : NO_ROW) << 16));
-        for (uint32_t q = 0; q < nq; ++q) {
+        for (uint32_t q = 0; q < nq && packed; ++q) {
+          uint64_t g[2];
+          for (int half = 0; half < 2; ++half) {
+            const VRow* v = vr[half];
+            g[half] = (v && (int)q < v->steps)
+                          ? groups[(size_t)v->g_begin + q]
+                          : (uint64_t)Wl;  // empty: five times the zero slot
+          }
+          Ids4 step;
+          step.x = (uint32_t)g[0];
+          step.y = (uint32_t)(g[0] >> 32);
+          step.z = (uint32_t)g[1];
+          step.w = (uint32_t)(g[1] >> 32);
+          pb.ids[id0 + (size_t)q * LANES + l] = step;
+        }
+        for (uint32_t q = 0; q < nq && !packed; ++q) {
           uint16_t e[8];
           for (int half = 0; half < 2; ++half) {
             const VRow* v = vr[half];
@@ -678,7 +737,8 @@ static void choose_shape(int64_t R, int64_t C, int64_t nnz, int n_block, int W,
                          double* cost_out) {
   double best = 1e300;
   int best_pr = 128, best_g = 1;
-  const int lds_rows = lds_budget_per_chain(K) - (W + 8);
+  // (K = 1: four more slots, the zero slots of a packed slice)
+  const int lds_rows = lds_budget_per_chain(K) - (W + 8) - (K == 1 ? 4 : 0);
   // (panels beyond 4096 rows only through BBX_TILED_PR[_T]: at 1M x 50k the
   // X^T geometries PR = 6272 x 96 blocks x G = 32 and PR = 5056 x 75 x 25 ran
   // the main kernel in 46.9 / 49.7 us against 48.5 us, with twice the slab
@@ -814,7 +874,7 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   }
   // LDS left after the vector slice and the row accumulators pays for the
   // extra accumulators of split rows (2 KB stay free for static LDS).
-  int extra_budget = lds_budget_per_chain(K) - (m.W + 8) - m.PR;
+  int extra_budget = lds_budget_per_chain(K) - (m.W + 8) - m.PR - (K == 1 ? 4 : 0);
   if (extra_budget > 8192) extra_budget = 8192;
   if (extra_budget < 0) extra_budget = 0;
   if (opt.extra_budget >= 0) extra_budget = opt.extra_budget;
@@ -822,6 +882,64 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   std::vector<PanelBuild> pbs((size_t)m.n_panel);
   unsigned n_thr = (unsigned)builder_threads(opt.max_threads);
   if ((unsigned)m.n_panel < n_thr) n_thr = (unsigned)m.n_panel;
+  // Packed groups or plain ids (value-free, one right-hand side)?  A row
+  // segment of `len` entries takes ceil(len / 4) plain steps, or as many groups
+  // as its gaps allow (five entries at best, fewer where columns lie more than
+  // 4095 slots apart).  Groups cost ~40 % more index arithmetic per entry and
+  // give up the bank-aware entry order, so they pay where the id stream comes
+  // from HBM and the slices are long enough to hide the decode behind it.
+  // Measured on MI355X (profiles/r04_packed_ids.txt; X~ v / X~^T w, us):
+  //   1M x 50k, 100 / row   235 MB of plain ids  46.4 -> 43.8 / 49.7 -> 45.7
+  //   400k x 20k, 100 / row 104 MB               32.1 -> 30.0 / 23.2 -> 21.6
+  //   1M x 20k, 40 / row    103 MB               24.4 -> 22.7 / 25.4 -> 24.6
+  //   1M x 50k, 50 / row    133 MB (12 / segment) 32.5 -> 32.1 / 32.5 -> 33.8
+  //   200k x 20k             56 MB               25.8 -> 25.1 / 15.8 -> 16.6
+  //   100k x 10k             26 MB               13.6 -> 14.8 / 12.5 -> 13.7
+  // Hence: groups if they save >= 5 % of the steps, the plain ids would exceed
+  // 80 MB and a row segment holds >= 20 entries on average.  One pass over the
+  // entries; TiledOptions::packed = 0 / 1 overrides (BBX_TILED_PACK).
+  m.packed = false;
+  if (!vals && K == 1 && opt.packed != 0 && m.W + 4 <= (1 << 14)) {
+    m.packed = opt.packed > 0;
+    if (opt.packed < 0 && nnz > 0) {
+      std::vector<int64_t> plain(n_thr, 0), grouped(n_thr, 0), segs(n_thr, 0);
+      std::vector<std::thread> counters;
+      const int Wl = packed_slots(m.W);
+      for (unsigned t = 0; t < n_thr; ++t)
+        counters.emplace_back([&, t]() {
+          const int64_t r0 = R * (int64_t)t / n_thr, r1 = R * (int64_t)(t + 1) / n_thr;
+          int64_t a = 0, b = 0, c = 0;
+          for (int64_t r = r0; r < r1; ++r) {
+            int32_t k = rowptr[r];
+            const int32_t e = rowptr[r + 1];
+            while (k < e) {
+              const int64_t cb = colidx[k] / m.W;
+              const int64_t col_end = (cb + 1) * m.W;
+              const int32_t b0 = k;
+              while (k < e && colidx[k] < col_end) ++k;
+              a += (k - b0 + 3) / 4;
+              b += pack_groups(colidx, b0, k - b0, cb * m.W, Wl, nullptr);
+              ++c;
+            }
+          }
+          plain[t] = a;
+          grouped[t] = b;
+          segs[t] = c;
+        });
+      for (auto& th : counters) th.join();
+      int64_t a = 0, b = 0, c = 0;
+      for (unsigned t = 0; t < n_thr; ++t) {
+        a += plain[t];
+        b += grouped[t];
+        c += segs[t];
+      }
+      // (a lane's step is 8 bytes per row: plain id bytes ~ 8 a)
+      m.packed = (double)b < 0.95 * (double)a && 8 * a >= (int64_t)80e6 &&
+                 nnz >= 20 * c;
+    }
+  }
+  m.Wl = m.packed ? packed_slots(m.W) : m.W;
+  const bool packed = m.packed;
   std::vector<std::thread> pool;
   std::vector<int> thread_status(n_thr, 0);
   for (unsigned t = 0; t < n_thr; ++t)
@@ -830,7 +948,7 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
       try {
         for (int p = (int)t; p < m.n_panel; p += (int)n_thr)
           build_panel(R, C, rowptr, colidx, vals, m.W, m.n_block, m.PR, m.G,
-                      extra_budget, p, opt, pbs[(size_t)p]);
+                      extra_budget, p, packed, opt, pbs[(size_t)p]);
       } catch (...) {
         thread_status[t] = -1;
       }
@@ -1008,6 +1126,25 @@ inline void emu_step(const TiledHost& m, const double* xs, const Ids4& e,
   }
 }
 
+// The packed step (step_accumulate_packed in spmv_tiled.hip): the five slots of
+// row A's group and of row B's, gathered unconditionally.
+inline void emu_step_packed(const double* xs, const Ids4& e, double& a0,
+                            double& a1, double& b0, double& b1) {
+  const uint32_t w[2][2] = {{e.x, e.y}, {e.z, e.w}};
+  double* s0[2] = {&a0, &b0};
+  double* s1[2] = {&a1, &b1};
+  for (int h = 0; h < 2; ++h) {
+    const uint64_t g = (uint64_t)w[h][0] | ((uint64_t)w[h][1] << 32);
+    const uint32_t i0 = (uint32_t)(g & 0x3FFFu);
+    const uint32_t i1 = i0 + (uint32_t)((g >> 14) & 0xFFFu);
+    const uint32_t i2 = i1 + (uint32_t)((g >> 26) & 0xFFFu);
+    const uint32_t i3 = i2 + (uint32_t)((g >> 38) & 0xFFFu);
+    const uint32_t i4 = i3 + (uint32_t)((g >> 50) & 0xFFFu);
+    *s0[h] += (xs[i0] + xs[i2]) + xs[i4];
+    *s1[h] += xs[i1] + xs[i3];
+  }
+}
+
 }  // namespace
 
 void emulate_tiled_spmv(const TiledHost& m, const double* x,
@@ -1015,7 +1152,7 @@ void emulate_tiled_spmv(const TiledHost& m, const double* x,
   slab->assign((size_t)m.G * (size_t)m.R, 0.);
   const int bpg = (m.n_block + m.G - 1) / m.G;
   const int n_acc = m.PR + m.n_extra;
-  std::vector<double> xs((size_t)m.W + 8), acc((size_t)n_acc);
+  std::vector<double> xs((size_t)m.Wl + 8), acc((size_t)n_acc);
   struct WaveState {
     int64_t cursor;
     bool ended;
@@ -1046,8 +1183,14 @@ void emulate_tiled_spmv(const TiledHost& m, const double* x,
       const int64_t col0 = (int64_t)cb * m.W;
       const int cols_here =
           (int)std::max<int64_t>(0, std::min<int64_t>(m.W, m.C - col0));
-      for (int j = 0; j < m.W + 8; ++j)
-        xs[(size_t)j] = j < cols_here ? x[col0 + j] : 0.;
+      if (m.packed) {
+        std::fill(xs.begin(), xs.end(), 0.);  // zero slots included
+        for (int j = 0; j < cols_here; ++j)
+          xs[(size_t)packed_slot(j)] = x[col0 + j];
+      } else {
+        for (int j = 0; j < m.W + 8; ++j)
+          xs[(size_t)j] = j < cols_here ? x[col0 + j] : 0.;
+      }
       for (int w = 0; w < TILE_WAVES; ++w) {
         WaveState& s = ws[w];
         if (s.ended) continue;
@@ -1065,9 +1208,13 @@ void emulate_tiled_spmv(const TiledHost& m, const double* x,
             const size_t q = (size_t)d.quad0 + (size_t)u;
             for (int l = 0; l < LANES; ++l) {
               const size_t at = q * LANES + (size_t)l;
-              emu_step(m, xs.data(), m.ids[at],
-                       m.has_vals ? &m.vals[at * 8] : nullptr, s.a0[l], s.a1[l],
-                       s.b0[l], s.b1[l]);
+              if (m.packed)
+                emu_step_packed(xs.data(), m.ids[at], s.a0[l], s.a1[l], s.b0[l],
+                                s.b1[l]);
+              else
+                emu_step(m, xs.data(), m.ids[at],
+                         m.has_vals ? &m.vals[at * 8] : nullptr, s.a0[l],
+                         s.a1[l], s.b0[l], s.b1[l]);
             }
           }
           if (cnt > 0 && (d.info & BD_LAST)) {
@@ -1109,6 +1256,34 @@ double tiled_mean_gather_cycles(const TiledHost& m) {
   const int n_groups = wide ? 4 : 2, group_lanes = wide ? 16 : 32;
   const int bmask = wide ? 15 : 31;
   double cycles = 0., groups = 0.;
+  if (m.packed) {
+    // ten gathers per step (five slots of row A's group, five of row B's)
+    for (int64_t q = 0; q < m.n_quad; ++q)
+      for (int pos = 0; pos < 10; ++pos)
+        for (int grp = 0; grp < 2; ++grp) {
+          uint16_t seen[32][32];
+          int n_seen[32] = {0};
+          int worst = 1;
+          for (int i = 0; i < 32; ++i) {
+            const Ids4& e = m.ids[(size_t)q * LANES + (size_t)(grp * 32 + i)];
+            const uint64_t g = pos < 5 ? ((uint64_t)e.x | ((uint64_t)e.y << 32))
+                                       : ((uint64_t)e.z | ((uint64_t)e.w << 32));
+            uint32_t id = (uint32_t)(g & 0x3FFFu);
+            for (int k = 0; k < pos % 5; ++k)
+              id += (uint32_t)((g >> (14 + 12 * k)) & 0xFFFu);
+            const int bank = (int)(id & 31u);
+            bool dup = false;
+            for (int k = 0; k < n_seen[bank]; ++k) dup = dup || seen[bank][k] == id;
+            if (!dup) {
+              seen[bank][n_seen[bank]++] = (uint16_t)id;
+              worst = std::max(worst, n_seen[bank]);
+            }
+          }
+          cycles += worst;
+          groups += 1.;
+        }
+    return cycles / groups;
+  }
   for (int64_t q = 0; q < m.n_quad; ++q) {
     for (int pos = 0; pos < 8; ++pos)
       for (int grp = 0; grp < n_groups; ++grp) {
@@ -1145,13 +1320,14 @@ extern "C" {
 
 // out[R] = A x for the R x C CSR matrix through the tiled layout + emulator
 // (the G partial slabs are added in group order, like the epilogue kernels).
-// info[0..7] = W, n_block, PR, G, n_quad, n_slice, n_extra, split_T;
+// info[0..8] = W, n_block, PR, G, n_quad, n_slice, n_extra, split_T, packed;
+// packed: -1 = the builder's choice, 0 / 1 = plain ids / groups of five forced;
 // gather_cycles = mean LDS cycles per ds_read_b64 half-wave group (or NULL).
 int bbx_layout_emulate(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
                        const int32_t* colidx, const double* vals,
                        int bank_aware, int force_PR, int force_G,
                        int force_blocks, int max_threads, int chains,
-                       const double* x, double* out,
+                       int packed, const double* x, double* out,
                        int64_t* info, double* gather_cycles) {
   bbx::TiledOptions opt;
   opt.bank_aware = bank_aware != 0;
@@ -1160,6 +1336,7 @@ int bbx_layout_emulate(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   opt.force_blocks = force_blocks;
   opt.stats = getenv("BBX_TILED_STATS") != nullptr;
   opt.chains = chains > 0 ? chains : 1;
+  opt.packed = packed;
   if (max_threads > 0) opt.max_threads = max_threads;
   bbx::TiledHost m;
   std::string err;
@@ -1177,7 +1354,7 @@ int bbx_layout_emulate(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   if (info) {
     info[0] = m.W; info[1] = m.n_block; info[2] = m.PR; info[3] = m.G;
     info[4] = m.n_quad; info[5] = m.n_slice; info[6] = m.n_extra;
-    info[7] = m.split_T;
+    info[7] = m.split_T; info[8] = m.packed ? 1 : 0;
   }
   if (gather_cycles) *gather_cycles = bbx::tiled_mean_gather_cycles(m);
   return 0;

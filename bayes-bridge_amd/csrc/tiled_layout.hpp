@@ -44,6 +44,22 @@ struct Ids4 {
 };
 static_assert(sizeof(Ids4) == 16, "one 16-byte lane load");
 
+// Packed value-free steps (one right-hand side; TiledHost::packed).  The 16
+// bytes of a lane and step hold one GROUP per row -- x | y << 32 for row A,
+// z | w << 32 for row B -- instead of four 16-bit ids per row: bits 0-13 the
+// slice slot of the group's first entry, then four 12-bit forward deltas, five
+// entries in eight bytes.  The kernel always gathers all five slots
+// (s_{k+1} = s_k + d_k): there is no "absent" marker to test.  Instead the
+// slice in LDS carries ZERO SLOTS -- one after every 4095 columns (slots 4095,
+// 8191, ...) and one behind the last column -- so that from every column's slot
+// a zero slot lies at most 4095 slots ahead: a group with fewer than five
+// entries steps onto the next zero slot and stays there (delta 0), adding 0.0.
+// A delta of 0 between entries is a duplicate column (counted twice, as CSR
+// semantics demand); entries more than 4095 slots apart start a new group.
+constexpr int PACK_PERIOD = 4095;  // columns between two zero slots
+inline int packed_slot(int j) { return j + j / PACK_PERIOD; }   // column -> slot
+inline int packed_slots(int W) { return W + (W - 1) / PACK_PERIOD; }  // = terminal zero slot
+
 // Set-up only (the kernel derives the column block arithmetically).
 struct TileDesc {
   int32_t col_block;
@@ -54,7 +70,7 @@ struct TileDesc {
 
 struct SliceMeta {
   uint32_t first_quad;  // offset into the id stream in units of 64 x 16 bytes
-  uint32_t n_quad;      // steps: 4 entries of row A + 4 of row B per lane
+  uint32_t n_quad;      // steps: 4 entries (packed: one group) of row A + of row B per lane
 };
 
 // One step of a wave's precomputed schedule: BATCH consecutive quads of one
@@ -87,6 +103,9 @@ struct TiledOptions {
   int extra_budget = -1;     // extra accumulators per panel (< 0: what LDS leaves)
   double t_factor = 0.;      // split threshold / mean segment (0: automatic)
   bool bank_aware = true;    // bank-aware entry order inside the rows
+  // value-free ids of a single right-hand side as groups of five (see
+  // packed_slot): -1 = whichever form stores fewer steps, 0 / 1 = forced
+  int packed = -1;
   bool stats = false;        // BBX_TILED_STATS=1
   int max_threads = 64;
   // transpose: the X^T orientation reads BBX_TILED_PR_T / BBX_TILED_G_T first
@@ -99,6 +118,8 @@ struct TiledHost {
   int W = 0, n_block = 0, PR = 0, n_panel = 0, G = 0;
   int K = 1;  // right-hand sides the geometry was sized for (TiledOptions::chains)
   bool has_vals = false;
+  bool packed = false;  // steps hold one 5-entry group per row (packed_slot)
+  int Wl = 0;           // slots of one vector slice in LDS: W, or packed_slots(W)
   int64_t n_slice = 0, n_quad = 0, n_tile = 0, n_desc = 0;
   int desc_stride = 0;  // > 0: wave k's schedule starts at k * desc_stride
   int n_extra = 0;      // extra accumulators per panel (row splitting)
@@ -113,7 +134,7 @@ struct TiledHost {
   std::string stats;                // filled when TiledOptions::stats
   double model_cost_us = 0.;        // the geometry search's estimate of one product
   int64_t lds_doubles() const {
-    return (int64_t)K * ((int64_t)W + 8 + PR + n_extra);
+    return (int64_t)K * ((int64_t)Wl + 8 + PR + n_extra);
   }
 };
 

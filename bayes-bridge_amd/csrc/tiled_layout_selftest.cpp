@@ -22,7 +22,7 @@ struct Lcg {
 };
 
 int run_case(int64_t R, int64_t C, double density, bool binary,
-             int force_PR, int force_G, uint64_t seed) {
+             int force_PR, int force_G, uint64_t seed, int packed = -1) {
   Lcg g{seed};
   std::vector<int32_t> rowptr((size_t)R + 1, 0), colidx;
   std::vector<double> vals;
@@ -53,6 +53,7 @@ int run_case(int64_t R, int64_t C, double density, bool binary,
   opt.force_PR = force_PR;
   opt.force_G = force_G;
   opt.max_threads = 4;
+  opt.packed = packed;
   bbx::TiledHost m;
   std::string err;
   if (colidx.empty()) colidx.push_back(0);
@@ -70,10 +71,10 @@ int run_case(int64_t R, int64_t C, double density, bool binary,
     worst = std::fmax(worst, std::fabs(a - ref[(size_t)r]));
   }
   const double cyc = bbx::tiled_mean_gather_cycles(m);
-  printf("R=%lld C=%lld nnz=%lld %s PR=%d G=%d W=%d blocks=%d extras=%d: "
+  printf("R=%lld C=%lld nnz=%lld %s%s PR=%d G=%d W=%d blocks=%d extras=%d: "
          "max err %.2e, %.2f LDS cycles per gather\n",
          (long long)R, (long long)C, (long long)nnz, binary ? "binary" : "valued",
-         m.PR, m.G, m.W, m.n_block, m.n_extra, worst, cyc);
+         m.packed ? " packed" : "", m.PR, m.G, m.W, m.n_block, m.n_extra, worst, cyc);
   return worst <= 1e-10 ? 0 : 1;
 }
 
@@ -88,6 +89,12 @@ int main() {
   bad += run_case(5000, 17000, .004, false, 512, 2, 5);
   bad += run_case(17, 3, .6, true, 0, 0, 6);
   bad += run_case(1, 70000, .001, true, 0, 0, 7);
+  // packed groups forced on and off (the builder picks by step count)
+  bad += run_case(3000, 900, .05, true, 0, 0, 1, 1);
+  bad += run_case(3000, 900, .05, true, 0, 0, 1, 0);
+  bad += run_case(700, 40000, .002, true, 128, 2, 3, 1);
+  bad += run_case(900, 33000, .0004, true, 0, 0, 8, 1);  // gaps beyond 4095 slots
+  bad += run_case(1, 70000, .001, true, 0, 0, 7, 1);
   if (bad) fprintf(stderr, "%d case(s) FAILED\n", bad);
   return bad ? 1 : 0;
 }

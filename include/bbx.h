@@ -197,11 +197,13 @@ int bbx_design_hybrid_info(const bbx_design* h, int* is_hybrid,
                            int64_t* dense_nnz, int* dense_cols);
 /* Geometry of the tiled format (BBX_FORMAT_TILED only): which = 0 for X, 1 for
  * X^T; W = column-block width, n_block = column blocks, PR = rows per panel,
- * G = column-block groups (partial-sum slabs), n_quad = 512-byte id groups
- * (4 entries x 64 lanes), n_slice = 64-row slices. */
+ * G = column-block groups (partial-sum slabs), n_quad = 1024-byte steps (16
+ * bytes x 64 lanes: per lane four 16-bit ids, or -- *packed = 1, value-free
+ * designs -- one group of up to five entries, for each of its two rows),
+ * n_slice = 128-row slices.  Any output pointer may be NULL. */
 int bbx_design_tiled_info(const bbx_design* h, int which, int* W,
                           int* n_block, int* PR, int* G, int64_t* n_quad,
-                          int64_t* n_slice);
+                          int64_t* n_slice, int* packed);
 
 /*
  * out[n] = X~ v,  v[P].  Replaces SparseDesignMatrix.dot / main_dot

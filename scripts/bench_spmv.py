@@ -1,5 +1,5 @@
 """Times the operator kernels alone (HIP events) on synthetic binary designs.
-Usage: python scripts/bench_spmv.py [config2|config3] [csr|tiled] [reps]"""
+Usage: python scripts/bench_spmv.py [config2|config3|NxPxF] [csr|tiled] [reps]"""
 import os
 import sys
 import time
@@ -18,12 +18,17 @@ from ctypes import c_void_p
 cfg = sys.argv[1] if len(sys.argv) > 1 else "config2"
 storage = sys.argv[2] if len(sys.argv) > 2 else "csr"
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-n, p, f = {"config2": (100000, 10000, .01),
+shapes = {"config2": (100000, 10000, .01),
            "config3": (1000000, 50000, .002),
            # same tiles as config3, twice as many per workgroup (marginal
            # cost of a tile vs per-launch fixed cost)
            "wide": (1000000, 100000, .002),
-           "tall": (2000000, 50000, .002)}[cfg]
+           "tall": (2000000, 50000, .002)}
+if cfg in shapes:
+    n, p, f = shapes[cfg]
+else:                       # e.g. 400000x20000x0.005
+    n, p, f = cfg.split("x")
+    n, p, f = int(n), int(p), float(f)
 t0 = time.time()
 indptr, indices = simulate.simulate_binary_csr_device(n, p, f, seed=111)
 torch.cuda.synchronize()

@@ -8,6 +8,8 @@ centring, non-binary values, skewed column counts.
 
 Tolerance: the reference's own bound is 1e-5; the oracle comparison uses
 |diff| <= 1e-11 * scale (f64 sums in a different order)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sparse
@@ -428,25 +430,41 @@ def test_kernel_equals_cpu_emulator_bitwise(shape):
     layout = TiledLayoutCpu()
     X = simulate.simulate_binary_csr_fast(n, p, f, seed=11)
     rng = np.random.default_rng(3)
-    for binary in (True, False):
+    # value-free ids: the builder's choice between four 16-bit ids and a group
+    # of five per eight bytes (tiled_layout.hpp packed_slot), and each forced
+    # (BBX_TILED_PACK is the builder's diagnostic override)
+    for binary, pack in ((True, -1), (True, 0), (True, 1), (False, -1)):
         A = X.copy()
         if not binary:
             A.data = rng.standard_normal(A.nnz)
         At = A.T.tocsr()
         At.sort_indices()
-        hip = HipSparseDesignMatrix(A.copy(), center_predictor=False,
-                                    add_intercept=False, storage='tiled')
+        old = os.environ.pop('BBX_TILED_PACK', None)
+        if pack >= 0:
+            os.environ['BBX_TILED_PACK'] = str(pack)
+        try:
+            hip = HipSparseDesignMatrix(A.copy(), center_predictor=False,
+                                        add_intercept=False, storage='tiled')
+        finally:
+            os.environ.pop('BBX_TILED_PACK', None)
+            if old is not None:
+                os.environ['BBX_TILED_PACK'] = old
         v, w = rng.standard_normal(p), rng.standard_normal(n)
-        emu_v, info_x = layout.matvec(A, v)
-        emu_w, info_t = layout.matvec(At, w)
+        emu_v, info_x = layout.matvec(A, v, packed=pack)
+        emu_w, info_t = layout.matvec(At, w, packed=pack)
         geo = hip.tiled_info()
         for side, info in (('X', info_x), ('Xt', info_t)):
-            for key in ('W', 'n_block', 'PR', 'G', 'n_quad', 'n_slice'):
+            for key in ('W', 'n_block', 'PR', 'G', 'n_quad', 'n_slice',
+                        'packed'):
                 assert geo[side][key] == info[key], (side, key)
+            if pack >= 0:
+                assert geo[side]['packed'] == (binary and pack == 1)
+            if not binary:
+                assert not geo[side]['packed']
         got_v, got_w = hip.dot(v), hip.Tdot(w)
         if binary:
-            assert np.array_equal(got_v, emu_v)
-            assert np.array_equal(got_w, emu_w)
+            assert np.array_equal(got_v, emu_v), pack
+            assert np.array_equal(got_w, emu_w), pack
         else:
             assert np.abs(got_v - emu_v).max() <= 1e-13 * np.abs(emu_v).max()
             assert np.abs(got_w - emu_w).max() <= 1e-13 * np.abs(emu_w).max()

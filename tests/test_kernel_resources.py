@@ -37,12 +37,15 @@ def _resource_table(src, tmp_path):
     return table
 
 
-# (VALS, WIDE, KP, FOLD, DENSEP) of every tiled_spmv_kernel instantiation
-TILED_INSTANCES = [("0", "0", "0", "0", "0"), ("0", "1", "0", "0", "0"),
-                   ("1", "0", "0", "0", "0"), ("1", "1", "0", "0", "0"),
-                   ("0", "1", "1", "0", "0"), ("0", "1", "2", "0", "0"),
-                   ("1", "1", "1", "0", "0"), ("0", "1", "0", "1", "0"),
-                   ("0", "1", "0", "0", "1")]
+# (VALS, WIDE, KP, FOLD, DENSEP, PACK) of every tiled_spmv_kernel instantiation
+TILED_INSTANCES = [("0", "0", "0", "0", "0", "0"), ("0", "1", "0", "0", "0", "0"),
+                   ("1", "0", "0", "0", "0", "0"), ("1", "1", "0", "0", "0", "0"),
+                   ("0", "1", "1", "0", "0", "0"), ("0", "1", "2", "0", "0", "0"),
+                   ("1", "1", "1", "0", "0", "0"), ("0", "1", "0", "1", "0", "0"),
+                   ("0", "1", "0", "0", "1", "0"),
+                   # value-free, one right-hand side, ids in groups of five
+                   ("0", "0", "0", "0", "0", "1"), ("0", "1", "0", "0", "0", "1"),
+                   ("0", "1", "0", "1", "0", "1"), ("0", "1", "0", "0", "1", "1")]
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
@@ -52,13 +55,15 @@ def test_tiled_kernels_do_not_spill(tmp_path):
         tmp_path)
     tiled = {k: v for k, v in table.items() if "tiled_spmv_kernel" in k}
     # exactly the instantiations build_tiled sets attributes on:
-    # (VALS, WIDE, KP, FOLD, DENSEP) -- value-free and valued, 8- and 16-byte
-    # slice refills, the K-column ones (KP = 1: two chains, KP = 2: four), the
-    # one that carries the CG direction step and the one with a mixed design's
-    # dense block in its epilogue; several sit at the 128-VGPR budget: a
-    # dropped or renamed one must be noticed
+    # (VALS, WIDE, KP, FOLD, DENSEP, PACK) -- value-free and valued, 8- and
+    # 16-byte slice refills, the K-column ones (KP = 1: two chains, KP = 2:
+    # four), the one that carries the CG direction step, the one with a mixed
+    # design's dense block in its epilogue, and the value-free single-chain
+    # ones again for ids packed in groups of five; several sit at the 128-VGPR
+    # budget: a dropped or renamed one must be noticed
     got = sorted(re.search(
-        r"tiled_spmv_kernelILb(\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)E", k).groups()
+        r"tiled_spmv_kernelILb(\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)ELb(\d)E",
+        k).groups()
         for k in tiled)
     assert got == sorted(TILED_INSTANCES), got
     for name, res in tiled.items():

@@ -31,22 +31,43 @@ def test_layout_emulation_equals_scipy(layout, case):
     ref_v, ref_w = X @ v, Xt @ w
     tol_v = 1e-11 * max(1., np.abs(ref_v).max())
     tol_w = 1e-11 * max(1., np.abs(ref_w).max())
-    variants = [dict(), dict(bank_aware=False)]
+    # packed: value-free ids as groups of five (tiled_layout.hpp packed_slot)
+    # forced on / off; left alone the builder takes the form with fewer steps
+    variants = [dict(), dict(bank_aware=False), dict(packed=1), dict(packed=0)]
     if case % 4 == 0:
         variants.append(dict(force_PR=128, force_G=2, threads=3))
     # geometries sized for 2 and 4 right-hand sides sharing the pass (batched
     # chains): narrower slices, shorter panels, same sums per right-hand side
     variants += [dict(chains=2), dict(chains=4)]
+    quads = {}
+    value_free = bool(np.all(X.data == 1.))    # what the builder is handed
     for kw in variants:
         out_v, info_v = layout.matvec(X, v, **kw)
         out_w, info_w = layout.matvec(Xt, w, **kw)
         assert np.abs(out_v - ref_v).max() <= tol_v, (kw, info_v)
         assert np.abs(out_w - ref_w).max() <= tol_w, (kw, info_w)
+        if set(kw) <= {'packed'}:
+            quads[kw.get('packed', -1)] = (info_v, info_w)
+        # groups only for value-free single-chain layouts, and only if asked
+        for info in (info_v, info_w):
+            assert info['packed'] in (0, 1)
+            if not value_free or kw.get('chains', 1) > 1 or kw.get('packed') == 0:
+                assert info['packed'] == 0, (kw, info)
+            if value_free and kw.get('packed') == 1:
+                assert info['packed'] == 1, (kw, info)
         # every layout fits the CU's LDS next to 2 KB of static use
         for info in (info_v, info_w):
             lds = 8 * kw.get('chains', 1) * (info['W'] + 8 + info['PR']
                                              + info['n_extra'])
             assert lds <= 160 * 1024 - 2048 + 8 * 8, info
+    # the builder's own choice: groups only where the id stream is large
+    # (>= 80 MB of plain ids: tests/test_hip_fullsize.py sees it at 1M x 50k),
+    # never for matrices of this size
+    for k in range(2):
+        auto, plain, grouped = quads[-1][k], quads[0][k], quads[1][k]
+        assert not auto['packed'] and auto['n_quad'] == plain['n_quad']
+        if value_free:
+            assert grouped['n_quad'] <= plain['n_quad'] + plain['n_slice']
     # binary designs: the emulator adds whole numbers exactly
     if binary and np.all(v == np.round(v)):
         assert np.array_equal(out_v, ref_v)
@@ -63,7 +84,8 @@ def test_integer_vectors_give_exact_sums(layout):
     Xt = X.T.tocsr()
     Xt.sort_indices()
     for kw in (dict(), dict(force_PR=256, force_G=2), dict(chains=2),
-               dict(chains=4)):
+               dict(chains=4), dict(packed=1), dict(packed=0),
+               dict(packed=1, force_PR=256, force_G=2)):
         assert np.array_equal(layout.matvec(X, v, **kw)[0], X @ v)
         assert np.array_equal(layout.matvec(Xt, w, **kw)[0], Xt @ w)
 
@@ -80,8 +102,10 @@ def test_bank_aware_order_lowers_lds_conflicts(layout):
     rng = np.random.default_rng(2)
     for A in (X, Xt):
         x = rng.standard_normal(A.shape[1])
-        plain, ip = layout.matvec(A, x, bank_aware=False, force_PR=4096)
-        tuned, it = layout.matvec(A, x, bank_aware=True, force_PR=4096)
+        plain, ip = layout.matvec(A, x, bank_aware=False, force_PR=4096,
+                                  packed=0)
+        tuned, it = layout.matvec(A, x, bank_aware=True, force_PR=4096,
+                                  packed=0)
         assert np.abs(plain - tuned).max() <= 1e-12 * np.abs(plain).max()
         assert ip['n_quad'] == it['n_quad']          # not a byte more
         assert ip['gather_cycles'] > 2.5
