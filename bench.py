@@ -677,6 +677,12 @@ def main():
                 "launch_grids": {k: v["grid"] for k, v in
                                  design.tiled_info().items()}
                 if design.storage_format == "tiled" else None,
+                # how the value-free ids are stored: four 16-bit ids or one
+                # group of five entries per eight bytes
+                "id_format": {k: ("groups of 5 / 8 B" if v["packed"]
+                                  else "4 ids / 8 B") for k, v in
+                              design.tiled_info().items()}
+                if design.storage_format == "tiled" else None,
                 "init": "coef=0 + intercept MLE, global_scale=.01, then %d "
                         "untimed burn-in iterations (in place of the "
                         "reference's L-BFGS mode search)" % B,
