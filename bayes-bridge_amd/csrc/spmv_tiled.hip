@@ -53,6 +53,12 @@
 // fine-grained wins by a little.  Measured at 1M x 50k, X v / X^T w in us:
 // 4x2: 48.6 / 50.8   3x2: 47.6 / 50.0   4x1: 46.8 / 49.5   3x1: 46.7 / 49.3
 // 2x1: 46.7 / 49.7   6x1: 47.4 / 50.1   (100k x 10k Gibbs: 4x2 614, 3x1 675 it/s)
+// Value-free single-chain steps re-arm their ring slot between the LDS gathers
+// and the additions (the ids are dead once the addresses exist): X~ v 43.4 ->
+// 42.7 us, X~^T w 45.8 -> 45.5 us at 1M x 50k; 0 restores gather, add, re-arm.
+#ifndef BBX_EARLY_ISSUE
+#define BBX_EARLY_ISSUE 1
+#endif
 #ifndef BBX_RING_BIN
 #define BBX_RING_BIN 3
 #endif
@@ -202,6 +208,22 @@ __device__ __forceinline__ void packed_group(unsigned xs_addr, unsigned lo,
   const unsigned o4 = lshl3_add(hi >> 18, o3);  // bits 62-63 of a group are 0
   s0 += (lds_read(o0) + lds_read(o2)) + lds_read(o4);
   s1 += lds_read(o1) + lds_read(o3);
+}
+// The five slots of a group, gathered but not yet added (the caller issues the
+// slot's next stream load between the gathers and the additions).
+__device__ __forceinline__ void packed_gather(unsigned xs_addr, unsigned lo,
+                                              unsigned hi, double* g) {
+  const unsigned o0 = lshl3_add(lo & 0x3FFFu, xs_addr);
+  const unsigned o1 = lshl3_add(__builtin_amdgcn_ubfe(lo, 14, 12), o0);
+  const unsigned o2 =
+      lshl3_add(__builtin_amdgcn_alignbit(hi, lo, 26) & 0xFFFu, o1);
+  const unsigned o3 = lshl3_add(__builtin_amdgcn_ubfe(hi, 6, 12), o2);
+  const unsigned o4 = lshl3_add(hi >> 18, o3);
+  g[0] = lds_read(o0);
+  g[1] = lds_read(o1);
+  g[2] = lds_read(o2);
+  g[3] = lds_read(o3);
+  g[4] = lds_read(o4);
 }
 __device__ __forceinline__ void step_accumulate_packed(
     unsigned xs_addr, v4u e, double& a0, double& a1, double& b0, double& b1) {
@@ -663,6 +685,55 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
             if (dbg) t_switch += (unsigned)__builtin_amdgcn_s_memtime() - t_sw0;
           }
           const int cntk = (int)(inf & 15u);
+          bool issued = false;
+          if constexpr (!PACK && !VALS && KP == 0 && BATCH == 1 && BBX_EARLY_ISSUE) {
+            if (cntk > 0) {
+              // (plain ids: the same order -- gathers, re-arm, additions)
+              BBX_WAIT(k);
+              const v4u ee = e[k][0];
+              const double g0 = xs[ee.x & 0xFFFFu], g1 = xs[ee.y & 0xFFFFu];
+              const double g2 = xs[ee.x >> 16], g3 = xs[ee.y >> 16];
+              const double g4 = xs[ee.z & 0xFFFFu], g5 = xs[ee.w & 0xFFFFu];
+              const double g6 = xs[ee.z >> 16], g7 = xs[ee.w >> 16];
+              const unsigned rr = rid[k];
+              BBX_ISSUE(k);
+              issued = true;
+              a0 += g0 + g1;
+              a1 += g2 + g3;
+              b0 += g4 + g5;
+              b1 += g6 + g7;
+              if (inf & BD_LAST) {
+                const unsigned ra = rr & 0xFFFFu, rb = rr >> 16;
+                if (ra != NO_ROW) acc[ra] += a0 + a1;
+                if (rb != NO_ROW) acc[rb] += b0 + b1;
+                a0 = a1 = b0 = b1 = 0.;
+              }
+            }
+          } else
+          if constexpr (PACK && BATCH == 1 && BBX_EARLY_ISSUE) {
+            if (cntk > 0) {
+              // decode, gather, then re-arm the slot BEFORE the additions: the
+              // ids are dead once the addresses exist, and the next stream
+              // load need not wait for the LDS round trip
+              BBX_WAIT(k);
+              double ga[5], gb[5];
+              packed_gather(xs_addr, e[k][0].x, e[k][0].y, ga);
+              packed_gather(xs_addr, e[k][0].z, e[k][0].w, gb);
+              const unsigned rr = rid[k];
+              BBX_ISSUE(k);
+              issued = true;
+              a0 += (ga[0] + ga[2]) + ga[4];
+              a1 += ga[1] + ga[3];
+              b0 += (gb[0] + gb[2]) + gb[4];
+              b1 += gb[1] + gb[3];
+              if (inf & BD_LAST) {
+                const unsigned ra = rr & 0xFFFFu, rb = rr >> 16;
+                if (ra != NO_ROW) acc[ra] += a0 + a1;
+                if (rb != NO_ROW) acc[rb] += b0 + b1;
+                a0 = a1 = b0 = b1 = 0.;
+              }
+            }
+          } else
           if (cntk > 0) {
             BBX_WAIT(k);
 #pragma unroll
@@ -698,7 +769,7 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
               }
             }
           }
-          BBX_ISSUE(k);
+          if (!issued) BBX_ISSUE(k);
         }
       }
     }

@@ -146,19 +146,20 @@ if line and line["config"].get("launch_grids"):
     want = {
         "dot (X~ v inside the CG loop%s)" % (", direction step folded in"
                                              if fold else ""):
-            (["tiled_spmv_kernel<false, true, 0, %s>" % ("true" if fold
-                                                          else "false")],
+            # (VALS, WIDE, KP, FOLD, DENSEP, PACK: either id format)
+            (["tiled_spmv_kernel<false, true, 0, %s, false" % ("true" if fold
+                                                                else "false")],
              grids["X"], other["dot"]["bytes"]),
         "tdot (X~^T w main kernel)":
-            (["tiled_spmv_kernel<false, true, 0, false>"], grids["Xt"],
+            (["tiled_spmv_kernel<false, true, 0, false, false"], grids["Xt"],
              other["tdot"]["bytes"]),
     }
     mc = (plain or line).get("multi_chain") or {}
     k2 = mc.get("k=2") or {}
     if k2.get("launch_grids"):
-        want["dot, K = 2 batch"] = (["tiled_spmv_kernel<false, true, 1, false>"],
+        want["dot, K = 2 batch"] = (["tiled_spmv_kernel<false, true, 1, false"],
                                     k2["launch_grids"]["X"], k2["dot"]["bytes"])
-        want["tdot, K = 2 batch"] = (["tiled_spmv_kernel<false, true, 1, false>"],
+        want["tdot, K = 2 batch"] = (["tiled_spmv_kernel<false, true, 1, false"],
                                      k2["launch_grids"]["Xt"], k2["tdot"]["bytes"])
     for label, (must, grid, nbytes) in want.items():
         key, tr = find(trace, must, grid)
@@ -184,11 +185,11 @@ out = dict(tag=tag, kernel_trace=trace, pmc=counters, hbm_traffic=traffic,
                "; the X~ v kernel inside the CG loop also reads the row scale "
                "Omega (8 n = 8.0 MB at n = 1e6), which `algorithmic_bytes` "
                "(format bytes + vector in + vector out, bbx_design_timed_bytes) "
-               "does not count: 246.4 MB measured / (234.7 + 8.0) MB = 1.015; "
+               "does not count; "
                "bench.iteration_bytes credits Omega separately")
 # bench.py's `traffic` lookup (committed_traffic) reads hbm_traffic["grid=N"]
-for marker in ("tiled_spmv_kernel<false, true, 0, false>",
-               "tiled_spmv_kernel<false, true, 0, true>"):
+for marker in ("tiled_spmv_kernel<false, true, 0, false, false",
+               "tiled_spmv_kernel<false, true, 0, true, false"):
     for key, val in list(traffic.items()):
         if marker in key:
             out["hbm_traffic"].setdefault(key.split(" ")[-1], val)
