@@ -16,7 +16,9 @@
 //     lane), stored "sliced ELL": [step q][lane][row A: 4 ids | row B: 4 ids]
 //     block-local uint16 column ids = one 16-byte load per lane and step
 //     (8-byte loads reach only ~0.6x the HBM rate of 16-byte ones), padded to
-//     a multiple of 4 entries with an id that points at a 0.0 in LDS;
+//     a multiple of 4 entries with an id that points at a 0.0 in LDS; large
+//     value-free layouts store GROUPS of five entries per row and step instead
+//     (a 14-bit slot and four 12-bit deltas: tiled_layout.hpp, packed_slot);
 //   * a row whose segment in some tile is much longer than the others' (the
 //     column counts of simulate_data.py designs are heavy-tailed) is split into
 //     chunks of <= T entries that sort next to rows of that length; every
@@ -29,7 +31,8 @@
 // One workgroup (1024 threads, 16 waves, one per CU) owns a row panel and a
 // group of column blocks: it fills the vector slice, streams the tile's ids
 // with coalesced 1 KiB wave loads (the only HBM traffic that scales with
-// nnz: 2 bytes per entry), adds lane-private sums into LDS accumulators, and
+// nnz: 2 bytes per entry, 1.6 in groups), adds lane-private sums into LDS
+// accumulators, and
 // writes the panel once.  No atomics: every sum has a fixed order.
 #include <algorithm>
 #include <cstdio>
@@ -209,6 +212,19 @@ __device__ __forceinline__ void packed_group(unsigned xs_addr, unsigned lo,
   s0 += (lds_read(o0) + lds_read(o2)) + lds_read(o4);
   s1 += lds_read(o1) + lds_read(o3);
 }
+// Row ids of a ring slot, split BEFORE the slot is re-armed.  As asm volatile
+// statements these stay between the slot's wait and its next load; a plain
+// `rr = rid[k]` kept across the re-arm makes the register allocator copy the
+// (tied) wait operand -- a register with a load still in flight -- in front of
+// the wait: stale row ids, sums flushed into the wrong accumulators (seen:
+// v_mov_b32 v38, v54 one instruction above s_waitcnt vmcnt(4)).
+__device__ __forceinline__ void split_row_ids(unsigned rr, unsigned& ra,
+                                              unsigned& rb) {
+  asm volatile("v_and_b32 %0, 0xffff, %2\n\tv_lshrrev_b32 %1, 16, %2"
+               : "=&v"(ra), "=v"(rb)
+               : "v"(rr));
+}
+
 // The five slots of a group, gathered but not yet added (the caller issues the
 // slot's next stream load between the gathers and the additions).
 __device__ __forceinline__ void packed_gather(unsigned xs_addr, unsigned lo,
@@ -695,7 +711,8 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
               const double g2 = xs[ee.x >> 16], g3 = xs[ee.y >> 16];
               const double g4 = xs[ee.z & 0xFFFFu], g5 = xs[ee.w & 0xFFFFu];
               const double g6 = xs[ee.z >> 16], g7 = xs[ee.w >> 16];
-              const unsigned rr = rid[k];
+              unsigned ra, rb;
+              split_row_ids(rid[k], ra, rb);
               BBX_ISSUE(k);
               issued = true;
               a0 += g0 + g1;
@@ -703,7 +720,6 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
               b0 += g4 + g5;
               b1 += g6 + g7;
               if (inf & BD_LAST) {
-                const unsigned ra = rr & 0xFFFFu, rb = rr >> 16;
                 if (ra != NO_ROW) acc[ra] += a0 + a1;
                 if (rb != NO_ROW) acc[rb] += b0 + b1;
                 a0 = a1 = b0 = b1 = 0.;
@@ -719,7 +735,8 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
               double ga[5], gb[5];
               packed_gather(xs_addr, e[k][0].x, e[k][0].y, ga);
               packed_gather(xs_addr, e[k][0].z, e[k][0].w, gb);
-              const unsigned rr = rid[k];
+              unsigned ra, rb;
+              split_row_ids(rid[k], ra, rb);
               BBX_ISSUE(k);
               issued = true;
               a0 += (ga[0] + ga[2]) + ga[4];
@@ -727,7 +744,6 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
               b0 += (gb[0] + gb[2]) + gb[4];
               b1 += gb[1] + gb[3];
               if (inf & BD_LAST) {
-                const unsigned ra = rr & 0xFFFFu, rb = rr >> 16;
                 if (ra != NO_ROW) acc[ra] += a0 + a1;
                 if (rb != NO_ROW) acc[rb] += b0 + b1;
                 a0 = a1 = b0 = b1 = 0.;

@@ -650,6 +650,49 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
                                bank_scratch, pp, nb);
           }
       }
+      if (packed && opt.bank_aware) {
+        // Groups ascend inside, but WHICH group a row presents at step q is
+        // free (it only fixes the order of the additions).  Per 32-lane half
+        // and row side, step by step: every lane takes, among the groups it has
+        // not placed yet, the one whose five slots fall into the LDS banks the
+        // lanes before it have loaded least at their positions.
+        for (int side = 0; side < 2; ++side)
+          for (int half32 = 0; half32 < 2; ++half32) {
+            int occ[5][32];
+            for (uint32_t q = 0; q < nq; ++q) {
+              memset(occ, 0, sizeof(occ));
+              for (int i = 0; i < 32; ++i) {
+                const int idx = base + side * LANES + half32 * 32 + i;
+                if (idx >= base + rows_in || idx >= n_rows) break;
+                const VRow& v = sorted[idx];
+                if ((int)q >= v.steps) continue;
+                uint64_t* gr = &groups[(size_t)v.g_begin];
+                int best = (int)q, best_cost = 1 << 30;
+                for (int c = (int)q; c < v.steps; ++c) {
+                  const uint64_t g = gr[c];
+                  uint32_t sl = (uint32_t)(g & 0x3FFFu);
+                  int cost = occ[0][sl & 31];
+                  for (int u = 1; u < 5; ++u) {
+                    sl += (uint32_t)((g >> (14 + 12 * (u - 1))) & 0xFFFu);
+                    cost += occ[u][sl & 31];
+                  }
+                  if (cost < best_cost) {
+                    best_cost = cost;
+                    best = c;
+                  }
+                }
+                std::swap(gr[q], gr[best]);
+                const uint64_t g = gr[q];
+                uint32_t sl = (uint32_t)(g & 0x3FFFu);
+                occ[0][sl & 31] += 1;
+                for (int u = 1; u < 5; ++u) {
+                  sl += (uint32_t)((g >> (14 + 12 * (u - 1))) & 0xFFFu);
+                  occ[u][sl & 31] += 1;
+                }
+              }
+            }
+          }
+      }
       for (int l = 0; l < LANES; ++l) {
         // lane l owns sorted rows base + l (A) and base + 64 + l (B)
         const VRow* vr[2] = {nullptr, nullptr};

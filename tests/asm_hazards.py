@@ -342,3 +342,35 @@ def check_rings(dis, only=None, strict=True):
         n += sum(1 for ins in code if vmem_load_dest(ins))
         bad += check_inflight(code, name, strict)
     return bad, n
+
+
+# Rule C': copies.  The lenient form of rule C accepts a touch that is also
+# reachable behind a covering wait, which let this one through in round 4: a
+# row-id value kept live across its ring slot's re-issue made the register
+# allocator copy the slot's wait operand (tied in/out) in front of the wait --
+# `v_mov_b32 v38, v54` one instruction above `s_waitcnt vmcnt(4)`, v54 still
+# the destination of a load in flight: stale row ids, CG iteration counts x 2.5.
+# A COPY of a ring register is never one of the kernel's own consumers (those
+# are the decode operations behind the wait), so every copy-like instruction
+# that the strict, path-insensitive walk reaches without a covering wait is
+# reported: no such instruction exists in a correct build, on any path.
+_COPY_LIKE = ("v_mov_b32", "v_mov_b64", "v_pk_mov_b32", "v_swap_b32",
+              "v_accvgpr_write_b32", "v_writelane_b32", "scratch_store",
+              "buffer_store")
+
+
+def check_ring_copies(dis, only=None):
+    """(violations, loads looked at): copy-like instructions reading the
+    destination of an in-flight load, reached without a covering wait."""
+    bad, n = check_rings(dis, only, strict=True)
+    seen, out = set(), []
+    for b in bad:
+        lines = b.split("\n")
+        touch = lines[-1].strip()
+        if not touch.startswith(_COPY_LIKE):
+            continue
+        key = (lines[0].split(":")[0], touch)
+        if key not in seen:
+            seen.add(key)
+            out.append(b)
+    return out, n

@@ -25,3 +25,12 @@ __global__ void ring_register_touched_in_flight(const unsigned* p, unsigned* out
   asm volatile("global_load_dword %0, %1, %2" : "=v"(x) : "v"(off), "s"(p) : "memory");
   out[threadIdx.x] = x + 1u;
 }
+// the round-4 bug: a value kept live across the slot's re-issue makes the
+// register allocator copy the tied wait operand IN FRONT of the wait -- a
+// v_mov from a register whose load is still in flight (here spelled out)
+__global__ void ring_register_copied_before_its_wait(const unsigned* p, unsigned* out) {
+  unsigned x, y, off = 4u * threadIdx.x;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(x) : "v"(off), "s"(p) : "memory");
+  asm volatile("v_mov_b32 %0, %1\n\ts_waitcnt vmcnt(0)" : "=v"(y) : "v"(x));
+  out[threadIdx.x] = y;
+}

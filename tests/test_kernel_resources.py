@@ -167,3 +167,10 @@ def test_registers_of_asm_issued_loads_are_untouched_while_in_flight(tmp_path):
         bad, n = asm_hazards.check_rings(
             neg, "ring_register_touched_in_flight", strict=strict)
         assert n == 1 and len(bad) == 1 and "in-flight load" in bad[0]
+    # copies of ring registers (what broke the early re-arm of the tiled
+    # kernel's slots in round 4: asm_hazards.check_ring_copies)
+    bad, n = asm_hazards.check_ring_copies(dis, "tiled_spmv_kernel")
+    assert n >= len(TILED_INSTANCES) * 20 and not bad, "\n".join(bad[:6])
+    bad, n = asm_hazards.check_ring_copies(
+        neg, "ring_register_copied_before_its_wait")
+    assert n == 1 and len(bad) == 1 and "v_mov_b32" in bad[0]
