@@ -15,6 +15,7 @@ for spec in "base:" "$@"; do
   if [ -n "$flags" ]; then
     (cd $dst/pkg/csrc && rm -rf build && make -j16 ../libbbx.so \
        CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $flags" \
+       LAYOUT_DEFS="$flags" \
        > $dst/build.log 2>&1) || { echo "build of $name failed"; tail -5 $dst/build.log; continue; }
   fi
   echo "=== $name ($flags)"

@@ -468,3 +468,45 @@ def test_kernel_equals_cpu_emulator_bitwise(shape):
         else:
             assert np.abs(got_v - emu_v).max() <= 1e-13 * np.abs(emu_v).max()
             assert np.abs(got_w - emu_w).max() <= 1e-13 * np.abs(emu_w).max()
+
+
+def test_packed_groups_edge_cases_on_the_device():
+    """The rows of tests/test_tiled_layout_cpu.py::packed_edge_case_matrix --
+    columns on both sides of the LDS slice's zero slots, gaps of exactly 4095
+    and 4096 slots, duplicate column entries, groups of 1 ... 5 entries -- through
+    tiled_spmv_kernel<..., PACK> (groups forced: the builder would not choose
+    them for a matrix this small), with integer vectors: exact sums."""
+    from bayesbridge_amd import HipSparseDesignMatrix
+    from test_tiled_layout_cpu import packed_edge_case_matrix
+    A = packed_edge_case_matrix()
+    rng = np.random.default_rng(8)
+    v = rng.integers(-40, 40, A.shape[1]).astype(np.float64)
+    w = rng.integers(-40, 40, A.shape[0]).astype(np.float64)
+    old = os.environ.pop('BBX_TILED_PACK', None)
+    os.environ['BBX_TILED_PACK'] = '1'
+    try:
+        hip = HipSparseDesignMatrix(A.copy(), center_predictor=False,
+                                    add_intercept=False, storage='tiled')
+    finally:
+        os.environ.pop('BBX_TILED_PACK', None)
+        if old is not None:
+            os.environ['BBX_TILED_PACK'] = old
+    info = hip.tiled_info()
+    assert info['X']['packed'] and info['Xt']['packed']
+    assert np.array_equal(hip.dot(v), A @ v)
+    assert np.array_equal(hip.Tdot(w), A.T @ w)
+    # with intercept and centring the input of the product is v + 1 doubles
+    # into the caller's array: the 8-byte slice fill (WIDE = false)
+    os.environ['BBX_TILED_PACK'] = '1'
+    try:
+        hipc = HipSparseDesignMatrix(A.copy(), center_predictor=True,
+                                     add_intercept=True, storage='tiled')
+    finally:
+        os.environ.pop('BBX_TILED_PACK', None)
+        if old is not None:
+            os.environ['BBX_TILED_PACK'] = old
+    n, P = hipc.shape
+    v1 = rng.standard_normal(P)
+    off = np.asarray(A.mean(axis=0)).ravel()
+    ref = v1[0] + A @ v1[1:] - off @ v1[1:]
+    assert np.abs(hipc.dot(v1) - ref).max() <= 1e-11 * max(1., np.abs(ref).max())

@@ -90,6 +90,49 @@ def test_integer_vectors_give_exact_sums(layout):
         assert np.array_equal(layout.matvec(Xt, w, **kw)[0], Xt @ w)
 
 
+def packed_edge_case_matrix():
+    """Rows built to hit every rule of the packed groups (csrc/tiled_layout.hpp
+    packed_slot): columns on both sides of the zero slots (4094 | 4095, 8189 |
+    8190, ...), gaps of exactly 4095 and 4096 slots, duplicate column entries
+    (a zero delta between REAL entries: counted twice, as in SciPy), rows of 1
+    to 11 entries (groups that end on a zero slot after 1 ... 4 entries), the
+    last column of a block and of the matrix."""
+    C = 13000
+    rows = [
+        [0], [4094], [4095], [4096], [C - 1],
+        [4094, 4095, 4096], [8189, 8190, 8191, 8192],
+        [0, 4095], [0, 4096], [1, 4096, 8191],             # gaps 4095 / 4096 / ...
+        [5, 5], [7, 7, 7, 9, 9, 4095, 4095],               # duplicates
+        list(range(100, 111)), list(range(4090, 4101)),    # 11 entries, across a zero slot
+        [3, 4000, 8000, 12000, C - 1], [2, 3, 4, 5, 6, 7], [12283, 12284, 12285, 12286],
+        [],
+    ]
+    rows = rows * 9                                         # several slices
+    indptr = np.concatenate(([0], np.cumsum([len(r) for r in rows]))).astype(np.int32)
+    indices = np.array([c for r in rows for c in r], dtype=np.int32)
+    return sparse.csr_matrix((np.ones(len(indices)), indices, indptr),
+                             shape=(len(rows), C))
+
+
+def test_packed_groups_edge_cases(layout):
+    A = packed_edge_case_matrix()
+    assert not A.has_canonical_format                # the duplicates are in
+    rng = np.random.default_rng(8)
+    v = rng.integers(-40, 40, A.shape[1]).astype(np.float64)
+    ref = A @ v                                      # csr_matvec adds duplicates
+    for kw in (dict(packed=1), dict(packed=1, bank_aware=False),
+               dict(packed=1, force_PR=64), dict(packed=0)):
+        out, info = layout.matvec(A, v, **kw)
+        assert info['packed'] == kw['packed'] and info['W'] > 12285
+        assert np.array_equal(out, ref), kw
+    # the transposed orientation: 162 columns, rows of 0 ... 27 entries
+    At = sparse.csr_matrix(A.T)
+    At.sort_indices()
+    w = rng.integers(-40, 40, A.shape[0]).astype(np.float64)
+    out, info = layout.matvec(At, w, packed=1)
+    assert info['packed'] == 1 and np.array_equal(out, At @ w)
+
+
 def test_bank_aware_order_lowers_lds_conflicts(layout):
     """The builder's entry order inside rows: fewer LDS cycles per gather
     (1.0 = conflict free; ascending ids give ~3.4) and the same sums."""
