@@ -197,11 +197,12 @@ __device__ __forceinline__ unsigned lds_address(const double* p) {
 __device__ __forceinline__ double lds_read(unsigned addr) {
   return *(lds_cdouble*)(uintptr_t)addr;
 }
-// xs_addr = lds_address(xs): the slice's LDS byte address, added once per
-// group instead of once per gather.
-__device__ __forceinline__ void packed_group(unsigned xs_addr, unsigned lo,
-                                             unsigned hi, double& s0,
-                                             double& s1) {
+// The five slots of a group, gathered but not yet added (the caller may issue
+// the ring slot's next stream load between the gathers and the additions).
+// xs_addr = lds_address(xs): the slice's LDS byte address, added once per group
+// instead of once per gather.
+__device__ __forceinline__ void packed_gather(unsigned xs_addr, unsigned lo,
+                                              unsigned hi, double* g) {
   // byte addresses of the five slots: o_{k+1} = o_k + 8 d_k
   const unsigned o0 = lshl3_add(lo & 0x3FFFu, xs_addr);
   const unsigned o1 = lshl3_add(__builtin_amdgcn_ubfe(lo, 14, 12), o0);
@@ -209,8 +210,19 @@ __device__ __forceinline__ void packed_group(unsigned xs_addr, unsigned lo,
       lshl3_add(__builtin_amdgcn_alignbit(hi, lo, 26) & 0xFFFu, o1);
   const unsigned o3 = lshl3_add(__builtin_amdgcn_ubfe(hi, 6, 12), o2);
   const unsigned o4 = lshl3_add(hi >> 18, o3);  // bits 62-63 of a group are 0
-  s0 += (lds_read(o0) + lds_read(o2)) + lds_read(o4);
-  s1 += lds_read(o1) + lds_read(o3);
+  g[0] = lds_read(o0);
+  g[1] = lds_read(o1);
+  g[2] = lds_read(o2);
+  g[3] = lds_read(o3);
+  g[4] = lds_read(o4);
+}
+__device__ __forceinline__ void packed_group(unsigned xs_addr, unsigned lo,
+                                             unsigned hi, double& s0,
+                                             double& s1) {
+  double g[5];
+  packed_gather(xs_addr, lo, hi, g);
+  s0 += (g[0] + g[2]) + g[4];
+  s1 += g[1] + g[3];
 }
 // Row ids of a ring slot, split BEFORE the slot is re-armed.  As asm volatile
 // statements these stay between the slot's wait and its next load; a plain
@@ -225,22 +237,6 @@ __device__ __forceinline__ void split_row_ids(unsigned rr, unsigned& ra,
                : "v"(rr));
 }
 
-// The five slots of a group, gathered but not yet added (the caller issues the
-// slot's next stream load between the gathers and the additions).
-__device__ __forceinline__ void packed_gather(unsigned xs_addr, unsigned lo,
-                                              unsigned hi, double* g) {
-  const unsigned o0 = lshl3_add(lo & 0x3FFFu, xs_addr);
-  const unsigned o1 = lshl3_add(__builtin_amdgcn_ubfe(lo, 14, 12), o0);
-  const unsigned o2 =
-      lshl3_add(__builtin_amdgcn_alignbit(hi, lo, 26) & 0xFFFu, o1);
-  const unsigned o3 = lshl3_add(__builtin_amdgcn_ubfe(hi, 6, 12), o2);
-  const unsigned o4 = lshl3_add(hi >> 18, o3);
-  g[0] = lds_read(o0);
-  g[1] = lds_read(o1);
-  g[2] = lds_read(o2);
-  g[3] = lds_read(o3);
-  g[4] = lds_read(o4);
-}
 __device__ __forceinline__ void step_accumulate_packed(
     unsigned xs_addr, v4u e, double& a0, double& a1, double& b0, double& b1) {
   packed_group(xs_addr, e.x, e.y, a0, a1);
