@@ -73,6 +73,7 @@ TiledOptions TiledOptions::from_env(bool transpose) {
   };
   geti("BBX_TILED_PR", &o.force_PR);
   geti("BBX_TILED_G", &o.force_G);
+  geti("BBX_TILED_BLOCKS", &o.force_blocks);
   geti("BBX_TILED_PACK", &o.packed);  // 0 / 1: plain ids / groups of five forced
   if (getenv("BBX_TILED_STATS")) o.stats = true;
   return o;
