@@ -12,6 +12,7 @@ from ctypes import (POINTER, byref, c_char_p, c_double, c_int, c_int32,
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libbbx.so")
 
+ABI_VERSION = 101          # BBX_VERSION of include/bbx.h
 FORMAT_AUTO, FORMAT_CSR, FORMAT_TILED = 0, 1, 2
 F64, F32 = 0, 1
 MODEL_LINEAR, MODEL_LOGIT = 0, 1
@@ -51,6 +52,8 @@ def _declare(lib):
         "bbx_last_error": ([], c_char_p),
         "bbx_device_count": ([POINTER(c_int)], c_int),
         "bbx_builder_threads": ([POINTER(c_int)], c_int),
+        "bbx_setup_lock_acquire": ([], c_int),
+        "bbx_setup_lock_release": ([], c_int),
         "bbx_design_create_csr": (
             [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
              c_int, c_int, c_int, POINTER(hp)], c_int),
@@ -201,6 +204,14 @@ def load():
                 % LIB_PATH)
         _one_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
+        lib.bbx_version.restype = c_int
+        if lib.bbx_version() != ABI_VERSION:
+            # the signatures below are those of include/bbx.h at ABI_VERSION; a
+            # stale library would be called with the wrong arity
+            raise BbxError(
+                "libbbx.so at %s reports version %d, this binding is written "
+                "against %d: rebuild it (`make -C bayes-bridge_amd/csrc`)"
+                % (LIB_PATH, lib.bbx_version(), ABI_VERSION))
         EXPORTED_SYMBOLS = sorted(_declare(lib))
         _lib = lib
     return _lib

@@ -83,29 +83,30 @@ def init_process_group_from_env(backend=None, single_rank_group=False):
 class setup_turn():
     """`with chains.setup_turn(): ...` around device-heavy set-up code of a
     rank: a no-op unless BBX_SETUP_LOCK names a lock file (ranks sharing a
-    GPU, see init_process_group_from_env), then an exclusive flock on it --
-    the same lock libbbx takes around its own device set-up."""
+    GPU, see init_process_group_from_env), then the library's process-global,
+    RE-ENTRANT lock on it (`bbx_setup_lock_acquire`): the design constructors
+    take the same lock around their own device work, so a constructor may be
+    called inside the bracket.  The device is synchronised before the turn
+    is handed on."""
 
     def __enter__(self):
-        self._fh = None
-        path = os.environ.get("BBX_SETUP_LOCK")
-        if path:
-            import fcntl
-            self._fh = open(path, "a+")
-            fcntl.flock(self._fh, fcntl.LOCK_EX)
+        self._held = 0
+        if os.environ.get("BBX_SETUP_LOCK"):
+            from . import _lib
+            self._held = _lib.load().bbx_setup_lock_acquire()
         return self
 
     def __exit__(self, *exc):
-        if self._fh is not None:
-            import fcntl
+        if self._held > 0:
             try:
                 import torch
                 if torch.cuda.is_available():
                     torch.cuda.synchronize()
             except Exception:      # noqa: BLE001
                 pass
-            fcntl.flock(self._fh, fcntl.LOCK_UN)
-            self._fh.close()
+            from . import _lib
+            _lib.load().bbx_setup_lock_release()
+            self._held = 0
         return False
 
 

@@ -289,27 +289,58 @@ static int validate_csr(bbx_design* h) {
 // exclusive flock on that file around the device part of a design's set-up
 // (validation, values check, transposition); the host-side layout builders
 // then run concurrently.  chains.py sets it when ranks outnumber devices.
-struct SetupLock {
-  int fd = -1;
-  SetupLock() {
-    const char* path = getenv("BBX_SETUP_LOCK");
-    if (path && *path) {
-      fd = open(path, O_CREAT | O_RDWR, 0600);
-      if (fd >= 0) (void)flock(fd, LOCK_EX);
+// The lock is PROCESS-GLOBAL and re-entrant (flock is held per open file
+// description: a second open() + flock() of the same file blocks even inside
+// the owning process, so the host wrapper's `with chains.setup_turn():` around
+// a design constructor used to hang): one descriptor, one depth counter, the
+// flock taken at depth 0 -> 1 and dropped at 1 -> 0.  bbx_setup_lock_acquire /
+// _release are the exported form (chains.setup_turn goes through them).
+static std::mutex g_setup_mutex;
+static int g_setup_fd = -1;
+static int g_setup_depth = 0;
+static bool g_setup_warned = false;
+
+static int setup_lock_acquire() {
+  const char* path = getenv("BBX_SETUP_LOCK");
+  if (!path || !*path) return 0;
+  std::lock_guard<std::mutex> guard(g_setup_mutex);
+  if (g_setup_depth == 0) {
+    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
+    if (fd < 0) {
+      if (!g_setup_warned) {
+        fprintf(stderr, "libbbx: BBX_SETUP_LOCK=%s cannot be opened (%s): the "
+                "device set-up of this process is NOT serialised\n", path,
+                strerror(errno));
+        g_setup_warned = true;
+      }
+      return 0;
     }
-  }
-  void release() {
-    if (fd >= 0) {
-      (void)flock(fd, LOCK_UN);
+    int rc;
+    do { rc = flock(fd, LOCK_EX); } while (rc != 0 && errno == EINTR);
+    if (rc != 0) {
+      fprintf(stderr, "libbbx: flock(%s) failed (%s): not serialised\n", path,
+              strerror(errno));
       (void)close(fd);
-      fd = -1;
+      return 0;
     }
+    g_setup_fd = fd;
   }
-  ~SetupLock() { release(); }
-};
+  ++g_setup_depth;
+  return 1;
+}
+
+static void setup_lock_release() {
+  std::lock_guard<std::mutex> guard(g_setup_mutex);
+  if (g_setup_depth <= 0) return;
+  if (--g_setup_depth == 0 && g_setup_fd >= 0) {
+    (void)flock(g_setup_fd, LOCK_UN);
+    (void)close(g_setup_fd);
+    g_setup_fd = -1;
+  }
+}
 
 static int finish_csr(bbx_design* h, int format) {
-  SetupLock lock;
+  SetupTurn lock;
   BBX_TRY(validate_csr(h));
   // Values that are all exactly 1.0 are dropped (binary designs,
   // simulate_data.py:100-117): the kernels then read indices only.
@@ -433,6 +464,17 @@ int bbx_device_count(int* count) {
   if (e != hipSuccess) c = 0;
   *count = c;
   return BBX_OK;
+}
+
+int bbx_setup_lock_acquire(void) {
+  return no_throw([&]() -> int { return setup_lock_acquire(); });
+}
+
+int bbx_setup_lock_release(void) {
+  return no_throw([&]() -> int {
+    setup_lock_release();
+    return BBX_OK;
+  });
 }
 
 int bbx_builder_threads(int* count) {

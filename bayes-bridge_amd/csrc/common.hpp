@@ -474,6 +474,21 @@ int tiled_describe(const bbx_design* h, int which, int* W, int* n_block,
 int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,
                        uint64_t stream, double* d_out);
 
+// Ranks that share a GPU take the device part of a design's set-up one at a
+// time: RAII form of bbx_setup_lock_acquire / _release (api.hip; a no-op unless
+// BBX_SETUP_LOCK names a lock file; re-entrant inside a process).
+struct SetupTurn {
+  int held;
+  SetupTurn() : held(bbx_setup_lock_acquire()) {}
+  void release() {
+    if (held > 0) bbx_setup_lock_release();
+    held = 0;
+  }
+  ~SetupTurn() { release(); }
+  SetupTurn(const SetupTurn&) = delete;
+  SetupTurn& operator=(const SetupTurn&) = delete;
+};
+
 int timer_begin(bbx_design* h, int which);
 int timer_end(bbx_design* h, int which);
 // Single-kernel families: hands out the event pair of this launch (nullptr,

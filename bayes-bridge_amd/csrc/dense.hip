@@ -1011,6 +1011,7 @@ static int create_dense_common(int64_t n, int64_t p, const void* X,
     return fail(BBX_ERR_INVALID, "device index out of range");
   }
   auto body = [&]() -> int {
+    SetupTurn turn;   // (ranks sharing a GPU: one device set-up at a time)
     BBX_HIP(hipSetDevice(device));
     h->device = device;
     BBX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));

@@ -2312,12 +2312,17 @@ int64_t tiled_storage_bytes(const bbx_design* h) {
 int tiled_describe(const bbx_design* h, int which, int* W, int* n_block,
                    int* PR, int* G, int64_t* n_quad, int64_t* n_slice,
                    int* packed) {
+  if (which < 0 || which > 7)
+    return fail(BBX_ERR_INVALID, "which must be 0 ... 7");
   const TiledPair* tp = static_cast<const TiledPair*>(h->tiled);
   // mixed designs: the value-free part (0, 1) and the valued rest (6, 7)
   if (h->hybrid) {
     const HybridParts* hp = static_cast<const HybridParts*>(h->hybrid);
     tp = (which >= 6) ? (hp->rest_nnz > 0 ? &hp->rest : nullptr) : &hp->ones;
     if (which >= 6) which -= 6;
+  } else if (which >= 6) {
+    return fail(BBX_ERR_INVALID,
+                "which = 6, 7 name the valued rest of a MIXED design");
   }
   if (!tp) return fail(BBX_ERR_STATE, "tiled format not built");
   if (which >= 2) {  // 2, 3: the K = 2 layout; 4, 5: the K = 4 layout

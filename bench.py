@@ -79,6 +79,13 @@ def parse_args(argv=None):
                          "inside the X~ v kernel, bbx_design_set_cg_fold) on / "
                          "off; default: the library's rule (on up to 250 000 "
                          "rows)")
+    ap.add_argument("--timing-blocks", default="first",
+                    choices=["first", "all", "none"],
+                    help="A/B of the block-0 bias (LABNOTES R5.1): which of the "
+                         "`repeat` blocks run with the kernel stamps on; the "
+                         "line's `roofline` needs 'first' or 'all'")
+    ap.add_argument("--timing-every", type=int, default=16,
+                    help="one launch in N carries kernel stamps")
     ap.add_argument("--repeat", type=int, default=5,
                     help="how many times the K-step block is run in all for "
                          "the `repeat` object (the first is the timed region "
@@ -489,40 +496,60 @@ def main():
     ncg_b = chain.run_device(B)[2] if B > 0 else np.zeros(0)
     burnin_ms = 1e3 * (time.perf_counter() - t_b) / max(B, 1)
     progress("burn-in done (%d iterations, %.1f ms each)" % (B, burnin_ms))
-    ncg_w = chain.run_device(W)[2] if W > 0 else np.zeros(0)
-    # state after warm-up (for the CPU baselines)
-    state = None
+    # Everything host-side that the timed region needs happens BEFORE the W
+    # warm-up steps (state for the CPU leg, sample buffer, event pool, the
+    # process group's first gather), so that the GPU runs Gibbs iterations
+    # right up to t0: a gap here lets the clocks fall and block 0 paid for the
+    # ramp (LABNOTES R5.1).
     widths = args.multi_chain
     if widths is None:
         widths = "4,8,16,32" if dense else "2,4"
     widths = [int(v) for v in widths.split(",") if int(v) > 1]
     solo = rank == 0 and world == 1 and env_world is None
-    if solo and ((args.cpu_baseline_iters > 0 and not dense) or widths):
-        coef, obs, ls, g = chain.get_state()
-        mean, square, navg = chain.get_summary()
-        state = (coef, obs, ls, g, mean, square, navg)
-
-    d_coef = torch.empty((max(K, 1), P), dtype=torch.float64, device=device)
-    # kernel stamps / brackets on one launch in 16 (timing every launch costs
-    # ~10% of the iteration; DESIGN.md "Measurement")
-    design.set_timing(True, every=16)
-    design.reset_timing()
+    want_state = solo and ((args.cpu_baseline_iters > 0 and not dense)
+                           or bool(widths))
+    d_buf = torch.empty((max(K, W, 1), P), dtype=torch.float64, device=device)
+    d_coef = d_buf[:max(K, 1)]          # (the warm-up may keep more samples)
     if grouped:
-        # part of the warm-up: the first gather of a process group sets up the
-        # point-to-point connections (RCCL does that lazily, 100s of ms)
+        # the first gather of a process group sets up the point-to-point
+        # connections (RCCL does that lazily, 100s of ms)
         chains.gather_chain_samples(d_coef, dst=0)
+    # kernel stamps / brackets on one launch in 16 (timing every launch costs
+    # ~10% of the iteration; DESIGN.md "Measurement"); switched on before the
+    # warm-up so that the event pool exists and the warm-up runs the same code
+    timing_on = args.timing_blocks != "none"
+    if timing_on:
+        design.set_timing(True, every=args.timing_every)
+    ncg_w = chain.run_device(W, d_coef_ptr=d_buf.data_ptr())[2] \
+        if W > 0 else np.zeros(0)
+    if timing_on:
+        design.reset_timing()
     chains.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     gs, lp, ncg, _ = chain.run_device(K, d_coef_ptr=d_coef.data_ptr())
+    t_run = time.perf_counter()
     gathered = chains.gather_chain_samples(d_coef, dst=0)
+    if grouped:
+        torch.cuda.synchronize()
+    t_gather = time.perf_counter()
     chains.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    own_elapsed, own_run, own_gather = elapsed, t_run - t0, t_gather - t_run
     elapsed = chains.max_over_ranks(elapsed)
     progress("timed region done (%.3f s)" % elapsed)
-    timing = design.get_timing()
-    design.set_timing(False)
+    timing = design.get_timing() if timing_on else {
+        "dot": (0, 0.), "tdot": (0, 0.), "operator": (0, 0.)}
+    if args.timing_blocks == "first":
+        design.set_timing(False)
+    # state after the timed block (for the CPU baselines and the batches): the
+    # chain is stationary, any post-burn-in state serves
+    state = None
+    if want_state:
+        coef, obs, ls, g = chain.get_state()
+        mean, square, navg = chain.get_summary()
+        state = (coef, obs, ls, g, mean, square, navg)
 
     # `repeat`: the same K-step block four more times, each bracketed like the
     # timed region (barrier + synchronize, max over ranks); value/steps/
@@ -549,11 +576,27 @@ def main():
     if grouped:
         import torch.distributed as dist
         box = [None] * world
-        dist.all_gather_object(box, (round(startup_s, 1), rss_mb,
-                                     _lib.builder_threads()))
-        per_rank = {"startup_s": [b[0] for b in box],
-                    "peak_host_rss_mb": [b[1] for b in box],
-                    "builder_threads": [b[2] for b in box]}
+        # what each rank saw of the timed region BEFORE the MAX all-reduce: if
+        # an N-GPU line is not N x the 1-GPU line, this says which rank, and
+        # whether it was the chain, the gather or the set-up
+        mine = dict(
+            startup_s=round(startup_s, 1), peak_host_rss_mb=rss_mb,
+            builder_threads=_lib.builder_threads(),
+            timed_s=round(own_elapsed, 4), run_s=round(own_run, 4),
+            gather_ms=round(1e3 * own_gather, 3),
+            iters_per_sec=round(K / own_run, 2) if own_run > 0 else None,
+            mean_n_cg_iter=round(float(ncg.mean()), 2),
+            burnin_ms_per_step=round(burnin_ms, 4),
+            device_index=dev_index,
+            device_name=torch.cuda.get_device_name(dev_index),
+            pid=os.getpid())
+        dist.all_gather_object(box, mine)
+        per_rank = {key: [b[key] for b in box] for key in mine}
+        per_rank["what"] = (
+            "one entry per rank: timed_s = this rank's barrier-to-barrier "
+            "seconds before the MAX over ranks, run_s = its K Gibbs "
+            "iterations alone, gather_ms = its share of the one gather of "
+            "the kept samples, iters_per_sec = K / run_s")
 
     if rank == 0:
         assert gathered is not None and gathered.shape[0] == world

@@ -33,7 +33,11 @@
 extern "C" {
 #endif
 
-#define BBX_VERSION 100 /* 0.1.0 */
+/* 101: bbx_design_tiled_info takes nine pointers (`packed`, since round 4),
+ *      bbx_setup_lock_acquire/_release, bbx_design_useful_bytes.  A binding
+ *      compares bbx_version() with the BBX_VERSION it was written against
+ *      (bayesbridge_amd/_lib.py does) instead of calling with a stale arity. */
+#define BBX_VERSION 101 /* 0.1.1 */
 
 /* status codes */
 #define BBX_OK 0
@@ -85,6 +89,18 @@ int bbx_device_count(int* count);
  * BBX_BUILD_THREADS=N overrides.  (The reference builds nothing on extra
  * threads: SciPy's CSR is used as is, sparse_matrix.py:21-49.) */
 int bbx_builder_threads(int* count);
+/* Ranks that SHARE a GPU take the device-heavy part of their set-up one at a
+ * time: when the environment variable BBX_SETUP_LOCK names a lock file, the
+ * constructors hold an exclusive flock on it around their device work, and a
+ * host wrapper brackets its own device set-up (data generation) with this
+ * pair.  The lock is process-global and RE-ENTRANT: nested acquires -- a
+ * constructor called inside a bracket -- only count.  acquire returns 1 when
+ * the lock is held afterwards (release it), 0 when BBX_SETUP_LOCK is unset or
+ * the file cannot be opened (a note goes to stderr; nothing to release).
+ * (No counterpart in the reference: one chain per process, one process per
+ * device, bayesbridge.py:109.) */
+int bbx_setup_lock_acquire(void);
+int bbx_setup_lock_release(void);
 
 /* ---------------------------------------------------- design operator (L1) */
 

@@ -207,3 +207,64 @@ def test_setup_turn_serialises_processes_that_share_a_lock_file(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], env=env,
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "TURN" in out.stdout
+
+
+def test_setup_turn_is_reentrant_inside_a_process(tmp_path):
+    """The library's lock is process-global with a depth counter: a design
+    constructor (which takes it itself) may be called inside
+    `with chains.setup_turn():`.  flock is per open file description -- two
+    independent opens of the lock file deadlock inside ONE process, which is
+    what the round-4 form did.  Nested turns must return, the lock must still
+    exclude another process while held and be free afterwards; a lock path
+    that cannot be opened degrades to "not serialised" with a note on stderr."""
+    code = textwrap.dedent("""
+        import fcntl, os, sys
+        sys.path.insert(0, os.path.join(%r, "bayes-bridge_amd"))
+        from bayesbridge_amd import _lib, chains
+        lib = _lib.load()
+        path = os.environ["BBX_SETUP_LOCK"]
+        def free():
+            fh = open(path, "a+")
+            try:
+                fcntl.flock(fh, fcntl.LOCK_EX | fcntl.LOCK_NB)
+            except OSError:
+                return False
+            finally:
+                fh.close()
+            return True
+        with chains.setup_turn():
+            with chains.setup_turn():          # the constructor's own turn
+                assert lib.bbx_setup_lock_acquire() == 1
+                assert not free()
+                lib.bbx_setup_lock_release()
+            assert not free()                  # still held by the outer turn
+        assert free()
+        lib.bbx_setup_lock_release()           # unbalanced release: ignored
+        assert free()
+        print("NESTED_OK")
+    """ % ROOT)
+    env = dict(os.environ, BBX_SETUP_LOCK=str(tmp_path / "setup.lock"),
+               BBX_NO_TORCH="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "NESTED_OK" in out.stdout, out.stderr[-2000:]
+    # a symlink is refused (O_NOFOLLOW) and a missing directory cannot be
+    # opened: acquire returns 0 and says so once
+    (tmp_path / "target").write_text("")
+    os.symlink(tmp_path / "target", tmp_path / "link.lock")
+    bad = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, os.path.join(%r, "bayes-bridge_amd"))
+        from bayesbridge_amd import _lib, chains
+        lib = _lib.load()
+        assert lib.bbx_setup_lock_acquire() == 0
+        with chains.setup_turn():
+            pass
+        print("DEGRADED_OK")
+    """ % ROOT)
+    for path in (tmp_path / "link.lock", tmp_path / "no" / "such" / "dir.lock"):
+        env["BBX_SETUP_LOCK"] = str(path)
+        out = subprocess.run([sys.executable, "-c", bad], env=env,
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and "DEGRADED_OK" in out.stdout, out.stderr
+        assert out.stderr.count("NOT serialised") == 1, out.stderr

@@ -137,3 +137,16 @@ def test_gpus_8_dry_run_over_gloo():
     assert line["value"] > 0
     assert line["config"]["startup_s"] > 0
     assert line["config"]["peak_host_rss_mb"] > 0
+    # the line explains itself rank by rank (timed seconds before the MAX
+    # all-reduce, the chain alone, the gather, n_cg, the device each sat on)
+    pr = line["config"]["per_rank"]
+    for key in ("startup_s", "peak_host_rss_mb", "builder_threads", "timed_s",
+                "run_s", "gather_ms", "iters_per_sec", "mean_n_cg_iter",
+                "burnin_ms_per_step", "device_index", "device_name", "pid"):
+        assert len(pr[key]) == 8, key
+    assert all(v > 0 for v in pr["timed_s"]) and all(v > 0 for v in pr["run_s"])
+    assert all(r <= t + 1e-3 for r, t in zip(pr["run_s"], pr["timed_s"]))
+    assert all(v >= 0 for v in pr["gather_ms"])
+    assert len(set(pr["pid"])) == 8
+    # `value` is N * K / the slowest rank's timed seconds
+    assert abs(line["value"] - 8 * 3 / max(pr["timed_s"])) < 2e-2 * line["value"]
