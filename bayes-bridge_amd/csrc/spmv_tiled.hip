@@ -92,22 +92,14 @@ struct TiledMatrix {
   int desc_stride = 0;  // > 0: wave k's schedule starts at k * desc_stride
   int64_t n_desc = 0;
   DevMem rowids;     // uint32[n_slice * 64]: panel-local rows A | B << 16
-  // dynamic dispatch (tiled_layout.hpp DynItem): the workgroups' item lists
-  // instead of per-wave schedules
-  bool dyn = false;
-  DevMem items;      // DynItem[n_slice + DYN_MAX_ITEMS]
-  DevMem wg_item;    // int32[n_panel * G + 1]
   DevMem folds;      // FoldDesc[n_fold]
   DevMem panel_fold; // int32[n_panel + 1]
   int n_extra = 0;   // extra accumulators per panel (row splitting)
   int split_T = 0;   // smallest split threshold used by any panel (0 = none)
   DevMem slab;       // double[G * R * K] partial sums when G > 1 (or Tdot)
   int64_t stream_bytes() const {
-    // (dyn: every wave reads its workgroup's list, but from L2 after the first)
     return (int64_t)n_quad * 64 * 16 * (has_vals ? 5 : 1) +
-           (int64_t)n_slice * 256 +
-           (dyn ? (int64_t)n_slice * (int64_t)sizeof(DynItem)
-                : (int64_t)n_desc * (int64_t)sizeof(BatchDesc));
+           (int64_t)n_slice * 256 + (int64_t)n_desc * (int64_t)sizeof(BatchDesc);
   }
 };
 
@@ -326,62 +318,6 @@ __device__ __forceinline__ void asm_load_u32(unsigned& dst, unsigned off,
                : "memory");
 }
 
-// Dynamic dispatch: the ticket counter.  One asm block: the LDS atomic (ONE
-// lane asks: 64 lanes adding to one address serialise in the atomic unit and
-// hold up every wave's gathers; control flow is wave-uniform here, so the
-// execution mask is all ones before and after), the wait for it and the move of
-// the answer to an SGPR.  Nothing of it is visible to the compiler as an LDS
-// operation in flight: written as __hip_atomic_fetch_add the atomic optimizer
-// produces the same synchronous sequence but for all 64 lanes' worth of
-// bookkeeping, and an asynchronous form (request before a step's stream wait,
-// take at its re-arm) left a VGPR owned by the LDS unit across compiler code --
-// the register allocator copied it before the answer had landed (seen in the
-// .s: v_mov_b32 v36, v99 between ds_add_rtn_u32 v99 and the wait).  Called
-// ahead of a step's wait for its stream data, the ~100 cycles of the round
-// trip are spent where the wave would wait for HBM anyway.
-__device__ __forceinline__ int ticket_take(unsigned addr) {
-  int t;
-  unsigned tmp;
-  asm volatile(
-      "s_mov_b64 exec, 1\n\t"
-      "ds_add_rtn_u32 %1, %2, %3\n\t"
-      "s_mov_b64 exec, -1\n\t"
-      "s_waitcnt lgkmcnt(0)\n\t"
-      "v_readfirstlane_b32 %0, %1"
-      : "=s"(t), "=&v"(tmp)
-      : "v"(addr), "v"(1u)
-      : "memory");
-  return t;
-}
-typedef __attribute__((address_space(3))) unsigned lds_unsigned;
-
-// Dynamic dispatch: item t of the workgroup's list, which every wave holds in
-// VGPRs (lane l of block b = item 64 b + l); t is wave-uniform.
-__device__ __forceinline__ void dyn_item(const unsigned (&tx)[DYN_MAX_ITEMS / WAVE],
-                                         const unsigned (&ty)[DYN_MAX_ITEMS / WAVE],
-                                         int t, unsigned& quad0, unsigned& steps_tile) {
-  const int l = t & (WAVE - 1);
-  static_assert(DYN_MAX_ITEMS / WAVE == 4, "four blocks of 64 items");
-  switch (t >> 6) {
-    case 0:
-      quad0 = (unsigned)__builtin_amdgcn_readlane((int)tx[0], l);
-      steps_tile = (unsigned)__builtin_amdgcn_readlane((int)ty[0], l);
-      break;
-    case 1:
-      quad0 = (unsigned)__builtin_amdgcn_readlane((int)tx[1], l);
-      steps_tile = (unsigned)__builtin_amdgcn_readlane((int)ty[1], l);
-      break;
-    case 2:
-      quad0 = (unsigned)__builtin_amdgcn_readlane((int)tx[2], l);
-      steps_tile = (unsigned)__builtin_amdgcn_readlane((int)ty[2], l);
-      break;
-    default:
-      quad0 = (unsigned)__builtin_amdgcn_readlane((int)tx[3], l);
-      steps_tile = (unsigned)__builtin_amdgcn_readlane((int)ty[3], l);
-      break;
-  }
-}
-
 constexpr int FILL_UNROLL = (TILE_W_MAX + TILE_THREADS - 1) / TILE_THREADS;
 // batched kernels: K slices share the LDS, K * W <= (158 KB / 8) doubles
 constexpr int FILL_K_PAIRS =
@@ -402,12 +338,8 @@ constexpr int FILL_K_PAIRS =
 //
 // DENSEP (KP == 0, direct epilogue): the dense block of a mixed design rides in
 // the epilogue (common.hpp DenseEpi).
-//
-// DYN (value-free, KP == 0): dynamic dispatch.  `wave_desc` is the layout's
-// wg_item, `descs` its DynItem list; the workgroup's waves take slices from an
-// LDS ticket counter instead of walking private schedules (tiled_layout.hpp).
 template <bool VALS, bool WIDE, int KP, bool FOLD = false, bool DENSEP = false,
-          bool PACK = false, bool DYN = false>
+          bool PACK = false>
 __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_kernel(
     int64_t R, int64_t C, int W, int PR, int G, int blocks_per_group,
     const int32_t* __restrict__ wave_desc, int desc_stride,
@@ -427,8 +359,6 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   static_assert(!FOLD || (KP == 0 && WIDE), "the folded direction step is single-chain");
   static_assert(!DENSEP || (KP == 0 && !FOLD), "dense epilogue: single chain, plain loop");
   static_assert(!PACK || (KP == 0 && !VALS), "packed groups: value-free, one right-hand side");
-  static_assert(!DYN || (KP == 0 && !VALS && !DENSEP && BATCH_BIN == 1),
-                "dynamic dispatch: value-free, one right-hand side, one step per slot");
   constexpr int K = KP > 0 ? 2 * KP : 1;
   // (scalar load, issued first; checked below once the descriptor loads that
   // every launch needs anyway have been issued, so it adds no round trip)
@@ -502,41 +432,13 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   // between two ISSUE steps; the next block of 64 is prefetched.
   // With equal-stride schedules the first descriptor block needs no lookup
   // (one dependent memory round trip less before the first stream load).
-  int blk = 0;
+  int blk = desc_stride > 0
+                ? (int)(bid * TILE_WAVES + wave) * desc_stride
+                : wave_desc[bid * TILE_WAVES + wave];
   int pos = 0;
   const uint4* __restrict__ desc4 = reinterpret_cast<const uint4*>(descs);
-  uint4 dcur = {0u, 0u, 0u, 0u}, dnxt = {0u, 0u, 0u, 0u};
-  // DYN: the issue cursor walks the current ITEM (slice); when its steps run out
-  // the wave takes the ticket it requested while issuing the item's last step.
-  // The first ticket of wave w is w (the counter starts at TILE_WAVES).
-  constexpr int DYN_BLOCKS = DYN_MAX_ITEMS / WAVE;
-  unsigned tabx[DYN_BLOCKS], taby[DYN_BLOCKS];
-  int dy_n = 0, dy_base = 0, dy_left = 0;
-  unsigned dy_quad = 0, dy_slot = 0, dy_tile1 = 0, dy_last1 = 0;
-  bool dy_end = false;
-  int dy_next = wave;                // the next ticket, when dy_have
-  bool dy_have = true;
-  int dy_switched = 0;               // tiles entered so far
-  __shared__ unsigned s_ticket;
-  const unsigned dy_addr = (unsigned)(uintptr_t)(lds_unsigned*)&s_ticket;
-  if constexpr (DYN) {
-    dy_base = wave_desc[bid];
-    dy_n = wave_desc[bid + 1] - dy_base;
-    const uint2* __restrict__ items = reinterpret_cast<const uint2*>(descs);
-#pragma unroll
-    for (int b = 0; b < DYN_BLOCKS; ++b) {
-      // (the list is padded by DYN_MAX_ITEMS items: in bounds for every b)
-      const uint2 it = items[dy_base + b * WAVE + lane];
-      tabx[b] = it.x;
-      taby[b] = it.y;
-    }
-    if (tid == 0) s_ticket = (unsigned)TILE_WAVES;
-  } else {
-    blk = desc_stride > 0 ? (int)(bid * TILE_WAVES + wave) * desc_stride
-                          : wave_desc[bid * TILE_WAVES + wave];
-    dcur = desc4[blk + lane];
-    dnxt = desc4[blk + WAVE + lane];
-  }
+  uint4 dcur = desc4[blk + lane];
+  uint4 dnxt = desc4[blk + WAVE + lane];
   // FOLD: everything the direction step reads goes out with the descriptor
   // loads -- one round trip for both.  Every WAVE re-adds the partials itself
   // (2 KB from L2 per wave): no LDS broadcast, no barrier.
@@ -568,16 +470,6 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   // Retire every compiler-visible load before the ring starts (see ISSUE).
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
   if (skip) return;  // the CG solve this launch belongs to has already stopped
-  if constexpr (DYN) {
-    // the counter's initial value must be visible before the first ticket is
-    // taken (a wave may run out of its first item while priming its ring)
-    __syncthreads();
-    if (dy_n > 0) {
-      unsigned q0_, st_;
-      dyn_item(tabx, taby, dy_n - 1, q0_, st_);
-      dy_last1 = (st_ >> 16) + 1u;   // tiles this workgroup enters
-    }
-  }
   if constexpr (FOLD) {
     // top of SciPy's cg loop (vecops.hip cg_direction_kernel): rho = r.r, the
     // same adds in the same order in every wave of every workgroup
@@ -640,7 +532,7 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
 
   if (dbg) t_start = (unsigned)__builtin_amdgcn_s_memtime();
 
-#define BBX_ISSUE_S(K)                                                         \
+#define BBX_ISSUE(K)                                                          \
   do {                                                                        \
     const unsigned d_quad0 =                                                  \
         (unsigned)__builtin_amdgcn_readlane((int)dcur.x, pos);                \
@@ -680,54 +572,6 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     }                                                                         \
   } while (0)
 
-// The same step from the workgroup's item list (DYN).  info: bit 0 count, 8
-// last step of the item, 10 end, bits 16-31 = (tile relative to the group) + 1.
-#define BBX_ISSUE_D(K)                                                        \
-  do {                                                                        \
-    if (dy_left == 0 && !dy_end) {                                            \
-      /* the ticket taken ahead of this step's stream wait (BBX_TICKET), or */ \
-      /* -- while the ring is primed -- now                                 */ \
-      const int t_ = dy_have ? dy_next : ticket_take(dy_addr);                \
-      dy_have = false;                                                        \
-      if (t_ >= dy_n) {                                                       \
-        dy_end = true;                                                        \
-      } else {                                                                \
-        unsigned q0_, st_;                                                    \
-        dyn_item(tabx, taby, t_, q0_, st_);                                   \
-        dy_quad = q0_;                                                        \
-        dy_left = (int)(st_ & 0xFFFFu);                                       \
-        dy_tile1 = (st_ >> 16) + 1u;                                          \
-        dy_slot = (unsigned)(dy_base + t_) * WAVE;                            \
-      }                                                                       \
-    }                                                                         \
-    /* (past the end: every lane reads the first 16 bytes, see above) */      \
-    asm_load_x4(e[K][0], dy_end ? 0u : (dy_quad * WAVE + lane) * 16u, ids);   \
-    asm_load_u32(rid[K], dy_end ? 0u : (dy_slot + lane) * 4u, rowids);        \
-    if (dy_end) {                                                             \
-      info[K] = BD_END | (dy_last1 << 16);                                    \
-    } else {                                                                  \
-      info[K] = 1u | (dy_left == 1 ? BD_LAST : 0u) | (dy_tile1 << 16);        \
-      ++dy_quad;                                                              \
-      --dy_left;                                                              \
-    }                                                                         \
-  } while (0)
-/* Ahead of a step's wait for its stream data: if the NEXT issue needs a new    */
-/* item, take the ticket now -- the LDS round trip overlaps the HBM wait.       */
-#define BBX_TICKET()                                                          \
-  do {                                                                        \
-    if constexpr (DYN) {                                                      \
-      if (dy_left == 0 && !dy_end && !dy_have) {                              \
-        dy_next = ticket_take(dy_addr);                                       \
-        dy_have = true;                                                       \
-      }                                                                       \
-    }                                                                         \
-  } while (0)
-#define BBX_ISSUE(K)                                                          \
-  do {                                                                        \
-    if constexpr (DYN) BBX_ISSUE_D(K);                                        \
-    else BBX_ISSUE_S(K);                                                      \
-  } while (0)
-
 // Wait until slot K's loads have landed (all later ISSUE steps may still be
 // in flight) and make its registers opaque to the scheduler at this point.
 #define BBX_WAIT(K)                                                           \
@@ -759,15 +603,10 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     for (int k = 0; k < RING; ++k) {
       if (!done) {
         const unsigned inf = info[k];
-        if (!DYN && (inf & BD_END)) {
+        if (inf & BD_END) {
           done = true;
         } else {
-          // DYN: a step names its tile; the wave enters every tile up to it, one
-          // switch each (all 16 waves pass the same barriers: an END step names
-          // the workgroup's last tile)
-          bool enter = DYN ? dy_switched < (int)(inf >> 16)
-                           : (inf & BD_TILE_FIRST) != 0;
-          while (enter) {
+          if (inf & BD_TILE_FIRST) {
             // ---- enter the next tile: replace the vector slice in LDS
             unsigned t_sw0 = 0;
             if (dbg) t_sw0 = (unsigned)__builtin_amdgcn_s_memtime();
@@ -864,23 +703,12 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
             }
             if (!(ablate & 4)) __syncthreads();
             if (dbg) t_switch += (unsigned)__builtin_amdgcn_s_memtime() - t_sw0;
-            if constexpr (DYN) {
-              ++dy_switched;
-              enter = dy_switched < (int)(inf >> 16);
-            } else {
-              enter = false;
-            }
-          }
-          if (DYN && (inf & BD_END)) {
-            done = true;
-            continue;
           }
           const int cntk = (int)(inf & 15u);
           bool issued = false;
           if constexpr (!PACK && !VALS && KP == 0 && BATCH == 1 && BBX_EARLY_ISSUE) {
             if (cntk > 0) {
               // (plain ids: the same order -- gathers, re-arm, additions)
-              BBX_TICKET();
               BBX_WAIT(k);
               const v4u ee = e[k][0];
               const double g0 = xs[ee.x & 0xFFFFu], g1 = xs[ee.y & 0xFFFFu];
@@ -907,7 +735,6 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
               // decode, gather, then re-arm the slot BEFORE the additions: the
               // ids are dead once the addresses exist, and the next stream
               // load need not wait for the LDS round trip
-              BBX_TICKET();
               BBX_WAIT(k);
               double ga[5], gb[5];
               packed_gather(xs_addr, e[k][0].x, e[k][0].y, ga);
@@ -987,9 +814,6 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     }
   }
 #undef BBX_ISSUE
-#undef BBX_ISSUE_S
-#undef BBX_ISSUE_D
-#undef BBX_TICKET
 #undef BBX_WAIT
   if (dbg) t_loop = (unsigned)__builtin_amdgcn_s_memtime() - t_start;
   if constexpr (KP > 0) {
@@ -1323,15 +1147,11 @@ static int upload(DevMem& dst, const void* src, size_t bytes) {
 // Builds one orientation on the host (tiled_layout.cpp) and moves it to HBM.
 static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
                      const int32_t* rowptr, const int32_t* colidx,
-                     const double* vals, bool transpose, int K,
-                     bool allow_dyn = false) {
+                     const double* vals, bool transpose, int K) {
   TiledHost host;
   std::string err;
   TiledOptions opt = TiledOptions::from_env(transpose);
   opt.chains = K;
-  // (the parts of a mixed design keep static schedules: their kernels -- dense
-  // epilogue, valued rest -- have no dynamic form)
-  if (!allow_dyn) opt.dynamic = 0;
   if (K > 1) opt.force_PR = opt.force_G = 0;  // overrides tune the K = 1 layout
   if (build_tiled_host(R, C, nnz, rowptr, colidx, vals, opt, &host, &err) != 0)
     return fail(BBX_ERR_INVALID, err);
@@ -1366,12 +1186,6 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
                  host.wave_desc.size() * sizeof(int32_t)));
   BBX_TRY(upload(m.rowids, host.rowids.data(),
                  host.rowids.size() * sizeof(uint32_t)));
-  m.dyn = host.dyn;
-  if (m.dyn) {
-    BBX_TRY(upload(m.items, host.items.data(), host.items.size() * sizeof(DynItem)));
-    BBX_TRY(upload(m.wg_item, host.wg_item.data(),
-                   host.wg_item.size() * sizeof(int32_t)));
-  }
   BBX_TRY(m.slab.alloc(sizeof(double) * (size_t)m.G * (size_t)R * (size_t)m.K));
   return BBX_OK;
 }
@@ -1435,11 +1249,11 @@ static int build_tiled_pair(bbx_design* h, int K, void** slot) {
   HostCsr c;
   BBX_TRY(fetch_host_csr(h, false, &c));
   BBX_TRY(build_one(tp->x, n, p, nnz, c.rowptr.data(), c.colidx.data(),
-                    h->binary ? nullptr : c.vals.data(), false, K, true));
+                    h->binary ? nullptr : c.vals.data(), false, K));
   // transpose orientation from the CSR of X^T built on the device
   BBX_TRY(fetch_host_csr(h, true, &c));
   BBX_TRY(build_one(tp->xt, p, n, nnz, c.rowptr.data(), c.colidx.data(),
-                    h->binary ? nullptr : c.vals.data(), true, K, true));
+                    h->binary ? nullptr : c.vals.data(), true, K));
   return check_lds(tp);
 }
 
@@ -1595,19 +1409,6 @@ int build_tiled(bbx_design* h) {
   BBX_TILED_ATTR(false, true, 0, false, true);
   BBX_TILED_ATTR(false, true, 0, true, true);
 #undef BBX_TILED_ATTR
-  // dynamic dispatch (4 bytes of static LDS: the ticket counter)
-#define BBX_TILED_ATTR_DYN(WW, FF, PP)                                         \
-  BBX_HIP(hipFuncSetAttribute(                                                 \
-      reinterpret_cast<const void*>(                                           \
-          &tiled_spmv_kernel<false, WW, 0, FF, false, PP, true>),              \
-      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048))
-  BBX_TILED_ATTR_DYN(false, false, false);
-  BBX_TILED_ATTR_DYN(true, false, false);
-  BBX_TILED_ATTR_DYN(true, true, false);
-  BBX_TILED_ATTR_DYN(false, false, true);
-  BBX_TILED_ATTR_DYN(true, false, true);
-  BBX_TILED_ATTR_DYN(true, true, true);
-#undef BBX_TILED_ATTR_DYN
   // The reference-layout index arrays stay in HBM (0.8 GB at 1M x 50k, next to
   // 288 GB): a layout sized for K batched chains is built from them on first
   // use (ensure_tiled_k), and storage = 'csr' cross-checks need them anyway.
@@ -1770,19 +1571,13 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
 #define BBX_TILED_LAUNCH_W(VV, WW, KK, VALPTR)                                 \
   BBX_TILED_LAUNCH_D(VV, WW, KK, false, false, false, VALPTR)
 #define BBX_TILED_LAUNCH_D(VV, WW, KK, FF, DD, PP, VALPTR)                     \
-  BBX_TILED_LAUNCH_Y(VV, WW, KK, FF, DD, PP, false, VALPTR)
-#define BBX_TILED_LAUNCH_Y(VV, WW, KK, FF, DD, PP, YY, VALPTR)                 \
-  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, WW, KK, FF, DD, PP, YY>),       \
+  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, WW, KK, FF, DD, PP>),           \
                      dim3(grid),                                               \
                      dim3(TILE_THREADS), (unsigned)lb, h->stream, ev_begin,    \
                      ev_end, 0u, m.R, m.C, m.W, m.PR,                          \
                      m.G, (m.n_block + m.G - 1) / m.G,                         \
-                     (YY) ? m.wg_item.as<int32_t>()                            \
-                          : m.wave_desc.as<int32_t>(),                         \
-                     m.desc_stride,                                            \
-                     (YY) ? reinterpret_cast<const BatchDesc*>(m.items.ptr)    \
-                          : m.descs.as<BatchDesc>(),                           \
-                     m.rowids.as<uint32_t>(),                                  \
+                     m.wave_desc.as<int32_t>(), m.desc_stride,                 \
+                     m.descs.as<BatchDesc>(), m.rowids.as<uint32_t>(),         \
                      m.ids.as<uint4>(), VALPTR, x, c_part, x0_ptr, rowscale,   \
                      out, slab, m.PR + m.n_extra,                              \
                      m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),       \
@@ -1792,15 +1587,8 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
 // value-free, one right-hand side: plain ids or packed groups (m.packed)
 #define BBX_TILED_LAUNCH_P(WW, FF, DD)                                         \
   do {                                                                         \
-    if (m.dyn && !(DD)) {                                                      \
-      if (m.packed)                                                            \
-        BBX_TILED_LAUNCH_Y(false, WW, 0, FF, false, true, true, nullptr);      \
-      else                                                                     \
-        BBX_TILED_LAUNCH_Y(false, WW, 0, FF, false, false, true, nullptr);     \
-    } else if (m.packed)                                                       \
-      BBX_TILED_LAUNCH_D(false, WW, 0, FF, DD, true, nullptr);                 \
-    else                                                                       \
-      BBX_TILED_LAUNCH_D(false, WW, 0, FF, DD, false, nullptr);                \
+    if (m.packed) BBX_TILED_LAUNCH_D(false, WW, 0, FF, DD, true, nullptr);     \
+    else BBX_TILED_LAUNCH_D(false, WW, 0, FF, DD, false, nullptr);             \
   } while (0)
   // 16-byte slice loads need every slice start 16-byte aligned: W is a multiple
   // of 64 doubles, so it is the alignment of x itself that decides (inside the
@@ -1817,7 +1605,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
     // mixed design inside an operator application: the dense block in the
     // value-free kernel's epilogue (single chain, direct epilogue)
     if (m.K != 1 || !wide || m.G != 1 || !out || m.has_vals || addend || fold ||
-        m.dyn || dense->kd < 1 || dense->kd > DENSE_EPI_MAX)
+        dense->kd < 1 || dense->kd > DENSE_EPI_MAX)
       return fail(BBX_ERR_STATE, "dense epilogue: unsupported launch");
     BBX_TILED_LAUNCH_P(true, false, true);
   } else if (fold) {
@@ -1845,7 +1633,6 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
 #undef BBX_TILED_LAUNCH_W
 #undef BBX_TILED_LAUNCH_P
 #undef BBX_TILED_LAUNCH_D
-#undef BBX_TILED_LAUNCH_Y
   BBX_HIP(hipGetLastError());
   if (dbg) {
     BBX_HIP(hipStreamSynchronize(h->stream));

@@ -75,7 +75,6 @@ TiledOptions TiledOptions::from_env(bool transpose) {
   geti("BBX_TILED_G", &o.force_G);
   geti("BBX_TILED_BLOCKS", &o.force_blocks);
   geti("BBX_TILED_PACK", &o.packed);  // 0 / 1: plain ids / groups of five forced
-  geti("BBX_TILED_DYN", &o.dynamic);  // 0 / 1: static schedules / dynamic dispatch
   if (getenv("BBX_TILED_STATS")) o.stats = true;
   return o;
 }
@@ -93,10 +92,6 @@ struct PanelBuild {
   int split_T = 0;
   std::vector<BatchDesc> descs;   // quad0/row_slot local to the panel
   std::vector<int32_t> wave_desc; // [G * TILE_WAVES] local start of each wave
-  // dynamic dispatch: the workgroups' item lists (quad0 local to the panel) and
-  // how many items each group of column blocks holds
-  std::vector<DynItem> items;
-  std::vector<int32_t> group_items;
   // schedule statistics (BBX_TILED_STATS): per workgroup, in batches
   std::vector<int64_t> wg_critical;  // sum over tiles of the busiest wave
   std::vector<int64_t> wg_total;     // all waves, all tiles
@@ -226,40 +221,6 @@ static void build_schedules(PanelBuild& pb, int G, int batch) {
   pb.vals.swap(new_vals);
   pb.rowids.swap(new_rowids);
   pb.slices.swap(new_slices);
-}
-
-// Dynamic dispatch: the slices stay in the order build_panel produced them --
-// tile by tile, by decreasing step count inside a tile -- which is the order the
-// tickets hand them out, so a workgroup reads ONE sequential stream.  No dealing:
-// the longest-processing-time rule is applied at run time by whichever wave is
-// free.  The statistics are those of the ideal deal (total / 16 per tile, at
-// least the longest slice).
-static void build_items(PanelBuild& pb, int G) {
-  pb.group_items.assign((size_t)G, 0);
-  size_t tile_cursor = 0;
-  for (int g = 0; g < G; ++g) {
-    const size_t t0 = tile_cursor, t1 = tile_cursor + pb.group_tile_count[g];
-    tile_cursor = t1;
-    int64_t crit = 0, total = 0;
-    for (size_t t = t0; t < t1; ++t) {
-      const TileDesc& td = pb.tiles[t];
-      int64_t tile_total = 0, longest = 0;
-      for (int sl = td.slice_begin; sl < td.slice_end; ++sl) {
-        const SliceMeta& sm = pb.slices[(size_t)sl];
-        DynItem it;
-        it.quad0 = sm.first_quad;
-        it.steps_tile = sm.n_quad | ((uint32_t)(t - t0) << 16);
-        pb.items.push_back(it);
-        pb.group_items[(size_t)g] += 1;
-        tile_total += sm.n_quad;
-        longest = std::max<int64_t>(longest, sm.n_quad);
-      }
-      crit += std::max(longest, (tile_total + TILE_WAVES - 1) / TILE_WAVES);
-      total += tile_total;
-    }
-    pb.wg_critical.push_back(crit);
-    pb.wg_total.push_back(total);
-  }
 }
 
 struct VRow {
@@ -449,8 +410,8 @@ static void bank_aware_order(const HalfRow* rows, int n_rows, int64_t col0,
 static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
                         const int32_t* colidx, const double* vals, int W,
                         int n_block, int PR, int G, int extra_budget,
-                        int panel, bool packed, bool dyn,
-                        const TiledOptions& opt, PanelBuild& pb) {
+                        int panel, bool packed, const TiledOptions& opt,
+                        PanelBuild& pb) {
   const int Wl = packed_slots(W);  // packed: terminal zero slot of a slice
   std::vector<uint64_t> groups;    // packed: groups of the tile's rows
   const int64_t row0 = (int64_t)panel * PR;
@@ -787,8 +748,7 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
     pb.tiles.push_back(td);
     pb.group_tile_count[cb / blocks_per_group] += 1;
   }
-  if (dyn) build_items(pb, G);
-  else build_schedules(pb, G, vals ? BATCH_VAL : BATCH_BIN);
+  build_schedules(pb, G, vals ? BATCH_VAL : BATCH_BIN);
 }
 
 // LDS doubles one right-hand side may use: slice + 8 + accumulators + extras
@@ -1024,43 +984,22 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   }
   m.Wl = m.packed ? packed_slots(m.W) : m.W;
   const bool packed = m.packed;
-  // Dynamic dispatch (DynItem): value-free, one right-hand side, and every
-  // workgroup's item list must fit the kernel's register table -- known only
-  // once the panels are built, so a layout that does not fit is built again
-  // with static schedules (bound first: slices <= tiles x (rows + extras) / 128).
-  bool dyn = !vals && K == 1 && opt.dynamic > 0;
-  if (dyn) {
-    const int64_t bpg = (m.n_block + m.G - 1) / m.G;
-    if (bpg >= 65536) dyn = false;
-  }
-  for (;;) {
-    for (auto& pb : pbs) pb = PanelBuild();
-    std::vector<std::thread> pool;
-    std::vector<int> thread_status(n_thr, 0);
-    for (unsigned t = 0; t < n_thr; ++t)
-      pool.emplace_back([&, t]() {
-        // an exception must not leave a worker thread (std::terminate)
-        try {
-          for (int p = (int)t; p < m.n_panel; p += (int)n_thr)
-            build_panel(R, C, rowptr, colidx, vals, m.W, m.n_block, m.PR, m.G,
-                        extra_budget, p, packed, dyn, opt, pbs[(size_t)p]);
-        } catch (...) {
-          thread_status[t] = -1;
-        }
-      });
-    for (auto& th : pool) th.join();
-    for (int st_t : thread_status)
-      if (st_t < 0) return fail("out of host memory while tiling");
-    if (!dyn) break;
-    bool fits = true;
-    for (const auto& pb : pbs) {
-      for (int32_t c : pb.group_items) fits = fits && c <= DYN_MAX_ITEMS;
-      for (const SliceMeta& sm : pb.slices) fits = fits && sm.n_quad < 65536u;
-    }
-    if (fits) break;
-    dyn = false;   // (rare: very many short slices per workgroup)
-  }
-  m.dyn = dyn;
+  std::vector<std::thread> pool;
+  std::vector<int> thread_status(n_thr, 0);
+  for (unsigned t = 0; t < n_thr; ++t)
+    pool.emplace_back([&, t]() {
+      // an exception must not leave a worker thread (std::terminate)
+      try {
+        for (int p = (int)t; p < m.n_panel; p += (int)n_thr)
+          build_panel(R, C, rowptr, colidx, vals, m.W, m.n_block, m.PR, m.G,
+                      extra_budget, p, packed, opt, pbs[(size_t)p]);
+      } catch (...) {
+        thread_status[t] = -1;
+      }
+    });
+  for (auto& th : pool) th.join();
+  for (int st_t : thread_status)
+    if (st_t < 0) return fail("out of host memory while tiling");
 
   if (opt.stats) {
     int64_t crit_max = 0, total = 0, dup = 0, quads = 0, n_wg = 0, crit_sum = 0;
@@ -1082,13 +1021,12 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
     }
     char line[1024];
     snprintf(line, sizeof(line),
-            "[bbx tiled %lldx%lld K=%d%s] W=%d blocks=%d PR=%d G=%d split T=%d "
+            "[bbx tiled %lldx%lld K=%d] W=%d blocks=%d PR=%d G=%d split T=%d "
             "extras=%d workgroups=%lld: "
             "quads=%lld (+%lld re-loaded to fill batches, %.1f%%); batches per "
             "wave: ideal %.1f, mean critical path %.1f, worst workgroup %lld "
             "(%.1f%% over ideal)\n",
-            (long long)R, (long long)C, K, dyn ? " dyn" : "", m.W, m.n_block,
-            m.PR, m.G, stat_T,
+            (long long)R, (long long)C, K, m.W, m.n_block, m.PR, m.G, stat_T,
             stat_extra, (long long)n_wg, (long long)quads, (long long)dup,
             100. * (double)dup / (double)std::max<int64_t>(quads, 1),
             (double)total / (double)(n_wg * TILE_WAVES),
@@ -1114,12 +1052,6 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   std::vector<uint32_t> rowids(tot_slices * LANES);
   std::vector<FoldDesc> folds;
   std::vector<int32_t> panel_fold((size_t)m.n_panel + 1, 0);
-  std::vector<DynItem> items;
-  std::vector<int32_t> wg_item;
-  if (dyn) {
-    items.reserve(tot_slices);
-    wg_item.reserve((size_t)m.n_panel * m.G + 1);
-  }
   m.n_extra = 0;
   m.split_T = 0;
   size_t id_off = 0, sl_off = 0, de_off = 0;
@@ -1152,18 +1084,6 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
     if (!pb.rowids.empty())
       memcpy(&rowids[sl_off * LANES], pb.rowids.data(),
              pb.rowids.size() * sizeof(uint32_t));
-    if (dyn) {
-      // item i of the matrix is slice i: the panels' lists, one after the other
-      size_t at = 0;
-      for (int g = 0; g < m.G; ++g) {
-        wg_item.push_back((int32_t)items.size());
-        for (int32_t k = 0; k < pb.group_items[(size_t)g]; ++k, ++at) {
-          DynItem it = pb.items[at];
-          it.quad0 += (uint32_t)(id_off / LANES);
-          items.push_back(it);
-        }
-      }
-    }
     id_off += pb.ids.size();
     sl_off += pb.slices.size();
     de_off += pb.descs.size();
@@ -1217,13 +1137,6 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   }
   if ((size_t)m.lds_doubles() * sizeof(double) > (size_t)TILE_LDS_BYTES)
     return fail("tile does not fit in LDS");
-  if (dyn) {
-    wg_item.push_back((int32_t)items.size());
-    // (the kernel's table loads read whole blocks of 64 items)
-    items.resize(items.size() + DYN_MAX_ITEMS, DynItem{0u, 0u});
-  }
-  m.items.swap(items);
-  m.wg_item.swap(wg_item);
   m.ids.swap(ids);
   m.vals.swap(vv);
   m.descs.swap(descs);
@@ -1295,50 +1208,7 @@ void emulate_tiled_spmv(const TiledHost& m, const double* x,
     const int64_t row0 = (int64_t)panel * m.PR;
     const int rows_here = (int)std::min<int64_t>(m.PR, m.R - row0);
     std::fill(acc.begin(), acc.end(), 0.);
-    if (m.dyn) {
-      // dynamic dispatch: the workgroup's items tile by tile, in list order --
-      // whichever wave takes an item does these additions in this order, and no
-      // two items of a tile share an accumulator
-      WaveState& s = ws[0];
-      int tile_now = -1;
-      for (int32_t it = m.wg_item[(size_t)wg]; it < m.wg_item[(size_t)wg + 1]; ++it) {
-        const DynItem& item = m.items[(size_t)it];
-        const int tile = (int)(item.steps_tile >> 16);
-        const uint32_t steps = item.steps_tile & 0xFFFFu;
-        if (tile != tile_now) {
-          tile_now = tile;
-          const int64_t col0 = (int64_t)(group * bpg + tile) * m.W;
-          const int cols_here =
-              (int)std::max<int64_t>(0, std::min<int64_t>(m.W, m.C - col0));
-          if (m.packed) {
-            std::fill(xs.begin(), xs.end(), 0.);
-            for (int j = 0; j < cols_here; ++j)
-              xs[(size_t)packed_slot(j)] = x[col0 + j];
-          } else {
-            for (int j = 0; j < m.W + 8; ++j)
-              xs[(size_t)j] = j < cols_here ? x[col0 + j] : 0.;
-          }
-        }
-        for (int l = 0; l < LANES; ++l) s.a0[l] = s.a1[l] = s.b0[l] = s.b1[l] = 0.;
-        for (uint32_t u = 0; u < steps; ++u)
-          for (int l = 0; l < LANES; ++l) {
-            const size_t at = ((size_t)item.quad0 + u) * LANES + (size_t)l;
-            if (m.packed)
-              emu_step_packed(xs.data(), m.ids[at], s.a0[l], s.a1[l], s.b0[l],
-                              s.b1[l]);
-            else
-              emu_step(m, xs.data(), m.ids[at], nullptr, s.a0[l], s.a1[l],
-                       s.b0[l], s.b1[l]);
-          }
-        for (int l = 0; l < LANES; ++l) {
-          const uint32_t rr = m.rowids[(size_t)it * LANES + (size_t)l];
-          const uint32_t ra = rr & 0xFFFFu, rb = rr >> 16;
-          if (ra != NO_ROW) acc[ra] += s.a0[l] + s.a1[l];
-          if (rb != NO_ROW) acc[rb] += s.b0[l] + s.b1[l];
-        }
-      }
-    }
-    for (int w = 0; w < TILE_WAVES && !m.dyn; ++w) {
+    for (int w = 0; w < TILE_WAVES; ++w) {
       WaveState& s = ws[w];
       s.cursor = m.desc_stride > 0
                      ? (int64_t)(wg * TILE_WAVES + w) * m.desc_stride
@@ -1348,7 +1218,7 @@ void emulate_tiled_spmv(const TiledHost& m, const double* x,
     }
     // tile by tile (the kernel's barriers): every wave processes its
     // descriptors of the tile, then all move on
-    for (int cb = group * bpg; !m.dyn; ++cb) {
+    for (int cb = group * bpg;; ++cb) {
       bool any = false;
       for (int w = 0; w < TILE_WAVES; ++w)
         any = any || (!ws[w].ended &&
@@ -1494,16 +1364,14 @@ extern "C" {
 
 // out[R] = A x for the R x C CSR matrix through the tiled layout + emulator
 // (the G partial slabs are added in group order, like the epilogue kernels).
-// info[0..9] = W, n_block, PR, G, n_quad, n_slice, n_extra, split_T, packed, dyn;
+// info[0..8] = W, n_block, PR, G, n_quad, n_slice, n_extra, split_T, packed;
 // packed: -1 = the builder's choice, 0 / 1 = plain ids / groups of five forced;
-// dynamic: -1 / 0 / 1 = the builder's choice / static schedules / item lists
-// for the workgroups' ticket counters wherever they apply;
 // gather_cycles = mean LDS cycles per ds_read_b64 half-wave group (or NULL).
 int bbx_layout_emulate(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
                        const int32_t* colidx, const double* vals,
                        int bank_aware, int force_PR, int force_G,
                        int force_blocks, int max_threads, int chains,
-                       int packed, int dynamic, const double* x, double* out,
+                       int packed, const double* x, double* out,
                        int64_t* info, double* gather_cycles) {
   bbx::TiledOptions opt;
   opt.bank_aware = bank_aware != 0;
@@ -1513,7 +1381,6 @@ int bbx_layout_emulate(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   opt.stats = getenv("BBX_TILED_STATS") != nullptr;
   opt.chains = chains > 0 ? chains : 1;
   opt.packed = packed;
-  opt.dynamic = dynamic;
   if (max_threads > 0) opt.max_threads = max_threads;
   bbx::TiledHost m;
   std::string err;
@@ -1531,7 +1398,7 @@ int bbx_layout_emulate(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   if (info) {
     info[0] = m.W; info[1] = m.n_block; info[2] = m.PR; info[3] = m.G;
     info[4] = m.n_quad; info[5] = m.n_slice; info[6] = m.n_extra;
-    info[7] = m.split_T; info[8] = m.packed ? 1 : 0; info[9] = m.dyn ? 1 : 0;
+    info[7] = m.split_T; info[8] = m.packed ? 1 : 0;
   }
   if (gather_cycles) *gather_cycles = bbx::tiled_mean_gather_cycles(m);
   return 0;

@@ -86,22 +86,6 @@ constexpr uint32_t BD_LAST = 1u << 8;
 constexpr uint32_t BD_TILE_FIRST = 1u << 9;
 constexpr uint32_t BD_END = 1u << 10;
 
-// Dynamic dispatch (TiledHost::dyn; value-free, one right-hand side): instead
-// of per-wave schedules a workgroup holds ONE list of work items -- its slices
-// in processing order, tile by tile, longest first inside a tile, which is also
-// the order of the id stream -- and its waves take the next item from an LDS
-// ticket counter when they run out of steps.  Which wave sums a slice does not
-// change a bit of the result: a slice is still summed by exactly one wave in a
-// fixed order and flushed into accumulators no other item of its tile touches.
-// An item is 8 bytes: quad0, then n_quad | tile << 16 (tile = column block
-// relative to the group's first).  Item i of the matrix is slice i (row ids at
-// i * 64).  A workgroup's list lives in VGPRs: at most DYN_MAX_ITEMS.
-constexpr int DYN_MAX_ITEMS = 256;
-struct DynItem {
-  uint32_t quad0;
-  uint32_t steps_tile;
-};
-
 // Row r of a panel was split: acc[r] += acc[first .. first+count) at the end.
 struct FoldDesc {
   uint16_t row, first, count, pad;
@@ -122,10 +106,6 @@ struct TiledOptions {
   // value-free ids of a single right-hand side as groups of five (see
   // packed_slot): -1 = whichever form stores fewer steps, 0 / 1 = forced
   int packed = -1;
-  // dynamic dispatch of the slices inside a workgroup (DynItem): 1 = wherever it
-  // applies (value-free, one right-hand side, <= DYN_MAX_ITEMS slices per
-  // workgroup), 0 = static per-wave schedules everywhere, -1 = the default
-  int dynamic = -1;          // BBX_TILED_DYN
   bool stats = false;        // BBX_TILED_STATS=1
   int max_threads = 64;
   // transpose: the X^T orientation reads BBX_TILED_PR_T / BBX_TILED_G_T first
@@ -146,9 +126,6 @@ struct TiledHost {
   int split_T = 0;      // smallest split threshold used by any panel (0 = none)
   std::vector<Ids4> ids;            // [n_quad * 64]
   std::vector<double> vals;         // [n_quad * 64 * 8] when has_vals
-  bool dyn = false;     // dynamic dispatch: `items` / `wg_item` instead of schedules
-  std::vector<DynItem> items;       // dyn: one per slice, in stream order
-  std::vector<int32_t> wg_item;     // dyn: [n_panel * G + 1] first item of a workgroup
   std::vector<BatchDesc> descs;     // per-wave schedules (+ 2 blocks of END)
   std::vector<int32_t> wave_desc;   // [n_panel * G * TILE_WAVES]
   std::vector<uint32_t> rowids;     // [n_slice * 64]: panel-local rows A | B<<16

@@ -108,17 +108,14 @@ class TiledLayoutCpu:
                  '../libbbx_layout.so'], stdout=subprocess.DEVNULL)
         self.lib = ctypes.CDLL(path)
         self.lib.bbx_layout_emulate.argtypes = (
-            [c_int64] * 3 + [c_void_p] * 3 + [c_int] * 8 + [c_void_p] * 2
+            [c_int64] * 3 + [c_void_p] * 3 + [c_int] * 7 + [c_void_p] * 2
             + [POINTER(c_int64), POINTER(c_double)])
 
     def matvec(self, A, x, bank_aware=True, force_PR=0,
-               force_G=0, threads=4, chains=1, force_blocks=0, packed=-1,
-               dynamic=-1):
+               force_G=0, threads=4, chains=1, force_blocks=0, packed=-1):
         """(A x, info dict) through the layout + emulator; A is R x C CSR
         with ascending column indices inside each row.  packed: -1 the
-        builder's choice between plain ids and groups of five, 0 / 1 forced;
-        dynamic: -1 / 0 / 1 the builder's choice / static per-wave schedules /
-        per-workgroup item lists (dynamic dispatch) wherever they apply."""
+        builder's choice between plain ids and groups of five, 0 / 1 forced."""
         import ctypes
         A = sparse.csr_matrix(A)
         R, C = A.shape
@@ -130,18 +127,18 @@ class TiledLayoutCpu:
         data = None if binary else np.ascontiguousarray(A.data, np.float64)
         x = np.ascontiguousarray(x, dtype=np.float64)
         out = np.empty(R)
-        info = (ctypes.c_int64 * 10)()
+        info = (ctypes.c_int64 * 9)()
         cyc = ctypes.c_double()
         st = self.lib.bbx_layout_emulate(
             R, C, A.nnz, indptr.ctypes.data, indices.ctypes.data,
             None if data is None else data.ctypes.data,
             int(bank_aware), int(force_PR), int(force_G), int(force_blocks),
-            int(threads), int(chains), int(packed), int(dynamic),
+            int(threads), int(chains), int(packed),
             x.ctypes.data, out.ctypes.data, info, ctypes.byref(cyc))
         if st != 0:
             raise RuntimeError("tiled layout could not be built")
         keys = ('W', 'n_block', 'PR', 'G', 'n_quad', 'n_slice', 'n_extra',
-                'split_T', 'packed', 'dyn')
+                'split_T', 'packed')
         meta = dict(zip(keys, (int(v) for v in info)))
         meta['gather_cycles'] = cyc.value
         return out, meta
