@@ -144,6 +144,50 @@ struct PolyaGamma {
     return x;
   }
 
+  // ---- the same sampler cut into pieces for the device's round structure
+  // (chain.hip polya_gamma_block).  jacobi() below stays the sequential form
+  // whose stream consumption is pinned to the reference's.
+
+  // ONE proposal of trunc_inv_gauss: false = rejected (propose again).  The
+  // nested loops above flatten to this: a rejection of the inner chi-square
+  // proposal and a rejection of the outer test both lead to a fresh inner
+  // proposal, i.e. to a fresh attempt.
+  template <class G>
+  BBX_HD static inline bool trunc_inv_gauss_attempt(G& g, double z, double cut,
+                                                    double& x) {
+    const double mean = 1. / z;
+    if (mean > cut) {
+      const double e = trunc_exp(g, 2., 0.5 * kPi);
+      if (g.uniform() > sqrt(0.5 * kPi / e)) return false;
+      x = 1.0 / e;
+      return log(g.uniform()) < -0.5 * x * z * z;
+    }
+    x = inv_gauss(g, mean);
+    return x < cut;
+  }
+
+  // The alternating-series test of a proposal x (the second half of one
+  // iteration of jacobi()): true = accepted.
+  template <class G>
+  BBX_HD static inline bool series_accept(G& g, double x) {
+    const double first = series_term(0, x);
+    const double u = g.uniform() * first;
+    double partial = first;
+    int n_summed = 1;
+    int sign = -1;
+    for (;;) {
+      partial += sign * series_term(n_summed, x);
+      n_summed += 1;
+      if (sign == -1) {
+        if (u <= partial) return true;
+      } else {
+        if (u > partial) return false;
+        if (n_summed >= kMaxTerms) return true;
+      }
+      sign = -sign;
+    }
+  }
+
   // Tilted Jacobi J*(1, z) (polya_gamma.pyx:86-111,139-162).
   template <class G>
   BBX_HD static inline double jacobi(G& g, double z) {

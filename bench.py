@@ -56,7 +56,8 @@ def parse_args(argv=None):
                          "begin: tau, logp and n_cg are stationary after "
                          "~250-300 iterations at config 3 "
                          "(profiles/r02_ncg_trajectory.txt).  Default: 300 for "
-                         "the sparse configs, 10 for config4")
+                         "the sparse configs, 100 for config4 (n_cg still falls "
+                         "by 6 %% over iterations 10-60 there)")
     ap.add_argument("--config", default="config3", choices=sorted(CONFIGS))
     ap.add_argument("--storage", default="auto",
                     choices=["auto", "csr", "tiled"])
@@ -79,11 +80,13 @@ def parse_args(argv=None):
                          "inside the X~ v kernel, bbx_design_set_cg_fold) on / "
                          "off; default: the library's rule (on up to 250 000 "
                          "rows)")
-    ap.add_argument("--timing-blocks", default="first",
+    ap.add_argument("--timing-blocks", default="all",
                     choices=["first", "all", "none"],
-                    help="A/B of the block-0 bias (LABNOTES R5.1): which of the "
-                         "`repeat` blocks run with the kernel stamps on; the "
-                         "line's `roofline` needs 'first' or 'all'")
+                    help="which of the `repeat` blocks run with the kernel "
+                         "stamps on (LABNOTES R5.1: a stamped launch costs ~8 us; "
+                         "with 'first' block 0 alone paid for them, 4 %% at "
+                         "config 2); the line's `roofline` is measured in block "
+                         "0 and needs 'first' or 'all'")
     ap.add_argument("--timing-every", type=int, default=16,
                     help="one launch in N carries kernel stamps")
     ap.add_argument("--repeat", type=int, default=5,
@@ -490,7 +493,7 @@ def main():
              % _lib.builder_threads())
     K, W, B = args.steps, args.warmup, args.burnin
     if B is None:
-        B = 10 if dense else 300
+        B = 100 if dense else 300
     torch.cuda.synchronize()
     t_b = time.perf_counter()
     ncg_b = chain.run_device(B)[2] if B > 0 else np.zeros(0)
@@ -558,6 +561,8 @@ def main():
     block_values = [world * K / elapsed]
     block_ncg = [float(ncg.mean())]
     for _ in range(max(args.repeat - 1, 0)):
+        if args.timing_blocks == "all":
+            design.reset_timing()      # (hands the event pairs back to the pool)
         chains.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -568,6 +573,8 @@ def main():
         dt_r = chains.max_over_ranks(time.perf_counter() - t0)
         block_values.append(world * K / dt_r)
         block_ncg.append(float(ncg_r.mean()))
+    if args.timing_blocks == "all":
+        design.set_timing(False)
     # set-up cost of EVERY rank (eight generators and eight layout builders
     # run side by side on one host at config 5)
     rss_mb = int(__import__("resource").getrusage(
@@ -616,7 +623,8 @@ def main():
         if dense and fused_b:
             # inside the CG loop family 0 is the single-pass operator kernel
             per["dot"]["bytes"] = fused_b
-            per["dot"]["gbs"] = fused_b / per["dot"]["avg_ms"] / 1e6
+            per["dot"]["gbs"] = fused_b / per["dot"]["avg_ms"] / 1e6 \
+                if per["dot"]["avg_ms"] > 0 else 0.
         dom = "dot" if timing["dot"][1] >= timing["tdot"][1] else "tdot"
         ach = per[dom]["gbs"]
         traffic, traffic_src = committed_traffic(design, dom, args.config)
@@ -760,13 +768,21 @@ def main():
             "repeat": {
                 "what": "the timed K-step block run %d times back to back "
                         "(block 0 is `value`); Gibbs iters/sec of each and "
-                        "their median" % len(block_values),
+                        "their median; us_per_cg_iter = a block's wall time per "
+                        "CG iteration of one chain (n_cg differs from block to "
+                        "block, the cost of an iteration does not)"
+                        % len(block_values),
                 "values": [round(v, 2) for v in block_values],
                 "median": round(float(np.median(block_values)), 2),
                 "spread_pct": round(100. * (max(block_values)
                                             - min(block_values))
                                     / float(np.median(block_values)), 2),
-                "mean_n_cg_iter": [round(v, 2) for v in block_ncg]},
+                "mean_n_cg_iter": [round(v, 2) for v in block_ncg],
+                # a block's time follows its CG iterations: this is what is
+                # flat from block to block (LABNOTES R5.1)
+                "us_per_cg_iter": [round(1e6 * world / v / max(c, 1e-9), 2)
+                                   for v, c in zip(block_values, block_ncg)],
+                "kernel_stamps": args.timing_blocks},
         }
         if state is not None and widths:
             # (an extra block beside the headline: it must never cost the line)
