@@ -76,6 +76,9 @@ def _declare(lib):
         "bbx_design_storage_bytes": ([hp, POINTER(c_int64)], c_int),
         "bbx_design_matvec_bytes": (
             [hp, POINTER(c_int64), POINTER(c_int64)], c_int),
+        "bbx_design_useful_bytes": (
+            [hp, POINTER(c_int64), POINTER(c_int64), POINTER(c_double),
+             POINTER(c_double)], c_int),
         "bbx_design_timed_bytes": (
             [hp, POINTER(c_int64), POINTER(c_int64)], c_int),
         "bbx_design_fused_operator_bytes": ([hp, POINTER(c_int64)], c_int),

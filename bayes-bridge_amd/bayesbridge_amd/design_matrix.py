@@ -122,6 +122,17 @@ class HipDesignMatrix():
         return int(a.value), int(b.value)
 
     @property
+    def useful_bytes(self):
+        """((dot, Tdot) bytes the timed kernels would move without padding and
+        schedules, (padding share of the id stream of X, of X^T))."""
+        from ctypes import c_double
+        a, b = c_int64(), c_int64()
+        pa, pb = c_double(), c_double()
+        _lib.check(self._lib.bbx_design_useful_bytes(
+            self._h, byref(a), byref(b), byref(pa), byref(pb)))
+        return (int(a.value), int(b.value)), (pa.value, pb.value)
+
+    @property
     def cg_launches(self):
         """Kernel launches per CG iteration on this design (3: direction step
         folded into the X~ v kernel, update into the Tdot epilogue)."""

@@ -1013,6 +1013,25 @@ int bbx_design_timed_bytes(const bbx_design* h, int64_t* dot_bytes,
   return matvec_bytes_impl(h, true, dot_bytes, tdot_bytes);
 }
 
+int bbx_design_useful_bytes(const bbx_design* h, int64_t* dot_bytes,
+                            int64_t* tdot_bytes, double* pad_dot,
+                            double* pad_tdot) {
+  BBX_TRY(check_handle(h));
+  int64_t db = 0, tb = 0;
+  double pd = 0., pt = 0.;
+  if (h->sparse && h->format == BBX_FORMAT_TILED && !h->hybrid) {
+    BBX_TRY(tiled_useful_bytes(h, &db, &tb, &pd, &pt));
+  } else {
+    // the other layouts store no padding: what the timed kernels move
+    BBX_TRY(matvec_bytes_impl(h, true, &db, &tb));
+  }
+  if (dot_bytes) *dot_bytes = db;
+  if (tdot_bytes) *tdot_bytes = tb;
+  if (pad_dot) *pad_dot = pd;
+  if (pad_tdot) *pad_tdot = pt;
+  return BBX_OK;
+}
+
 int bbx_design_set_cg_fold(bbx_design* h, int on) {
   BBX_TRY(check_handle(h));
   h->cg_fold = on < 0 ? -1 : (on ? 1 : 0);

@@ -464,6 +464,8 @@ int dense_batch_predict(const bbx_design* h, int K, double* speedup);
 // without the epilogue kernel's slab read and P-vector output)
 int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
                        int64_t* tdot_bytes, bool timed_only = false);
+int tiled_useful_bytes(const bbx_design* h, int64_t* dot_bytes,
+                       int64_t* tdot_bytes, double* pad_dot, double* pad_tdot);
 int64_t tiled_storage_bytes(const bbx_design* h);
 // 1 when the design is stored split by value (HybridParts), else 0
 int tiled_hybrid_info(const bbx_design* h, int64_t* ones_nnz,

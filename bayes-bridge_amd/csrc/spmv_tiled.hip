@@ -2296,6 +2296,28 @@ int tiled_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
   return BBX_OK;
 }
 
+// What the TIMED kernels move that a reader of the matrix cannot do without:
+// the ids of the stored entries at the layout's rate (2 bytes, or 1.6 in groups
+// of five; + 8 for a stored value), the row ids of the slices, the vector in and
+// the output -- no padding of the steps, no schedules.  *pad_* = the share of the
+// id (and value) stream that is padding.
+int tiled_useful_bytes(const bbx_design* h, int64_t* dot_bytes,
+                       int64_t* tdot_bytes, double* pad_dot, double* pad_tdot) {
+  const TiledPair* tp = static_cast<const TiledPair*>(h->tiled);
+  if (h->hybrid || !tp) return fail(BBX_ERR_STATE, "plain tiled designs only");
+  auto ids = [](const TiledMatrix& m, double* pad) {
+    const double per_entry = (m.packed ? 1.6 : 2.0) + (m.has_vals ? 8. : 0.);
+    const double useful = per_entry * (double)m.nnz;
+    const double moved = (double)m.n_quad * 64. * 16. * (m.has_vals ? 5. : 1.);
+    if (pad) *pad = moved > 0. ? 1. - useful / moved : 0.;
+    return (int64_t)useful + (int64_t)m.n_slice * 256;
+  };
+  *dot_bytes = ids(tp->x, pad_dot) + 8 * (h->P + h->n) +
+               (tp->x.G > 1 ? 16 * tp->x.G * h->n : 0);
+  *tdot_bytes = ids(tp->xt, pad_tdot) + 8 * h->n + 8 * (int64_t)tp->xt.G * h->p;
+  return BBX_OK;
+}
+
 int tiled_hybrid_info(const bbx_design* h, int64_t* ones_nnz,
                       int64_t* rest_nnz, int64_t* dense_nnz, int* kd) {
   const HybridParts* hp = static_cast<const HybridParts*>(h->hybrid);

@@ -96,6 +96,9 @@ struct PanelBuild {
   std::vector<int64_t> wg_critical;  // sum over tiles of the busiest wave
   std::vector<int64_t> wg_total;     // all waves, all tiles
   int64_t dup_quads = 0;             // quads re-loaded to fill a batch
+  // where the padding of the id stream comes from, in entry slots
+  int64_t pad_round = 0;   // a row segment rounds up to whole steps (4 / 5 entries)
+  int64_t pad_slice = 0;   // a slice is as long as its longest row, 128 rows wide
 };
 
 // Per-wave schedules of one panel: for every workgroup (group of column
@@ -609,6 +612,16 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
     for (int base = 0; base < n_rows; base += SLICE_ROWS) {
       const int rows_in = std::min(SLICE_ROWS, n_rows - base);
       const uint32_t nq = (uint32_t)sorted[base].steps;  // longest row
+      {
+        const int per_step = packed ? 5 : 4;
+        int64_t steps_rows = 0;
+        for (int i = 0; i < rows_in; ++i) {
+          steps_rows += sorted[base + i].steps;
+          pb.pad_round += (int64_t)sorted[base + i].steps * per_step -
+                          sorted[base + i].len;
+        }
+        pb.pad_slice += ((int64_t)nq * SLICE_ROWS - steps_rows) * per_step;
+      }
       SliceMeta sm;
       sm.first_quad = (uint32_t)(pb.ids.size() / LANES);
       sm.n_quad = nq;
@@ -1004,7 +1017,10 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   if (opt.stats) {
     int64_t crit_max = 0, total = 0, dup = 0, quads = 0, n_wg = 0, crit_sum = 0;
     int stat_extra = 0, stat_T = 0;
+    int64_t pad_round = 0, pad_slice = 0;
     for (auto& pb : pbs) {
+      pad_round += pb.pad_round;
+      pad_slice += pb.pad_slice;
       for (size_t g = 0; g < pb.wg_critical.size(); ++g) {
         crit_max = std::max(crit_max, pb.wg_critical[g]);
         crit_sum += pb.wg_critical[g];
@@ -1019,19 +1035,27 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
       if (pb.split_T > 0 && (stat_T == 0 || pb.split_T < stat_T))
         stat_T = pb.split_T;
     }
-    char line[1024];
+    char line[1536];
     snprintf(line, sizeof(line),
             "[bbx tiled %lldx%lld K=%d] W=%d blocks=%d PR=%d G=%d split T=%d "
             "extras=%d workgroups=%lld: "
             "quads=%lld (+%lld re-loaded to fill batches, %.1f%%); batches per "
             "wave: ideal %.1f, mean critical path %.1f, worst workgroup %lld "
-            "(%.1f%% over ideal)\n",
+            "(%.1f%% over ideal); padding of the id stream: %.1f%% = %.1f%% rows "
+            "rounded up to whole steps + %.1f%% slices as long as their longest "
+            "row\n",
             (long long)R, (long long)C, K, m.W, m.n_block, m.PR, m.G, stat_T,
             stat_extra, (long long)n_wg, (long long)quads, (long long)dup,
             100. * (double)dup / (double)std::max<int64_t>(quads, 1),
             (double)total / (double)(n_wg * TILE_WAVES),
             (double)crit_sum / (double)n_wg, (long long)crit_max,
-            100. * ((double)crit_max * n_wg * TILE_WAVES / (double)total - 1.));
+            100. * ((double)crit_max * n_wg * TILE_WAVES / (double)total - 1.),
+            100. * (double)(pad_round + pad_slice) /
+                (double)std::max<int64_t>(quads * SLICE_ROWS * (packed ? 5 : 4), 1),
+            100. * (double)pad_round /
+                (double)std::max<int64_t>(quads * SLICE_ROWS * (packed ? 5 : 4), 1),
+            100. * (double)pad_slice /
+                (double)std::max<int64_t>(quads * SLICE_ROWS * (packed ? 5 : 4), 1));
     m.stats = line;
     fputs(line, stderr);
   }

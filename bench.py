@@ -627,6 +627,14 @@ def main():
                 if per["dot"]["avg_ms"] > 0 else 0.
         dom = "dot" if timing["dot"][1] >= timing["tdot"][1] else "tdot"
         ach = per[dom]["gbs"]
+        # the same launch on the bytes a reader cannot do without: no padding of
+        # the 16-byte steps, no schedules (bbx_design_useful_bytes)
+        (use_dot, use_tdot), (pad_dot, pad_tdot) = design.useful_bytes
+        if dense and fused_b:
+            use_dot = fused_b
+        useful_b = use_dot if dom == "dot" else use_tdot
+        useful_gbs = useful_b / per[dom]["avg_ms"] / 1e6 \
+            if per[dom]["avg_ms"] > 0 else 0.
         traffic, traffic_src = committed_traffic(design, dom, args.config)
         # whole operator application (dot + Tdot + epilogue kernel)
         op_cnt, op_ms = timing["operator"]
@@ -671,6 +679,11 @@ def main():
             kernel=kernel_name,
             avg_launch_ms=round(per[dom]["avg_ms"], 5),
             algorithmic_bytes_per_launch=per[dom]["bytes"],
+            useful_bytes_per_launch=int(useful_b),
+            useful_frac=round(useful_gbs / HBM_PEAK_GBS, 4),
+            useful_what="the launch's bytes without the padding of the id "
+                        "steps and without the schedules: stored entries x "
+                        "index bytes + row ids + vector in + output",
             timing="kernel begin/end stamps (hipExtLaunchKernelGGL events) on "
                    "the launching stream, one launch in 16, inside the timed "
                    "region" if design.storage_format == "tiled" else
@@ -733,6 +746,11 @@ def main():
                 "id_format": {k: ("groups of 5 / 8 B" if v["packed"]
                                   else "4 ids / 8 B") for k, v in
                               design.tiled_info().items()}
+                if design.storage_format == "tiled" else None,
+                # share of the id stream that is padding (steps are 16 bytes
+                # per lane: a row segment rounds up to whole groups / quads, a
+                # slice to its longest row)
+                "id_padding": {"X": round(pad_dot, 4), "Xt": round(pad_tdot, 4)}
                 if design.storage_format == "tiled" else None,
                 "init": "coef=0 + intercept MLE, global_scale=.01, then %d "
                         "untimed burn-in iterations (in place of the "

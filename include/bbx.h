@@ -179,6 +179,18 @@ int bbx_design_matvec_bytes(const bbx_design* h, int64_t* dot_bytes,
  * (the epilogue's slab read and its P-vector output are not counted here). */
 int bbx_design_timed_bytes(const bbx_design* h, int64_t* dot_bytes,
                            int64_t* tdot_bytes);
+/* The USEFUL part of bbx_design_timed_bytes: the stored entries at the
+ * layout's index rate (tiled: 2 bytes per entry, 1.6 in groups of five, + 8 per
+ * stored value -- no padding of the 16-byte steps, no schedules), the slices'
+ * row ids, the vector in, the output.  *pad_dot / *pad_tdot = the share of the
+ * id (and value) stream of X / X^T that is padding (0 for layouts without).
+ * SURVEY.md 8(d) credits a kernel with the bytes it moves; this is the figure
+ * beside it that a format with less padding would also have to move.  Mixed
+ * designs (bbx_design_hybrid_info) and the other layouts report the timed
+ * bytes.  Any output pointer may be NULL. */
+int bbx_design_useful_bytes(const bbx_design* h, int64_t* dot_bytes,
+                            int64_t* tdot_bytes, double* pad_dot,
+                            double* pad_tdot);
 /* Kernel launches per CG iteration of bbx_cg_sample / the chains on this design
  * (the loop of scipy.sparse.linalg.cg called at cg_sampler.py:77-80): 3 where
  * the direction step rides in the X~ v kernel and the update in the X~^T w
