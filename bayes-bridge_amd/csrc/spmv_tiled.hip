@@ -89,6 +89,7 @@ struct TiledMatrix {
   DevMem vals;       // double[n_quad * 64 * 8] when has_vals
   DevMem descs;      // BatchDesc[n_desc]: per-wave schedules
   DevMem wave_desc;  // int32[n_panel * G * 16]: first descriptor of each wave
+  DevMem wg_quad0;   // uint32[n_panel * G]: first step of each workgroup's stretch
   int desc_stride = 0;  // > 0: wave k's schedule starts at k * desc_stride
   int64_t n_desc = 0;
   DevMem rowids;     // uint32[n_slice * 64]: panel-local rows A | B << 16
@@ -344,7 +345,8 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     int64_t R, int64_t C, int W, int PR, int G, int blocks_per_group,
     const int32_t* __restrict__ wave_desc, int desc_stride,
     const BatchDesc* __restrict__ descs, const uint32_t* __restrict__ rowids,
-    const uint4* __restrict__ ids, const double* __restrict__ vals,
+    const uint32_t* __restrict__ wg_quad0,
+    const uint4* __restrict__ ids_all, const double* __restrict__ vals_all,
     const double* __restrict__ x,
     // epilogue (direct mode, G == 1 and out != nullptr):
     //   out[r] = rowscale[r] * (c0 - sum(c_part) + acc)
@@ -395,6 +397,12 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
   const int bid = panel * G + group;
   const int64_t row0 = (int64_t)panel * PR;
   const int rows_here = (int)((R - row0 < PR) ? (R - row0) : PR);
+  // This workgroup's stretch of the id (and value) stream: a 64-bit base, the
+  // schedules' steps count from it and every byte offset below is 32-bit --
+  // the stream as a whole may exceed 4 GiB (a valued design of 6e8 entries: 38 GB)
+  const size_t wg_q0 = (size_t)wg_quad0[bid];
+  const uint4* __restrict__ ids = ids_all + wg_q0 * WAVE;
+  const double* __restrict__ vals = VALS ? vals_all + wg_q0 * WAVE * 8 : nullptr;
 
   if constexpr (KP > 0) {
     const v2d zero2 = {0., 0.};
@@ -1184,6 +1192,8 @@ static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
                  host.descs.size() * sizeof(BatchDesc)));
   BBX_TRY(upload(m.wave_desc, host.wave_desc.data(),
                  host.wave_desc.size() * sizeof(int32_t)));
+  BBX_TRY(upload(m.wg_quad0, host.wg_quad0.data(),
+                 host.wg_quad0.size() * sizeof(uint32_t)));
   BBX_TRY(upload(m.rowids, host.rowids.data(),
                  host.rowids.size() * sizeof(uint32_t)));
   BBX_TRY(m.slab.alloc(sizeof(double) * (size_t)m.G * (size_t)R * (size_t)m.K));
@@ -1578,6 +1588,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                      m.G, (m.n_block + m.G - 1) / m.G,                         \
                      m.wave_desc.as<int32_t>(), m.desc_stride,                 \
                      m.descs.as<BatchDesc>(), m.rowids.as<uint32_t>(),         \
+                     m.wg_quad0.as<uint32_t>(),                                \
                      m.ids.as<uint4>(), VALPTR, x, c_part, x0_ptr, rowscale,   \
                      out, slab, m.PR + m.n_extra,                              \
                      m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),       \

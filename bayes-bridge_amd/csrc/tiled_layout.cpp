@@ -92,6 +92,7 @@ struct PanelBuild {
   int split_T = 0;
   std::vector<BatchDesc> descs;   // quad0/row_slot local to the panel
   std::vector<int32_t> wave_desc; // [G * TILE_WAVES] local start of each wave
+  std::vector<uint32_t> wg_quad0; // [G] first step of each workgroup (panel-local)
   // schedule statistics (BBX_TILED_STATS): per workgroup, in batches
   std::vector<int64_t> wg_critical;  // sum over tiles of the busiest wave
   std::vector<int64_t> wg_total;     // all waves, all tiles
@@ -122,9 +123,13 @@ static void build_schedules(PanelBuild& pb, int G, int batch) {
   new_rowids.reserve(pb.rowids.size());
   new_slices.reserve(pb.slices.size());
   if (has_vals) new_vals.reserve(pb.vals.size());
+  pb.wg_quad0.assign((size_t)G, 0u);
   for (int g = 0; g < G; ++g) {
     const size_t t0 = tile_cursor, t1 = tile_cursor + pb.group_tile_count[g];
     tile_cursor = t1;
+    // (a workgroup's steps are one contiguous stretch of the re-laid stream)
+    const uint32_t wg_first = (uint32_t)(new_ids.size() / LANES);
+    pb.wg_quad0[(size_t)g] = wg_first;
     // tile_deal[t - t0][w] = slices of tile t handled by wave w
     std::vector<std::vector<std::vector<int>>> tile_deal(t1 - t0);
     for (size_t t = t0; t < t1; ++t) {
@@ -190,7 +195,7 @@ static void build_schedules(PanelBuild& pb, int G, int batch) {
                             pb.rowids.begin() + (size_t)(sl + 1) * LANES);
           for (uint32_t q0 = 0; q0 < sm.n_quad; q0 += (uint32_t)batch) {
             BatchDesc d;
-            d.quad0 = sm.first_quad + q0;
+            d.quad0 = sm.first_quad + q0 - wg_first;   // workgroup-relative
             d.row_slot = new_sl * LANES;
             const uint32_t left = sm.n_quad - q0;
             d.info = left < (uint32_t)batch ? left : (uint32_t)batch;
@@ -1073,6 +1078,7 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   std::vector<double> vv(m.has_vals ? tot_ids * 8 : 0);
   std::vector<BatchDesc> descs(tot_descs);
   std::vector<int32_t> wave_desc((size_t)m.n_panel * m.G * TILE_WAVES, 0);
+  std::vector<uint32_t> wg_quad0((size_t)m.n_panel * m.G, 0u);
   std::vector<uint32_t> rowids(tot_slices * LANES);
   std::vector<FoldDesc> folds;
   std::vector<int32_t> panel_fold((size_t)m.n_panel + 1, 0);
@@ -1096,12 +1102,12 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
       memcpy(&vv[id_off * 8], pb.vals.data(), pb.vals.size() * sizeof(double));
     for (size_t k = 0; k < pb.descs.size(); ++k) {
       BatchDesc d = pb.descs[k];
-      if (d.info & 15u) {
-        d.quad0 += (uint32_t)(id_off / LANES);
-        d.row_slot += (uint32_t)(sl_off * LANES);
-      }
+      // (quad0 stays relative to the workgroup's first step)
+      if (d.info & 15u) d.row_slot += (uint32_t)(sl_off * LANES);
       descs[de_off + k] = d;
     }
+    for (size_t g = 0; g < pb.wg_quad0.size(); ++g)
+      wg_quad0[(size_t)p * m.G + g] = pb.wg_quad0[g] + (uint32_t)(id_off / LANES);
     for (size_t k = 0; k < pb.wave_desc.size(); ++k)
       wave_desc[(size_t)p * m.G * TILE_WAVES + k] =
           pb.wave_desc[k] + (int32_t)de_off;
@@ -1119,10 +1125,21 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   m.n_slice = (int64_t)tot_slices;
   m.n_tile = (int64_t)tot_tiles;
   m.n_desc = (int64_t)tot_descs;
-  // the kernel addresses the streams with 32-bit byte offsets
-  if ((uint64_t)tot_ids * (m.has_vals ? 64u : 16u) >= ((uint64_t)1 << 32))
-    return fail("matrix too large for the tiled format");
-  if (tot_slices * LANES >= ((size_t)1 << 31) || tot_descs >= ((size_t)1 << 31))
+  // The kernel addresses the id and value streams with 32-bit byte offsets
+  // INSIDE a workgroup's stretch (64-bit base per workgroup, wg_quad0): what
+  // must stay below 4 GiB is one workgroup's share, not the stream.
+  {
+    size_t longest = 0;
+    for (size_t k = 0; k < wg_quad0.size(); ++k) {
+      const size_t end = k + 1 < wg_quad0.size() ? (size_t)wg_quad0[k + 1]
+                                                 : tot_ids / LANES;
+      longest = std::max(longest, end - (size_t)wg_quad0[k]);
+    }
+    if ((uint64_t)longest * LANES * (m.has_vals ? 64u : 16u) >= ((uint64_t)1 << 32))
+      return fail("matrix too large for the tiled format");
+  }
+  // (row ids: 32-bit byte offsets from the start of the array)
+  if (tot_slices * LANES >= ((size_t)1 << 30) || tot_descs >= ((size_t)1 << 31))
     return fail("matrix too large for the tiled format");
   {  // equal-stride schedules when the padding stays small
     const size_t n_wave = wave_desc.size();
@@ -1165,6 +1182,7 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   m.vals.swap(vv);
   m.descs.swap(descs);
   m.wave_desc.swap(wave_desc);
+  m.wg_quad0.swap(wg_quad0);
   m.rowids.swap(rowids);
   m.folds.swap(folds);
   m.panel_fold.swap(panel_fold);
@@ -1273,7 +1291,8 @@ void emulate_tiled_spmv(const TiledHost& m, const double* x,
           first = false;
           const int cnt = (int)(d.info & 15u);
           for (int u = 0; u < cnt; ++u) {
-            const size_t q = (size_t)d.quad0 + (size_t)u;
+            const size_t q = (size_t)m.wg_quad0[(size_t)wg] + (size_t)d.quad0 +
+                             (size_t)u;
             for (int l = 0; l < LANES; ++l) {
               const size_t at = q * LANES + (size_t)l;
               if (m.packed)

@@ -77,7 +77,11 @@ struct SliceMeta {
 // slice.  The schedule of every (workgroup, wave) is laid out in processing
 // order, so the kernel's issue cursor is a single scalar index.
 struct BatchDesc {
-  uint32_t quad0;     // first step (units of 64 x 16 bytes in the id stream)
+  uint32_t quad0;     // first step (units of 64 x 16 bytes), counted from the
+                      // first step of the WORKGROUP's stretch of the stream
+                      // (TiledHost::wg_quad0): the kernel forms 64-bit bases per
+                      // workgroup and 32-bit byte offsets inside them, so a
+                      // stream may exceed 4 GiB
   uint32_t row_slot;  // slice * 64: where the slice's row-id pairs start
   uint32_t info;      // bits 0-3 count, 8 last-of-slice, 9 tile-first, 10 end
   uint32_t pad;
@@ -128,6 +132,7 @@ struct TiledHost {
   std::vector<double> vals;         // [n_quad * 64 * 8] when has_vals
   std::vector<BatchDesc> descs;     // per-wave schedules (+ 2 blocks of END)
   std::vector<int32_t> wave_desc;   // [n_panel * G * TILE_WAVES]
+  std::vector<uint32_t> wg_quad0;   // [n_panel * G] first step of each workgroup
   std::vector<uint32_t> rowids;     // [n_slice * 64]: panel-local rows A | B<<16
   std::vector<FoldDesc> folds;
   std::vector<int32_t> panel_fold;  // [n_panel + 1]
