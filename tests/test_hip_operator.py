@@ -349,14 +349,17 @@ def test_mixed_design_of_the_reference_helper_is_stored_split():
     assert np.abs(c_h - c_o).max() <= tol * max(1., np.abs(c_o).max())
 
 
-@pytest.mark.parametrize("n_dense", [1, 5, 8, 9, 20])
+@pytest.mark.parametrize("n_dense", [1, 5, 8, 9, 20, 127, 130, 300, 700])
 def test_dense_columns_ride_in_the_dot_epilogue_of_an_operator_application(n_dense):
     """Binary covariates plus a few continuous ones (the OHDSI shape).  Inside
     ONE operator application X~^T (Omega (X~ v)) -- bbx_design_gram_matvec and
     the CG loop -- up to 8 dense columns are handled by the value-free X~ v
     kernel's epilogue (csrc/common.hpp DenseEpi: t += D v_D, and the partials of
     D^T (Omega t) for the transposed product), instead of three kernels of their
-    own; more than 8 take the separate kernels (measured crossover).  Against the two separate
+    own; 9 ... 1024 take ONE pass over a row-major copy of the dense block
+    (hyb_dense_fused_kernel: a wave per row, 1 / 2 / 4 / 8 column pairs per
+    lane -- 127, 130, 300 and 700 columns cross those widths), more the two
+    separate kernels.  Against the two separate
     products (which never use the fused epilogue) and NumPy; a CG draw against
     the oracle; bitwise repeatable."""
     import scipy.sparse as sparse
