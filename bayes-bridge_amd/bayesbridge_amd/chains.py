@@ -189,6 +189,8 @@ def run_chains(bridge, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
                        on the number of ranks and on the chosen width;
       int k            batches of exactly k where k chains are left (k = 2, 4
                        sparse; 2 ... 32 dense), the rest alone; same caveat.
+                       Built even where the library's cost model prices the
+                       width below single chains (`allow_slow`).
     The decision is recorded per chain in mcmc_info['batch'] = {'requested':
     batch, 'width': w, 'slot': i} (width 1: run alone).
 
@@ -234,10 +236,14 @@ def run_chains(bridge, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
         width = pick_width(len(todo))
         if width >= 2:
             group, todo = todo[:width], todo[width:]
+            # (an explicit integer width is the caller's decision: it also
+            # builds a width the library's cost model prices below single
+            # chains, e.g. four sparse chains at 1M x 50k; 'auto' never asks
+            # for such a width)
             results = bridge.gibbs_batch(
                 [chain_seed(seed, k) for k in group], n_iter, n_burnin, thin,
                 init=copy.deepcopy(init), params_to_save=params_to_save,
-                options=options)
+                options=options, allow_slow=batch != 'auto')
             for k, (samples, info) in zip(group, results):
                 info['batch']['requested'] = batch
                 keep(k, samples, info)

@@ -731,6 +731,7 @@ static int gram_matvec_device(bbx_design* h, const double* d_obs_prec,
     ~OperatorScope() { h->in_operator = false; }
   } op_scope{h};
   h->in_operator = true;
+  h->operator_serial += 1;
   BBX_TRY(launch_dot(h, d_v, d_obs_prec, t, part_slot(h, PS_SUMW)));
   return launch_tdot(h, t, part_slot(h, PS_SUMW), ep, d_out);
 }

@@ -642,14 +642,32 @@ extern "C" {
 int bbx_batch_predict(bbx_design* design, int n_chain, double* speedup) {
   if (!design || !speedup) return fail(BBX_ERR_INVALID, "NULL argument");
   *speedup = 0.;
-  if (design->sparse) return tiled_batch_predict(design, n_chain, speedup);
-  if (n_chain != 2 && n_chain != 4 && n_chain != 8 && n_chain != 16 &&
-      n_chain != 32)
-    return fail(BBX_ERR_INVALID, "a batch holds 2, 4, 8, 16 or 32 chains");
-  if (!dense_batch_applies(design))
-    return fail(BBX_ERR_STATE,
-                "batched chains: this dense layout is not supported");
-  return dense_batch_predict(design, n_chain, speedup);
+  if (!design_alive(design))
+    return fail(BBX_ERR_INVALID, "not a live design handle");
+  int slot = -1;
+  for (int k = 0, w = 2; k < 5; ++k, w *= 2)
+    if (n_chain == w) slot = k;
+  if (slot < 0 || (design->sparse && n_chain > 4))
+    return fail(BBX_ERR_INVALID, design->sparse
+                                     ? "sparse designs batch 2 or 4 chains"
+                                     : "a batch holds 2, 4, 8, 16 or 32 chains");
+  // (asked per candidate width on every round of run_chains(batch='auto') and
+  // again by bbx_batch_create: the answer of a design does not change)
+  if (design->batch_speedup[slot] >= 0.) {
+    *speedup = design->batch_speedup[slot];
+    return BBX_OK;
+  }
+  BBX_HIP(hipSetDevice(design->device));
+  if (design->sparse) {
+    BBX_TRY(tiled_batch_predict(design, n_chain, speedup));
+  } else {
+    if (!dense_batch_applies(design))
+      return fail(BBX_ERR_STATE,
+                  "batched chains: this dense layout is not supported");
+    BBX_TRY(dense_batch_predict(design, n_chain, speedup));
+  }
+  design->batch_speedup[slot] = *speedup;
+  return BBX_OK;
 }
 
 int bbx_batch_create(bbx_design* design, int n_chain, bbx_chain* const* chains,

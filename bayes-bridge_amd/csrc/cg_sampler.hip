@@ -110,6 +110,7 @@ static int apply_operator(bbx_design* h, const double* d_omega,
     ~OperatorScope() { h->in_operator = false; }
   } op_scope{h};
   h->in_operator = true;
+  h->operator_serial += 1;
   BBX_TRY(timer_begin(h, 2));  // family 2: the whole application (sampled)
   if (!h->sparse && dense_fused_applies(h)) {
     // f32 dense designs: both products in one pass over the matrix

@@ -211,6 +211,9 @@ struct bbx_design {
   // layouts sized for 2 and 4 right-hand sides (batched chains), built on
   // first use from the CSR arrays above
   void* tiled_k[2] = {nullptr, nullptr};
+  // bbx_batch_predict's answers, per width slot (2, 4, 8, 16, 32); < 0: not
+  // asked yet.  (The sparse model fetches two index arrays from the device.)
+  double batch_speedup[5] = {-1., -1., -1., -1., -1.};
 
   bbx::DevMem offset;  // column means (p), zeros when not centred
 
@@ -229,6 +232,10 @@ struct bbx_design {
   // design's dense block can ride in the dot kernel's epilogue for both
   // products (spmv_tiled.hip DenseEpi) instead of three kernels of its own.
   bool in_operator = false;
+  // counts operator applications: what the dot kernel of ONE application leaves
+  // for its Tdot (a mixed design's D^T t partials) is tagged with it, so that
+  // nothing of an earlier application -- a re-used buffer address -- is consumed
+  uint64_t operator_serial = 0;
   // direction step folded into the X~ v kernel (DotFold): -1 = the default
   // (by size; BBX_CG_FOLD=0|1 for the process), 0 / 1 = bbx_design_set_cg_fold
   int cg_fold = -1;

@@ -147,6 +147,7 @@ struct HybridParts {
   // left by the X~ v kernel's epilogue, one row of kd per workgroup
   DevMem dw_part;        // double[NPART][kd]
   const double* dw_for = nullptr;  // the t they belong to (consumed by the next Tdot)
+  uint64_t dw_serial = 0;          // ... of this operator application (bbx_design::operator_serial)
   int dw_chunks = 0;
   DevMem slab;           // double[(G_B + G_S + 1)][p]
   int n_slab = 0;
@@ -1636,8 +1637,10 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
   if (dense) {
     // mixed design inside an operator application: the dense block in the
     // value-free kernel's epilogue (single chain, direct epilogue)
+    // (the epilogue writes one row of kd partials per workgroup into a buffer
+    // of NPART rows: the launch site guards the grid, not only its caller)
     if (m.K != 1 || !wide || m.G != 1 || !out || m.has_vals || addend || fold ||
-        dense->kd < 1 || dense->kd > DENSE_EPI_MAX)
+        dense->kd < 1 || dense->kd > DENSE_EPI_MAX || grid > (unsigned)NPART)
       return fail(BBX_ERR_STATE, "dense epilogue: unsupported launch");
     BBX_TILED_LAUNCH_P(true, false, true);
   } else if (fold) {
@@ -2019,6 +2022,7 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
                            nullptr, d_sum_part, ea, eb, twt_off, nullptr,
                            nullptr, nullptr, &de));
       hp->dw_for = d_t;
+      hp->dw_serial = h->operator_serial;
       hp->dw_chunks = mb.n_panel * mb.G;
       return BBX_OK;
     }
@@ -2074,6 +2078,7 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
 #undef BBX_HYB_FUSED
       BBX_HIP(hipGetLastError());
       hp->dw_for = d_t;
+      hp->dw_serial = h->operator_serial;
       hp->dw_chunks = NPART;
       return timer_end(h, 0);
     }
@@ -2142,7 +2147,10 @@ static int launch_tdot_hybrid(bbx_design* h, const double* d_w,
                          slab + (size_t)at * (size_t)h->p, nullptr));
     at += ms.G;
   }
-  if (hp->kd > 0 && hp->dw_for == d_w) {
+  // (valid for the Tdot of the SAME operator application only; a kernel that
+  // rewrote t between the two products would have to clear dw_for)
+  if (hp->kd > 0 && hp->dw_for == d_w && h->in_operator &&
+      hp->dw_serial == h->operator_serial) {
     // the preceding X~ v kernel of this operator application left the partials
     // of D^T w, one row per workgroup: only the fixed-order sum is left to do
     hipLaunchKernelGGL(hyb_dense_scatter_kernel, dim3((unsigned)hp->kd),
