@@ -120,7 +120,7 @@ constexpr int HYB_FUSED_MAX_KD = 1024; // widest dense block of the single-pass 
 // WHOLE matrix to the valued layout (10 bytes per entry instead of 2.4: 4x the
 // time per product).  Instead the entries are split by value at construction:
 //   B  every entry equal to 1.0            value-free tiled layout
-//   D  the other entries of columns that hold many of them (>= n / 16): a
+//   D  the other entries of columns that hold many of them (>= n / 2): a
 //      dense column-major block n x kd in f64 (a continuous covariate is a
 //      dense column)
 //   S  what is left                        valued tiled layout (often empty)
@@ -1319,7 +1319,10 @@ static int build_hybrid(bbx_design* h) {
   std::vector<int64_t> c_one((size_t)p, 0), c_val((size_t)p, 0);
   for (int64_t k = 0; k < nnz; ++k)
     (cx.vals[(size_t)k] == 1.0 ? c_one : c_val)[(size_t)cx.colidx[(size_t)k]] += 1;
-  const int64_t dense_min = std::max<int64_t>(n / 16, 1);
+  // a dense column: at least half of its rows hold a value other than 1.0 (a
+  // continuous covariate; it is stored as n doubles, so a sparser column costs
+  // more in the block than in the valued layout's 10 bytes per entry)
+  const int64_t dense_min = std::max<int64_t>(n / 2, 1);
   std::vector<uint8_t> is_dense((size_t)p, 0);
   std::vector<int32_t> dense_cols;
   int64_t ones_nnz = 0, dense_nnz = 0;
@@ -1346,7 +1349,10 @@ static int build_hybrid(bbx_design* h) {
   // Gaussian columns next to 9 000 binary ones, tests/helper.py:13 at scale,
   // are 92 % dense entries and still belong here)
   if (2 * (ones_nnz + dense_nnz) < nnz) return 1;
-  if (dense_nnz == 0 && 4 * ones_nnz < nnz) return 1;
+  // ... and outside the dense block at least a quarter of the entries are ones
+  // (what the value-free layout is for; also keeps designs without a single
+  // 1.0 in the plain valued layout)
+  if (ones_nnz == 0 || 4 * ones_nnz < nnz - dense_nnz) return 1;
   HybridParts* hp = new (std::nothrow) HybridParts();
   if (!hp) return fail(BBX_ERR_INVALID, "out of host memory");
   h->hybrid = hp;  // owned by the handle (destroy_tiled)

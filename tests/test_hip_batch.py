@@ -83,14 +83,32 @@ def test_batched_products_equal_the_cpu_emulator_bitwise(K, shape):
 
 @pytest.mark.parametrize("K", [2, 4])
 def test_batched_products_with_centring_and_intercept(K):
-    """Intercept column and implicit centring per column, against SciPy; valued
-    entries for K = 2 (four valued right-hand sides exceed the register budget
-    and are refused)."""
-    from bayesbridge_amd import BbxError, HipChainBatch
-    for binary_frac in (1., .7):
-        X, y, hip = _problem(6000, 3000, 'linear', binary_frac)
+    """Intercept column and implicit centring per column, against SciPy: a
+    binary design, a mixed one (stored split: value-free kernels), and one whose
+    every entry carries a value -- K = 2 only (four valued right-hand sides
+    exceed the register budget and are refused)."""
+    from bayesbridge_amd import (BbxError, HipChainBatch,
+                                 HipSparseDesignMatrix)
+    for binary_frac in (1., .7, 'valued'):
+        if binary_frac == 'valued':
+            # every stored entry carries a value: the valued layout, no split
+            X, y, _ = _problem(6000, 3000, 'linear', 1.)
+            X = X.copy()
+            X.data = np.random.default_rng(8).uniform(.5, 2., X.nnz)
+            hip = HipSparseDesignMatrix(X, center_predictor=True,
+                                        add_intercept=True, storage='tiled')
+            assert hip.hybrid_info is None
+        else:
+            X, y, hip = _problem(6000, 3000, 'linear', binary_frac)
+        if binary_frac == .7:
+            # 900 Gaussian columns next to 2100 binary ones: stored split (ones
+            # + dense block, no valued rest), so that a batch runs value-free
+            # kernels at either width
+            assert hip.hybrid_info is not None
+            assert hip.hybrid_info['rest_nnz'] == 0
+            assert hip.hybrid_info['dense_cols'] == 900
         chains = _chains(hip, y, 'linear', list(range(K)))
-        if binary_frac < 1. and K == 4:
+        if binary_frac == 'valued' and K == 4:
             with pytest.raises(BbxError):
                 HipChainBatch(chains, allow_slow=True)
             continue

@@ -81,12 +81,12 @@ def test_device_chain_iteration_equals_oracle(family, kind, storage):
     X, y = _problem(family, kind, binary=storage.endswith('+fold'))
     hip = _designs(X, kind, storage)
     if kind == 'sparse' and storage == 'tiled':
-        # binary_frac = .8 of 200 columns: the 40 continuous ones are a dense
+        # binary_frac = .8 of 200 columns: the 39 continuous ones are a dense
         # block that every operator application of the CG loop takes in ONE pass
         # (csrc/spmv_tiled.hip hyb_dense_fused_kernel; up to 8 columns ride in
         # the value-free kernel's epilogue instead)
         assert hip.hybrid_info is not None
-        assert hip.hybrid_info['dense_cols'] == 40
+        assert hip.hybrid_info['dense_cols'] == 39
         assert hip.hybrid_info['rest_nnz'] == 0
     if family == 'logit':
         n_success, n_trial = y
