@@ -75,7 +75,11 @@ RUN_CHAINS_WORKER = textwrap.dedent("""
             return 2 if n_left >= 2 else 0
 
         def gibbs_batch(self, seeds, n_iter, n_burnin, thin, init=None,
-                        params_to_save=None, options=None):
+                        params_to_save=None, options=None, allow_slow=False):
+            # (run_chains: an explicit width is built even where the cost
+            # model refuses it, 'auto' never is)
+            self.allow_slow_seen = getattr(self, 'allow_slow_seen', []) + \
+                [allow_slow]
             out = []
             for slot, sd in enumerate(seeds):
                 s, info = self.gibbs(n_iter, n_burnin, thin, seed=sd)
@@ -103,9 +107,14 @@ RUN_CHAINS_WORKER = textwrap.dedent("""
     # batch='auto' / an explicit width: this rank's chains in pairs, the odd
     # one alone; same seeds, same output slots
     for how in ('auto', 2):
+        fake = FakeBridge()
         merged_b, infos_b = chains.run_chains(
-            FakeBridge(), %(n_chain)d, 8, n_burnin=2, thin=2, seed=111,
+            fake, %(n_chain)d, 8, n_burnin=2, thin=2, seed=111,
             batch=how)
+        # an explicit width is the caller's decision (built even where the
+        # library's cost model prices it below single chains), 'auto' is not
+        assert set(getattr(fake, 'allow_slow_seen', [how != 'auto'])) \
+            == {how != 'auto'}
         mine = chains.split_chains(%(n_chain)d, world, rank)
         assert [i['chain'] for i in infos_b] == mine
         widths = [2] * (len(mine) // 2 * 2) + [1] * (len(mine) %% 2)
