@@ -110,7 +110,8 @@ struct TiledPair {
 };
 
 constexpr int HYB_TDOT_CHUNKS = 256;  // row chunks of the dense block's D^T w
-constexpr int HYB_FUSED_MAX_KD = 1024; // widest dense block of the single-pass kernel
+constexpr int HYB_FUSED_WAVE_KD = 1024; // widest dense block of the wave-per-row kernel
+constexpr int HYB_FUSED_MAX_KD = 4096;  // ... of the workgroup-per-row-block kernel (= the split's cap)
 
 // Mixed designs: X = B + D + S.
 //
@@ -1907,6 +1908,117 @@ __global__ __launch_bounds__(NT) void hyb_dense_fused_kernel(
   }
 }
 
+// The same pass for WIDER dense blocks (1024 < kd <= 4096 columns): a row no
+// longer fits the registers of one wave, so a 1024-thread workgroup takes RB rows
+// at a time (4 up to 2048 columns, 2 beyond: ~48 KB per barrier) -- thread t owns the column pairs t + 1024 k, k < G (1 KiB of
+// contiguous bytes per wave and load instruction) with its slices of v_D and of
+// D^T t in registers, the rows' inner products go through one LDS exchange and
+// ONE barrier per RB rows, the next RB are in flight meanwhile -- the shape of
+// the dense designs' single-pass operator (dense.hip dense_fused_f64_kernel).
+// Every thread owns its columns outright: the workgroup's row of D^T t partials
+// is written without a reduction.
+template <int G, int RB>
+__global__ __launch_bounds__(1024) void hyb_dense_fused_wg_kernel(
+    int64_t n, int kd, int ld_rm, const double* __restrict__ Drm,
+    const int32_t* __restrict__ cols, int intercept,
+    const double* __restrict__ v, const double* __restrict__ a,
+    const double* __restrict__ rowscale, double* __restrict__ t_out,
+    double* __restrict__ sum_part, int twt_off, double* __restrict__ dw_part,
+    const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  constexpr int NW = 1024 / WAVE;
+  __shared__ double red[2][RB][NW];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+  const int ldp = ld_rm / 2;
+  hyb_d2 vo[G], g[G];
+  bool has[G];
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    const int q = tid + 1024 * k;
+    has[k] = q < ldp;
+    vo[k] = hyb_d2{0., 0.};
+    g[k] = hyb_d2{0., 0.};
+    if (has[k]) {
+      if (2 * q < kd) vo[k].x = v[intercept + cols[2 * q]];
+      if (2 * q + 1 < kd) vo[k].y = v[intercept + cols[2 * q + 1]];
+    }
+  }
+  const int64_t per_wg = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per_wg;
+  const int64_t r1 = (r0 + per_wg < n) ? r0 + per_wg : n;
+  const hyb_d2* __restrict__ D2 = reinterpret_cast<const hyb_d2*>(Drm);
+  hyb_d2 xc[RB][G], xn[RB][G];
+  double sc[RB], sn[RB], ac[RB], an[RB];
+  auto load_rows = [&](int64_t r, hyb_d2 (&x)[RB][G], double (&sr)[RB],
+                       double (&ar)[RB]) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const bool ok = r + i < r1;
+      sr[i] = ok ? (rowscale ? rowscale[r + i] : 1.) : 0.;
+      ar[i] = ok ? a[r + i] : 0.;
+#pragma unroll
+      for (int k = 0; k < G; ++k)
+        x[i][k] = (ok && has[k])
+                      ? __builtin_nontemporal_load(D2 + (r + i) * ldp + tid + 1024 * k)
+                      : hyb_d2{0., 0.};
+    }
+  };
+  double tsum = 0., t2sum = 0.;
+  if (r0 < r1) load_rows(r0, xc, sc, ac);
+  int buf = 0;
+  for (int64_t r = r0; r < r1; r += RB) {
+    load_rows(r + RB, xn, sn, an);   // in flight across the exchange below
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      double d0 = 0., d1 = 0.;
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        d0 = fma(xc[i][k].x, vo[k].x, d0);
+        d1 = fma(xc[i][k].y, vo[k].y, d1);
+      }
+      const double w = wave_allsum(d0 + d1);
+      if (lane == 0) red[buf][i][wave] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      double dot = 0.;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) dot += red[buf][i][w];   // fixed order
+      const bool ok = r + i < r1;
+      const double tt = ok ? ac[i] + dot : 0.;
+      const double tv = sc[i] * tt;      // (sc = 0 past the range)
+      if (ok && tid == i) t_out[r + i] = tv;
+      tsum += tv;
+      t2sum = fma(tv, tt, t2sum);
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        g[k].x = fma(xc[i][k].x, tv, g[k].x);
+        g[k].y = fma(xc[i][k].y, tv, g[k].y);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      sc[i] = sn[i];
+      ac[i] = an[i];
+#pragma unroll
+      for (int k = 0; k < G; ++k) xc[i][k] = xn[i][k];
+    }
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    const int q = tid + 1024 * k;
+    if (2 * q < kd) dw_part[(int64_t)blockIdx.x * kd + 2 * q] = g[k].x;
+    if (2 * q + 1 < kd) dw_part[(int64_t)blockIdx.x * kd + 2 * q + 1] = g[k].y;
+  }
+  if (tid == 0 && sum_part) {   // (every thread holds the same sums)
+    sum_part[blockIdx.x] = tsum;
+    if (twt_off) sum_part[twt_off + blockIdx.x] = t2sum;
+  }
+}
+
 // ---- the same for K interleaved right-hand sides: addend[i][c] =
 // sum_g rest_slab[g][i][c] + sum_j D[j][i] v[intercept + dense_cols[j]][c]
 template <int K>
@@ -2055,6 +2167,24 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
       BBX_TRY(launch_tiled(h, mb, x, part_slot(h, PS_C), x0, nullptr,
                            hp->addend.as<double>(), nullptr, nullptr));
       const int ldp = hp->ld_rm / 2;
+      if (hp->kd > HYB_FUSED_WAVE_KD) {
+        // a row of more than 1024 columns: the workgroup-per-row-pair kernel
+#define BBX_HYB_WG(GG, RR)                                                     \
+  hipLaunchKernelGGL((hyb_dense_fused_wg_kernel<GG, RR>), dim3(NPART),         \
+                     dim3(1024),                                               \
+                     0, h->stream, h->n, hp->kd, hp->ld_rm,                    \
+                     hp->D_rm.as<double>(), hp->dense_cols.as<int32_t>(),      \
+                     h->intercept, d_v, hp->addend.as<double>(), d_rowscale,   \
+                     d_t, d_sum_part, twt_off, hp->dw_part.as<double>(),       \
+                     h->skip_flag)
+        if (ldp <= 1024) BBX_HYB_WG(1, 4); else BBX_HYB_WG(2, 2);
+#undef BBX_HYB_WG
+        BBX_HIP(hipGetLastError());
+        hp->dw_for = d_t;
+        hp->dw_serial = h->operator_serial;
+        hp->dw_chunks = NPART;
+        return timer_end(h, 0);
+      }
       const int gw = ldp <= WAVE ? 1 : ldp <= 2 * WAVE ? 2 : ldp <= 4 * WAVE ? 4 : 8;
       const int nt = gw == 8 ? 512 : 1024;
       // (the widest forms hold 64 KB + of per-wave partials in dynamic LDS)

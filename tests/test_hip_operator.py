@@ -349,7 +349,8 @@ def test_mixed_design_of_the_reference_helper_is_stored_split():
     assert np.abs(c_h - c_o).max() <= tol * max(1., np.abs(c_o).max())
 
 
-@pytest.mark.parametrize("n_dense", [1, 5, 8, 9, 20, 127, 130, 300, 700])
+@pytest.mark.parametrize("n_dense", [1, 5, 8, 9, 20, 127, 130, 300, 700, 1500,
+                                     2100])
 def test_dense_columns_ride_in_the_dot_epilogue_of_an_operator_application(n_dense):
     """Binary covariates plus a few continuous ones (the OHDSI shape).  Inside
     ONE operator application X~^T (Omega (X~ v)) -- bbx_design_gram_matvec and
@@ -358,8 +359,9 @@ def test_dense_columns_ride_in_the_dot_epilogue_of_an_operator_application(n_den
     D^T (Omega t) for the transposed product), instead of three kernels of their
     own; 9 ... 1024 take ONE pass over a row-major copy of the dense block
     (hyb_dense_fused_kernel: a wave per row, 1 / 2 / 4 / 8 column pairs per
-    lane -- 127, 130, 300 and 700 columns cross those widths), more the two
-    separate kernels.  Against the two separate
+    lane -- 127, 130, 300 and 700 columns cross those widths; 1025 ... 4096:
+    hyb_dense_fused_wg_kernel, a workgroup per row pair, 1 / 2 pairs per thread
+    -- 1500 and 2100), more the two separate kernels.  Against the two separate
     products (which never use the fused epilogue) and NumPy; a CG draw against
     the oracle; bitwise repeatable."""
     import scipy.sparse as sparse
