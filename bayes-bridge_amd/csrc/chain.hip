@@ -71,11 +71,21 @@ __global__ __launch_bounds__(256) void chain_prior_kernel(
 
 // Running mean / second moment of the scaled coefficients
 // (reg_coef_posterior_summarizer.py:11-19,93-103).
+// The three small kernels that lead the tau / lambda branch are a serial prefix
+// of the longest path after a draw (a single wave's gamma draw takes 51 us under
+// the pass and the Polya-Gamma kernel, 10 us alone): they ask the wave scheduler
+// for priority.  (BBX_BRANCH_PRIO=0: A/B.)
+#define BBX_BRANCH_PRIO() do { if (prio) __builtin_amdgcn_s_setprio(3); } while (0)
+static int branch_prio() {
+  static const int on = !(getenv("BBX_BRANCH_PRIO") && atoi(getenv("BBX_BRANCH_PRIO")) == 0);
+  return on;
+}
 __global__ __launch_bounds__(256) void chain_summary_kernel(
     int64_t P, int nu, double slab, long long n_avg,
     const ChainScalars* __restrict__ sc, const double* __restrict__ lscale,
     const double* __restrict__ coef, double* __restrict__ mean,
-    double* __restrict__ square) {
+    double* __restrict__ square, int prio) {
+  BBX_BRANCH_PRIO();
   const double g = sc->gscale;
   const double w = 1. / (1. + (double)n_avg);
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < P;
@@ -185,7 +195,8 @@ __global__ __launch_bounds__(256) void chain_coef_sums_kernel(
     int64_t P, int nu, double alpha, double slab,
     const double* __restrict__ coef, const double* __restrict__ sd_unshrunk,
     double* __restrict__ part_pow, double* __restrict__ part_slab,
-    double* __restrict__ part_fixed) {
+    double* __restrict__ part_fixed, int prio) {
+  BBX_BRANCH_PRIO();
   double a = 0., b = 0., c = 0.;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < P;
        j += (int64_t)gridDim.x * 256) {
@@ -216,7 +227,9 @@ __global__ __launch_bounds__(256) void chain_gscale_kernel(
     double lower_bd, int update_mode, uint64_t seed, uint64_t stream,
     const double* __restrict__ part_pow, const double* __restrict__ part_slab,
     const double* __restrict__ part_fixed,
-    const double* __restrict__ sd_unshrunk, ChainScalars* __restrict__ sc) {
+    const double* __restrict__ sd_unshrunk, ChainScalars* __restrict__ sc,
+    int prio) {
+  BBX_BRANCH_PRIO();
   const double pow_sum = sum_row_parts(part_pow, NPART);
   const double slab_sum = sum_row_parts(part_slab, NPART);
   const double fixed_sum = sum_row_parts(part_fixed, NPART);
@@ -581,20 +594,22 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
   hipLaunchKernelGGL(chain_summary_kernel, dim3(NPART), dim3(256), 0, s_b, P,
                      nu, c->slab, (long long)c->n_averaged, sc,
                      c->lscale.as<double>(), c->coef.as<double>(),
-                     c->mean.as<double>(), c->square.as<double>());
+                     c->mean.as<double>(), c->square.as<double>(),
+                     fork ? branch_prio() : 0);
   c->n_averaged += 1;
   // the chain's own partial slots: the branches of a batch's chains run side by side
   double* pp = c->misc_part.as<double>();
   hipLaunchKernelGGL(chain_coef_sums_kernel, dim3(NPART), dim3(256), 0, s_b, P,
                      nu, c->bridge_exp, c->slab, c->coef.as<double>(),
                      c->sd_unshrunk.as<double>(), pp, pp + NPART,
-                     pp + 2 * NPART);
+                     pp + 2 * NPART, fork ? branch_prio() : 0);
   const double lower_bd = .001 / power_exp_ave_magnitude(c->bridge_exp);
   hipLaunchKernelGGL(chain_gscale_kernel, dim3(1), dim3(256), 0, s_b, n_shrunk,
                      nu, c->bridge_exp, c->shape0, c->rate0, lower_bd,
                      c->gscale_update, c->seed,
                      iter_stream(STREAM_GSCALE, c->iter), pp, pp + NPART,
-                     pp + 2 * NPART, c->sd_unshrunk.as<double>(), sc);
+                     pp + 2 * NPART, c->sd_unshrunk.as<double>(), sc,
+                     fork ? branch_prio() : 0);
   if (n_shrunk > 0) {
     // Measured at p = 50k (ms per Gibbs iteration, items per block): 256:
     // 5.69, 128: 5.63, 64: 5.72, 32: 5.83, 16: 6.11 -- the speculative copies
