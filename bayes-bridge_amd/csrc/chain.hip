@@ -627,6 +627,28 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
 
   hipError_t launch_err = hipSuccess;
   if (phases & POST_MAIN) {
+  // --- the next draw's normals: 14 us of two fill kernels that nothing here
+  // depends on, moved from the serial stretch in front of the next solve to
+  // the design's stream under the tau / lambda branch (the longer one).
+  // Single chains only (a batch draws its chains' normals itself).  Measured
+  // (three alternating pairs, us per CG iteration): 1M x 50k 106.5 against
+  // 108.2 (+1.5 %), 100k x 10k 37.9 against 37.6 (nothing: its two branches are
+  // short) -- on from 250 000 rows; BBX_ETA_AHEAD=0 / 1 forces it off / on.
+  static const int eta_env =
+      getenv("BBX_ETA_AHEAD") ? atoi(getenv("BBX_ETA_AHEAD")) : -1;
+  const bool eta_ahead = eta_env >= 0 ? eta_env == 1 : n >= 250000;
+  if (eta_ahead && fork && branch_of == nullptr && (phases & POST_JOIN)) {
+    if (!c->eta1_next.ptr) {
+      BBX_TRY(c->eta1_next.alloc(sizeof(double) * (size_t)n));
+      BBX_TRY(c->eta2_next.alloc(sizeof(double) * (size_t)P));
+    }
+    const uint64_t next_seed = cg_draw_seed(c, (uint64_t)c->iter + 1);
+    BBX_TRY(launch_fill_normal(h, n, next_seed, STREAM_ETA1,
+                               c->eta1_next.as<double>()));
+    BBX_TRY(launch_fill_normal(h, P, next_seed, STREAM_ETA2,
+                               c->eta2_next.as<double>()));
+    c->eta_iter = c->iter + 1;
+  }
   // --- Omega | beta, continued
   const int rg = grid_for(n, ROW_GRID);
   double* rp = c->row_part.as<double>();
@@ -663,11 +685,16 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
   const uint64_t it = (uint64_t)c->iter;
   BBX_TRY(chain_pre_draw(c));
   int info = 0;
+  // (the normals of this draw, if the previous iteration filled them ahead)
+  const bool have_eta = c->eta_iter == (long long)it && c->eta1_next.ptr;
   int st = cg_sample_device(
       c->h, c->obs_prec.as<double>(), c->phi.as<double>(), c->z.as<double>(),
-      c->x0.as<double>(), c->sd.as<double>(), c->n_unshrunk, nullptr, nullptr,
+      c->x0.as<double>(), c->sd.as<double>(), c->n_unshrunk,
+      have_eta ? c->eta1_next.as<double>() : nullptr,
+      have_eta ? c->eta2_next.as<double>() : nullptr,
       cg_draw_seed(c, it), maxiter, atol, c->coef.as<double>(), n_cg_iter,
       &info, c->mean_zero ? 1 : 0);
+  c->eta_iter = -1;
   if (st < 0) return st;
   c->mean_zero = false;
   BBX_TRY(chain_post_draw(c, false, POST_ALL));
@@ -958,6 +985,7 @@ int bbx_chain_set_iteration(bbx_chain* c, int64_t iteration) {
   BBX_TRY(chain_check(c));
   if (iteration < 0) return fail(BBX_ERR_INVALID, "iteration < 0");
   c->iter = iteration;
+  c->eta_iter = -1;   // (normals filled ahead belong to the old numbering)
   return BBX_OK;
 }
 
@@ -970,6 +998,7 @@ int bbx_chain_get_seed(bbx_chain* c, uint64_t* seed) {
 int bbx_chain_set_seed(bbx_chain* c, uint64_t seed) {
   BBX_TRY(chain_check(c));
   c->seed = seed;
+  c->eta_iter = -1;   // (normals filled ahead used the old seed)
   return BBX_OK;
 }
 

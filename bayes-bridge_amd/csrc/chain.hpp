@@ -47,6 +47,12 @@ struct bbx_chain {
   bbx::DevMem scalars;                  // ChainScalars
   bbx::DevMem row_part;                 // ROW_GRID partials x 2
   bbx::DevMem misc_part;                // NPART x 3: sums over the coefficients (tau branch)
+  // The normals of the NEXT draw (cg_sampler.py:61-62), filled on the design's
+  // stream while the Polya-Gamma and lambda kernels run: Philox values depend on
+  // (seed, iteration, element) only, so WHEN they are generated changes no bit.
+  // eta_iter = the iteration these buffers hold (-1: none).
+  bbx::DevMem eta1_next, eta2_next;     // n, P
+  long long eta_iter = -1;
   bbx::DevMem samp_gscale, samp_logp;   // per kept sample (device)
   void* pinned = nullptr;
   // second stream for the tau / lambda branch of an iteration
