@@ -609,6 +609,7 @@ int bbx_design_destroy(bbx_design* h) {
     (void)hipEventDestroy(pr.a);
     (void)hipEventDestroy(pr.b);
   }
+  if (h->ev_poll) (void)hipEventDestroy(h->ev_poll);
   if (h->host_pinned) (void)hipHostFree(h->host_pinned);
   destroy_tiled(h);
   hipStream_t s = h->stream;

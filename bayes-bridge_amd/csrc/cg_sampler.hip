@@ -311,6 +311,40 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     BBX_TRY(launch_tdot(h, h->w_n[0].as<double>(), part_slot(h, PS_SUMW), ep, q));
     return timer_end(h, 2);
   };
+  // The caller's work behind a look at the stop flag (bbx_design::tail_hook):
+  // enqueued before the host waits, it runs iff the rule has fired -- its
+  // kernels take &running as their skip flag -- so that the GPU does not idle
+  // while the host wakes up and launches what follows the draw.  Not timed, and
+  // a product that returned at entry is not counted.
+  h->tail_ran = false;
+  auto speculative_tail = [&]() -> int {
+    if (!h->tail_hook) return 0;
+    const bool timing = h->timer.enabled;
+    h->timer.enabled = false;
+    h->skip_flag = &st->running;
+    const int rc = h->tail_hook(h->tail_ctx);
+    h->skip_flag = &st->done;
+    h->timer.enabled = timing;
+    return rc < 0 ? rc : 1;
+  };
+  // The host waits for the READ-BACK of the state (an event behind the copy),
+  // not for the tail behind it: what follows the draw is launched while the
+  // tail runs.  Without a hook this is the stream sync it always was.
+  int tail = 0;
+  auto wait_for_look = [&]() -> int {
+    tail = 0;
+    if (!h->tail_hook) {
+      BBX_HIP(hipStreamSynchronize(h->stream));
+      return BBX_OK;
+    }
+    if (!h->ev_poll)
+      BBX_HIP(hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming));
+    BBX_HIP(hipEventRecord(h->ev_poll, h->stream));
+    tail = speculative_tail();
+    if (tail < 0) return tail;
+    BBX_HIP(hipEventSynchronize(h->ev_poll));
+    return BBX_OK;
+  };
   while (fold && !done) {
     const int stop = (next_poll < maxiter) ? next_poll : maxiter;
     for (; k < stop; ++k) BBX_TRY(folded_iteration(k));
@@ -322,12 +356,15 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     BBX_TRY(launch_cg_finish(h, s, x, d_coef));
     BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,
                            h->stream));
-    BBX_HIP(hipStreamSynchronize(h->stream));
+    const int64_t dots_before = h->n_dot;
+    BBX_TRY(wait_for_look());
     if (host_st->done) {
       done = true;
       finished_at_poll = true;
+      h->tail_ran = tail == 1;
       break;
     }
+    h->n_dot = dots_before;   // (the tail's product returned at entry)
     next_poll = k + 2;
   }
   while (!fold && !done) {
@@ -350,12 +387,15 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     BBX_TRY(launch_cg_finish(h, s, x, d_coef));
     BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,
                            h->stream));
-    BBX_HIP(hipStreamSynchronize(h->stream));
+    const int64_t dots_before = h->n_dot;
+    BBX_TRY(wait_for_look());
     if (host_st->done) {
       done = true;
       finished_at_poll = true;  // host_st is final: later kernels exit at entry
+      h->tail_ran = tail == 1;
       break;
     }
+    h->n_dot = dots_before;   // (the tail's product returned at entry)
     // direction(k) already ran: finish iteration k, then continue.
     BBX_TRY(operator_and_update(k));
     ++k;

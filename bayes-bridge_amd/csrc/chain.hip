@@ -508,10 +508,30 @@ static int grid_for(int64_t len, int cap) {
 // psi = X~ coef
 static int chain_linear_predictor(bbx_chain* c) {
   bbx_design* h = c->h;
+  // (h->skip_flag: null outside a CG solve; inside one -- the speculative form
+  // below -- the flag both kernels return on)
   BBX_TRY(launch_prep_v(h, c->coef.as<double>(), nullptr, nullptr,
-                        part_slot(h, PS_C)));
+                        part_slot(h, PS_C), h->skip_flag));
   return launch_dot(h, c->coef.as<double>(), nullptr, c->psi.as<double>(),
                     nullptr);
+}
+
+// The pass for X~ beta enqueued by the CG loop itself, right behind a look at
+// the stop flag (bbx_design::tail_hook): when the host wakes up from that look
+// the pass is already running, and the kernels of both branches are launched
+// under it instead of after a 25-35 us gap.  If the rule had not fired the two
+// kernels returned at entry.  Layouts whose X~ v is a single kernel that honours
+// the skip flag: the tiled format, one column group, not split by value.
+static int chain_tail_hook(void* ctx) {
+  return chain_linear_predictor(static_cast<bbx_chain*>(ctx));
+}
+static bool chain_tail_applies(const bbx_chain* c) {
+  static const bool on = !(getenv("BBX_CHAIN_TAIL") && atoi(getenv("BBX_CHAIN_TAIL")) == 0);
+  const bbx_design* h = c->h;
+  if (!on || !h->sparse || h->format != BBX_FORMAT_TILED || h->hybrid) return false;
+  int G = 0;
+  return tiled_describe(h, 0, nullptr, nullptr, nullptr, &G, nullptr, nullptr) ==
+             BBX_OK && G == 1;
 }
 
 static int chain_check(const bbx_chain* c) {
@@ -614,7 +634,10 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
     // Measured at p = 50k (ms per Gibbs iteration, items per block): 256:
     // 5.69, 128: 5.63, 64: 5.72, 32: 5.83, 16: 6.11 -- the speculative copies
     // of small blocks cost more arithmetic than the extra blocks hide latency.
-    const int items = (n_shrunk / TS_BLOCK < 1024) ? 128 : TS_BLOCK;
+    static const int items_env =
+        getenv("BBX_TS_ITEMS") ? atoi(getenv("BBX_TS_ITEMS")) : 0;
+    const int items = (items_env >= 8 && items_env <= TS_BLOCK) ? items_env
+                      : (n_shrunk / TS_BLOCK < 1024) ? 128 : TS_BLOCK;
     int64_t nb = (n_shrunk + items - 1) / items;
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(chain_lscale_kernel, dim3((unsigned)nb), dim3(TS_BLOCK),
@@ -687,6 +710,14 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
   int info = 0;
   // (the normals of this draw, if the previous iteration filled them ahead)
   const bool have_eta = c->eta_iter == (long long)it && c->eta1_next.ptr;
+  struct TailScope {
+    bbx_design* h;
+    ~TailScope() { h->tail_hook = nullptr; h->tail_ctx = nullptr; }
+  } tail_scope{c->h};
+  if (chain_tail_applies(c)) {
+    c->h->tail_hook = chain_tail_hook;
+    c->h->tail_ctx = c;
+  }
   int st = cg_sample_device(
       c->h, c->obs_prec.as<double>(), c->phi.as<double>(), c->z.as<double>(),
       c->x0.as<double>(), c->sd.as<double>(), c->n_unshrunk,
@@ -697,7 +728,9 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
   c->eta_iter = -1;
   if (st < 0) return st;
   c->mean_zero = false;
-  BBX_TRY(chain_post_draw(c, false, POST_ALL));
+  // (psi is under way if the pass was enqueued at the look that found the rule fired)
+  BBX_TRY(chain_post_draw(c, c->h->tail_ran, POST_ALL));
+  c->h->tail_ran = false;
   return info;
 }
 

@@ -142,6 +142,11 @@ struct CGState {
   int done;          // 1 once the stop rule fired; later kernels exit at entry
   int bad;           // 1 if a non-finite or non-positive curvature was seen
   int pad;
+  // !done, for work enqueued BEHIND the stop test that must only run once the
+  // rule has fired (the chain's pass for X~ beta, bbx_design::tail_hook): such
+  // kernels take &running as their skip flag
+  int running;
+  int pad2;
 };
 
 struct KernelTimer {
@@ -231,6 +236,13 @@ struct bbx_design {
   // gram_matvec): the Tdot's input is the dot's scaled output, so a mixed
   // design's dense block can ride in the dot kernel's epilogue for both
   // products (spmv_tiled.hip DenseEpi) instead of three kernels of its own.
+  // Work the caller wants enqueued right behind a look at the stop flag, before
+  // the host waits: it runs iff the rule has fired (skip flag = &CGState::running;
+  // cg_sampler.hip).  tail_ran: it was enqueued at the look that found `done`.
+  int (*tail_hook)(void*) = nullptr;
+  void* tail_ctx = nullptr;
+  bool tail_ran = false;
+  hipEvent_t ev_poll = nullptr;   // the look's read-back has landed (the tail may still run)
   bool in_operator = false;
   // counts operator applications: what the dot kernel of ONE application leaves
   // for its Tdot (a mixed design's D^T t partials) is tagged with it, so that
@@ -375,8 +387,9 @@ int launch_tdot(bbx_design* h, const double* d_w, const double* d_sumw_part,
 // ---- vector kernels (vecops.hip) -------------------------------------------
 // v = s ? s .* x : x  (written to d_v unless d_v == x and s == nullptr), and the
 // NPART partials of <offset, v[1:]> into c_part.
+// (skip: a device flag; the kernel returns at entry while it is non-zero)
 int launch_prep_v(bbx_design* h, const double* d_x, const double* d_s,
-                  double* d_v, double* d_c_part);
+                  double* d_v, double* d_c_part, const int* d_skip = nullptr);
 // partials of sum(w .* a) (a may be nullptr => sum(w)) over n entries.
 int launch_sum_n(bbx_design* h, const double* d_w, int64_t len,
                  double* d_part);

@@ -501,6 +501,7 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     if (!finite || sqrt(rho) < f_atol) {   // uniform over the whole grid
       if (bid == 0 && tid == 0) {
         fa.st->done = 1;
+        fa.st->running = 0;
         if (!finite) fa.st->bad = 1;
       }
       return;

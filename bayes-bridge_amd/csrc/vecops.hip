@@ -72,7 +72,9 @@ __device__ inline double part_finish(const PartLoad& p) {
 __global__ __launch_bounds__(VEC_BLOCK) void prep_v_kernel(
     int64_t P, int intercept, const double* __restrict__ x,
     const double* __restrict__ s, const double* __restrict__ offset,
-    double* __restrict__ v, double* __restrict__ c_part) {
+    double* __restrict__ v, double* __restrict__ c_part,
+    const int* __restrict__ skip) {
+  if (skip && *skip) return;   // (work enqueued behind a CG stop test)
   double acc = 0.;
   for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
        jj += (int64_t)gridDim.x * VEC_BLOCK) {
@@ -113,10 +115,10 @@ __global__ __launch_bounds__(VEC_BLOCK) void sqrt_scale_kernel(
 }
 
 int launch_prep_v(bbx_design* h, const double* d_x, const double* d_s,
-                  double* d_v, double* d_c_part) {
+                  double* d_v, double* d_c_part, const int* d_skip) {
   hipLaunchKernelGGL(prep_v_kernel, dim3(NPART), dim3(VEC_BLOCK), 0, h->stream,
                      h->P, h->intercept, d_x, d_s, h->offset.as<double>(), d_v,
-                     d_c_part);
+                     d_c_part, d_skip);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }
@@ -158,6 +160,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_setup_kernel(
     st->done = 0;
     st->bad = 0;
     st->pad = 0;
+    st->running = 1;
+    st->pad2 = 0;
   }
   for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
        jj += (int64_t)gridDim.x * VEC_BLOCK) {
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_direction_kernel(
   if (!finite || sqrt(rho) < atol) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       st->done = 1;
+      st->running = 0;
       if (!finite) st->bad = 1;
     }
     return;
