@@ -35,7 +35,12 @@ int launch_cg_finish(bbx_design* h, const double* s, const double* x,
                      double* coef);
 
 __global__ __launch_bounds__(256) void fill_normal_kernel(
-    int64_t len, uint64_t seed, uint64_t stream, double* __restrict__ out) {
+    int64_t len, uint64_t seed, uint64_t stream, double* __restrict__ out,
+    int prio) {
+  // (prio: the chain fills the NEXT draw's normals in front of its Polya-Gamma
+  // kernel while the lambda kernel runs beside -- 49 us at normal priority, a
+  // delay of the longer branch)
+  if (prio) __builtin_amdgcn_s_setprio(3);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
        i += (int64_t)gridDim.x * blockDim.x) {
     Philox g(seed, stream, (uint64_t)i);
@@ -53,12 +58,14 @@ __global__ __launch_bounds__(256) void any_nonzero_kernel(
 }
 
 int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,
-                       uint64_t stream, double* d_out) {
+                       uint64_t stream, double* d_out, bool prio,
+                       hipStream_t on) {
   int64_t nb = (len + 255) / 256;
   if (nb > 4096) nb = 4096;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)nb), dim3(256), 0,
-                     h->stream, len, seed, stream, d_out);
+                     on ? on : h->stream, len, seed, stream, d_out,
+                     prio ? 1 : 0);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }

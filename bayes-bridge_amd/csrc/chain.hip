@@ -666,10 +666,15 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
       BBX_TRY(c->eta2_next.alloc(sizeof(double) * (size_t)P));
     }
     const uint64_t next_seed = cg_draw_seed(c, (uint64_t)c->iter + 1);
+    // (with wave priority: beside the lambda kernel the n-vector fill takes
+    // 49 us at normal priority and 16 us with it -- and delays the Polya-Gamma
+    // kernel behind it, the longer branch by then; BBX_FILL_PRIO=0: A/B)
+    static const bool fill_prio = !(getenv("BBX_FILL_PRIO") &&
+                                    atoi(getenv("BBX_FILL_PRIO")) == 0);
     BBX_TRY(launch_fill_normal(h, n, next_seed, STREAM_ETA1,
-                               c->eta1_next.as<double>()));
+                               c->eta1_next.as<double>(), fill_prio));
     BBX_TRY(launch_fill_normal(h, P, next_seed, STREAM_ETA2,
-                               c->eta2_next.as<double>()));
+                               c->eta2_next.as<double>(), fill_prio));
     c->eta_iter = c->iter + 1;
   }
   // --- Omega | beta, continued

@@ -493,8 +493,10 @@ int tiled_hybrid_info(const bbx_design* h, int64_t* ones_nnz,
 int tiled_describe(const bbx_design* h, int which, int* W, int* n_block,
                    int* PR, int* G, int64_t* n_quad, int64_t* n_slice,
                    int* packed = nullptr);
+// (prio: ask the wave scheduler for priority; on: the HIP stream, null = the design's)
 int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,
-                       uint64_t stream, double* d_out);
+                       uint64_t stream, double* d_out, bool prio = false,
+                       hipStream_t on = nullptr);
 
 // Ranks that share a GPU take the device part of a design's set-up one at a
 // time: RAII form of bbx_setup_lock_acquire / _release (api.hip; a no-op unless
