@@ -12,7 +12,7 @@ from ctypes import (POINTER, byref, c_char_p, c_double, c_int, c_int32,
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libbbx.so")
 
-ABI_VERSION = 101          # BBX_VERSION of include/bbx.h
+ABI_VERSION = 102          # BBX_VERSION of include/bbx.h
 FORMAT_AUTO, FORMAT_CSR, FORMAT_TILED = 0, 1, 2
 F64, F32 = 0, 1
 MODEL_LINEAR, MODEL_LOGIT = 0, 1
@@ -55,6 +55,9 @@ def _declare(lib):
         "bbx_setup_lock_acquire": ([], c_int),
         "bbx_setup_lock_release": ([], c_int),
         "bbx_design_create_csr": (
+            [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+             c_int, c_int, c_int, POINTER(hp)], c_int),
+        "bbx_design_create_csr64": (
             [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
              c_int, c_int, c_int, POINTER(hp)], c_int),
         "bbx_design_create_csr_dev": (

@@ -355,15 +355,57 @@ class HipSparseDesignMatrix(HipDesignMatrix):
         else:
             self.column_offset = np.zeros(p)
             offset = None
-        indptr = np.ascontiguousarray(X.indptr, dtype=np.int32)
-        indices = np.ascontiguousarray(X.indices, dtype=np.int32)
         data = np.ascontiguousarray(X.data, dtype=np.float64)
+        self._create(n, p, X.indptr, X.indices, data, offset, add_intercept,
+                     device, storage)
+
+    def _create(self, n, p, indptr, indices, data, offset, add_intercept,
+                device, storage):
+        """int32 index arrays go to bbx_design_create_csr; 64-bit ones (what
+        SciPy holds from 2^31 stored entries on) to bbx_design_create_csr64,
+        which narrows them itself below that size."""
         fmt = {'auto': _lib.FORMAT_AUTO, 'csr': _lib.FORMAT_CSR,
                'tiled': _lib.FORMAT_TILED}[storage]
-        _lib.check(self._lib.bbx_design_create_csr(
-            n, p, X.nnz, _ptr(indptr), _ptr(indices), _ptr(data),
+        wide = (np.asarray(indptr).dtype == np.int64
+                and np.asarray(indices).dtype == np.int64)
+        dtype = np.int64 if wide else np.int32
+        indptr = np.ascontiguousarray(indptr, dtype=dtype)
+        indices = np.ascontiguousarray(indices, dtype=dtype)
+        nnz = int(indptr[-1]) if len(indptr) else 0
+        if len(indptr) != n + 1 or len(indices) < nnz:
+            raise ValueError("indptr / indices do not describe %d rows" % n)
+        create = (self._lib.bbx_design_create_csr64 if wide
+                  else self._lib.bbx_design_create_csr)
+        _lib.check(create(
+            n, p, nnz, _ptr(indptr), _ptr(indices), _ptr(data),
             _ptr(offset), int(bool(add_intercept)), int(device), fmt,
             byref(self._h)))
+
+    @classmethod
+    def from_csr_arrays(cls, shape, indptr, indices, data=None,
+                        column_offset=None, add_intercept=True, device=0,
+                        storage='auto'):
+        """The design from raw CSR arrays in host memory, int32 or int64 --
+        for matrices too large to also hold SciPy's float64 `data` of a
+        binary design (`data=None`: every stored value is 1.0).  Column ids
+        must ascend within a row; `column_offset` (p) centres the columns."""
+        self = cls.__new__(cls)
+        HipDesignMatrix.__init__(self)
+        _lib.require_gpu()
+        n, p = int(shape[0]), int(shape[1])
+        self.centered = column_offset is not None
+        self.intercept_added = add_intercept
+        if column_offset is None:
+            self.column_offset = np.zeros(p)
+            offset = None
+        else:
+            offset = self.column_offset = np.ascontiguousarray(
+                column_offset, dtype=np.float64).reshape(p)
+        if data is not None:
+            data = np.ascontiguousarray(data, dtype=np.float64)
+        self._create(n, p, indptr, indices, data, offset, add_intercept,
+                     device, storage)
+        return self
 
     @classmethod
     def from_device_csr(cls, n, p, nnz, indptr_ptr, indices_ptr, data_ptr=None,

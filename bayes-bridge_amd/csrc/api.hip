@@ -10,6 +10,7 @@
 #include <unistd.h>
 
 #include <mutex>
+#include <thread>
 #include <unordered_set>
 
 #include "common.hpp"
@@ -217,7 +218,9 @@ static int check_csr_args(int64_t n, int64_t p, int64_t nnz,
     return fail(BBX_ERR_INVALID, "n and p must be positive, nnz >= 0");
   if (nnz >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31) - 1 ||
       p >= ((int64_t)1 << 31) - 1)
-    return fail(BBX_ERR_INVALID, "sizes must fit int32 indices (SciPy CSR)");
+    return fail(BBX_ERR_INVALID,
+                "sizes must fit int32 indices (SciPy CSR); a matrix with 64-bit "
+                "index arrays goes through bbx_design_create_csr64");
   if (!indptr || (nnz > 0 && !indices))
     return fail(BBX_ERR_INVALID, "indptr/indices must not be NULL");
   return BBX_OK;
@@ -442,6 +445,157 @@ static int create_csr_common(int64_t n, int64_t p, int64_t nnz,
   return BBX_OK;
 }
 
+// ---- 64-bit index arrays (bbx_design_create_csr64) --------------------------
+// Splits [0, len) over the builder's threads and runs fn(begin, end, thread).
+template <typename F>
+static void host_parallel(int64_t len, F fn) {
+  unsigned n_thr = (unsigned)builder_threads(TiledOptions().max_threads);
+  if ((int64_t)n_thr > len / 65536 + 1) n_thr = (unsigned)(len / 65536 + 1);
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < n_thr; ++t)
+    pool.emplace_back([&, t]() {
+      fn(len * (int64_t)t / n_thr, len * (int64_t)(t + 1) / n_thr, (int)t);
+    });
+  for (auto& th : pool) th.join();
+}
+
+static int csr64_structure_error(int flag) {
+  if (flag & 1)
+    return fail(BBX_ERR_INVALID,
+                "indptr must start at 0, end at nnz and be non-decreasing");
+  if (flag & 2) return fail(BBX_ERR_INVALID, "column index out of range");
+  if (flag & 4)
+    return fail(BBX_ERR_INVALID,
+                "column indices must be ascending within each row "
+                "(scipy: X.sort_indices())");
+  return BBX_OK;
+}
+
+// 2^31 or more stored entries: no reference-layout arrays on the device (their
+// kernels index with int32) -- validation, the all-ones test and the
+// transposition run on the host, the LDS-tiled layout (whose offsets are 32-bit
+// per workgroup, 64-bit across workgroups) is the only storage.
+static int create_csr64_big(int64_t n, int64_t p, int64_t nnz,
+                            const int64_t* indptr, const int64_t* indices,
+                            const double* data, const double* col_offset,
+                            int add_intercept, int device, int format,
+                            bbx_design** out) {
+  if (format != BBX_FORMAT_AUTO && format != BBX_FORMAT_TILED)
+    return fail(BBX_ERR_INVALID,
+                "2^31 or more stored entries: only the tiled format applies "
+                "(the reference-layout kernels index with int32)");
+  const int max_thr = TiledOptions().max_threads;
+  BBX_TRY(csr64_structure_error(
+      check_csr64_host(n, p, nnz, indptr, indices, max_thr)));
+  HostCsr x, xt;
+  x.rowptr.assign(indptr, indptr + n + 1);
+  x.colidx.resize((size_t)nnz);
+  host_parallel(nnz, [&](int64_t b, int64_t e, int) {
+    for (int64_t k = b; k < e; ++k) x.colidx[(size_t)k] = (int32_t)indices[k];
+  });
+  bool binary = true;
+  if (data) {
+    std::vector<int> not_one(256, 0);
+    host_parallel(nnz, [&](int64_t b, int64_t e, int t) {
+      for (int64_t k = b; k < e; ++k)
+        if (data[k] != 1.0) {
+          not_one[(size_t)t & 255] = 1;
+          break;
+        }
+    });
+    for (int v : not_one) binary = binary && !v;
+    if (!binary) x.vals.assign(data, data + nnz);
+  }
+  transpose_csr_host(n, p, x.rowptr.data(), x.colidx.data(),
+                     binary ? nullptr : x.vals.data(), max_thr, &xt);
+  bbx_design* h = new (std::nothrow) bbx_design();
+  if (!h) return fail(BBX_ERR_INVALID, "out of host memory");
+  design_register(h);
+  int st = open_device(device, h);
+  if (st < 0) {
+    design_unregister(h);
+    delete h;
+    return st;
+  }
+  h->n = n;
+  h->p = p;
+  h->intercept = add_intercept ? 1 : 0;
+  h->P = p + h->intercept;
+  h->nnz = nnz;
+  h->sparse = true;
+  h->binary = binary;
+  h->centred = (col_offset != nullptr);
+  h->format = BBX_FORMAT_TILED;
+  auto body = [&]() -> int {
+    BBX_TRY(design_alloc_work(h));
+    BBX_TRY(h->offset.alloc(sizeof(double) * (size_t)p));
+    if (col_offset)
+      BBX_HIP(hipMemcpy(h->offset.ptr, col_offset, sizeof(double) * (size_t)p,
+                        hipMemcpyHostToDevice));
+    else
+      BBX_HIP(hipMemset(h->offset.ptr, 0, sizeof(double) * (size_t)p));
+    BBX_HIP(hipDeviceSynchronize());
+    h->host_csr[0] = &x;
+    h->host_csr[1] = &xt;
+    const int st_b = build_tiled(h);
+    h->host_csr[0] = h->host_csr[1] = nullptr;
+    return st_b;
+  };
+  st = no_throw(body);
+  h->host_csr[0] = h->host_csr[1] = nullptr;
+  if (st < 0) {
+    bbx_design_destroy(h);
+    return st;
+  }
+  *out = h;
+  return BBX_OK;
+}
+
+static int create_csr64(int64_t n, int64_t p, int64_t nnz,
+                        const int64_t* indptr, const int64_t* indices,
+                        const double* data, const double* col_offset,
+                        int add_intercept, int device, int format,
+                        bbx_design** out) {
+  if (!out) return fail(BBX_ERR_INVALID, "out handle pointer is NULL");
+  *out = nullptr;
+  if (n <= 0 || p <= 0 || nnz < 0)
+    return fail(BBX_ERR_INVALID, "n and p must be positive, nnz >= 0");
+  if (n >= ((int64_t)1 << 31) - 1 || p >= ((int64_t)1 << 31) - 1)
+    return fail(BBX_ERR_INVALID, "n and p must fit int32");
+  if (!indptr || (nnz > 0 && !indices))
+    return fail(BBX_ERR_INVALID, "indptr/indices must not be NULL");
+  if (format != BBX_FORMAT_AUTO && format != BBX_FORMAT_CSR &&
+      format != BBX_FORMAT_TILED)
+    return fail(BBX_ERR_INVALID, "unknown storage format");
+  // (tests lower the switch-over to walk the host path on small matrices)
+  int64_t big_min = (int64_t)1 << 31;
+  if (const char* e = getenv("BBX_CSR64_BIG_MIN"))
+    big_min = std::min<int64_t>(big_min, std::max<int64_t>(atoll(e), 1));
+  if (nnz >= big_min)
+    return create_csr64_big(n, p, nnz, indptr, indices, data, col_offset,
+                            add_intercept, device, format, out);
+  // fewer entries: the int32 constructor on narrowed copies (the structure is
+  // validated there; here only what narrowing would hide)
+  std::vector<int32_t> ip((size_t)n + 1), ix((size_t)std::max<int64_t>(nnz, 1));
+  for (int64_t r = 0; r <= n; ++r) {
+    if (indptr[r] < 0 || indptr[r] > nnz)
+      return fail(BBX_ERR_INVALID,
+                  "indptr must start at 0, end at nnz and be non-decreasing");
+    ip[(size_t)r] = (int32_t)indptr[r];
+  }
+  std::vector<int> out_of_range(256, 0);
+  host_parallel(nnz, [&](int64_t b, int64_t e, int t) {
+    for (int64_t k = b; k < e; ++k) {
+      if (indices[k] < 0 || indices[k] >= p) out_of_range[(size_t)t & 255] = 1;
+      ix[(size_t)k] = (int32_t)indices[k];
+    }
+  });
+  for (int v : out_of_range)
+    if (v) return fail(BBX_ERR_INVALID, "column index out of range");
+  return create_csr_common(n, p, nnz, ip.data(), ix.data(), data, col_offset,
+                           add_intercept, device, format, false, out);
+}
+
 static int check_handle(const bbx_design* h) {
   if (!h) return fail(BBX_ERR_INVALID, "design handle is NULL");
   return BBX_OK;
@@ -586,6 +740,17 @@ int bbx_design_create_csr(int64_t n, int64_t p, int64_t nnz,
                           bbx_design** out) {
   return create_csr_common(n, p, nnz, indptr, indices, data, col_offset,
                            add_intercept, device, format, false, out);
+}
+
+int bbx_design_create_csr64(int64_t n, int64_t p, int64_t nnz,
+                            const int64_t* indptr, const int64_t* indices,
+                            const double* data, const double* col_offset,
+                            int add_intercept, int device, int format,
+                            bbx_design** out) {
+  return no_throw([&]() -> int {
+    return create_csr64(n, p, nnz, indptr, indices, data, col_offset,
+                        add_intercept, device, format, out);
+  });
 }
 
 int bbx_design_create_csr_dev(int64_t n, int64_t p, int64_t nnz,

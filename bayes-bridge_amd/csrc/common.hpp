@@ -216,6 +216,10 @@ struct bbx_design {
   // layouts sized for 2 and 4 right-hand sides (batched chains), built on
   // first use from the CSR arrays above
   void* tiled_k[2] = {nullptr, nullptr};
+  // const bbx::HostCsr* of X and X^T WHILE a design created from 64-bit index
+  // arrays with 2^31 or more entries is being built (bbx_design_create_csr64):
+  // the layout builders read these instead of fetching device arrays.  Not owned.
+  const void* host_csr[2] = {nullptr, nullptr};
   // bbx_batch_predict's answers, per width slot (2, 4, 8, 16, 32); < 0: not
   // asked yet.  (The sparse model fetches two index arrays from the device.)
   double batch_speedup[5] = {-1., -1., -1., -1., -1.};

@@ -1163,7 +1163,7 @@ static int upload(DevMem& dst, const void* src, size_t bytes) {
 
 // Builds one orientation on the host (tiled_layout.cpp) and moves it to HBM.
 static int build_one(TiledMatrix& m, int64_t R, int64_t C, int64_t nnz,
-                     const int32_t* rowptr, const int32_t* colidx,
+                     const int64_t* rowptr, const int32_t* colidx,
                      const double* vals, bool transpose, int K) {
   TiledHost host;
   std::string err;
@@ -1225,29 +1225,51 @@ void destroy_tiled(bbx_design* h) {
   }
 }
 
-struct HostCsr {
-  std::vector<int32_t> rowptr, colidx;
-  std::vector<double> vals;  // empty: every stored value is 1.0
+// A host CSR as the builders read it: HostCsr (tiled_layout.hpp) owns storage,
+// CsrRef points into one -- a copy fetched from the device arrays of the
+// handle, or the host copy a design of 2^31 or more entries was created from
+// (bbx_design::host_csr: such a design never has device CSR arrays).
+struct CsrRef {
+  const int64_t* rowptr = nullptr;
+  const int32_t* colidx = nullptr;
+  const double* vals = nullptr;   // nullptr: every stored value is 1.0
 };
 
-static int fetch_host_csr(const bbx_design* h, bool transpose, HostCsr* out) {
+static int fetch_host_csr(const bbx_design* h, bool transpose, HostCsr* store,
+                          CsrRef* ref) {
+  if (const HostCsr* held =
+          static_cast<const HostCsr*>(h->host_csr[transpose ? 1 : 0])) {
+    ref->rowptr = held->rowptr.data();
+    ref->colidx = held->colidx.data();
+    ref->vals = h->binary ? nullptr : held->vals.data();
+    return BBX_OK;
+  }
   const int64_t R = transpose ? h->p : h->n, nnz = h->nnz;
   const DevMem& ip = transpose ? h->t_indptr : h->indptr;
   const DevMem& ix = transpose ? h->t_indices : h->indices;
   const DevMem& da = transpose ? h->t_data : h->data;
-  out->rowptr.resize((size_t)R + 1);
-  out->colidx.resize((size_t)std::max<int64_t>(nnz, 1));
-  BBX_HIP(hipMemcpy(out->rowptr.data(), ip.ptr, sizeof(int32_t) * (size_t)(R + 1),
+  if (!ip.ptr || !ix.ptr)
+    return fail(BBX_ERR_STATE,
+                "the reference-layout arrays of this design are not in HBM (a "
+                "design of 2^31 or more stored entries keeps its tiled form "
+                "only: one chain at a time, no batch layouts)");
+  std::vector<int32_t> narrow((size_t)R + 1);
+  BBX_HIP(hipMemcpy(narrow.data(), ip.ptr, sizeof(int32_t) * (size_t)(R + 1),
                     hipMemcpyDeviceToHost));
+  store->rowptr.assign(narrow.begin(), narrow.end());
+  store->colidx.resize((size_t)std::max<int64_t>(nnz, 1));
   if (nnz > 0)
-    BBX_HIP(hipMemcpy(out->colidx.data(), ix.ptr, sizeof(int32_t) * (size_t)nnz,
+    BBX_HIP(hipMemcpy(store->colidx.data(), ix.ptr, sizeof(int32_t) * (size_t)nnz,
                       hipMemcpyDeviceToHost));
-  out->vals.clear();
+  store->vals.clear();
   if (!h->binary) {
-    out->vals.resize((size_t)std::max<int64_t>(nnz, 1));
-    BBX_HIP(hipMemcpy(out->vals.data(), da.ptr, sizeof(double) * (size_t)nnz,
+    store->vals.resize((size_t)std::max<int64_t>(nnz, 1));
+    BBX_HIP(hipMemcpy(store->vals.data(), da.ptr, sizeof(double) * (size_t)nnz,
                       hipMemcpyDeviceToHost));
   }
+  ref->rowptr = store->rowptr.data();
+  ref->colidx = store->colidx.data();
+  ref->vals = h->binary ? nullptr : store->vals.data();
   return BBX_OK;
 }
 
@@ -1265,21 +1287,21 @@ static int build_tiled_pair(bbx_design* h, int K, void** slot) {
   TiledPair* tp = new (std::nothrow) TiledPair();
   if (!tp) return fail(BBX_ERR_INVALID, "out of host memory");
   *slot = tp;  // owned by the handle from here on (destroy_tiled)
-  HostCsr c;
-  BBX_TRY(fetch_host_csr(h, false, &c));
-  BBX_TRY(build_one(tp->x, n, p, nnz, c.rowptr.data(), c.colidx.data(),
-                    h->binary ? nullptr : c.vals.data(), false, K));
-  // transpose orientation from the CSR of X^T built on the device
-  BBX_TRY(fetch_host_csr(h, true, &c));
-  BBX_TRY(build_one(tp->xt, p, n, nnz, c.rowptr.data(), c.colidx.data(),
-                    h->binary ? nullptr : c.vals.data(), true, K));
+  HostCsr store;
+  CsrRef c;
+  BBX_TRY(fetch_host_csr(h, false, &store, &c));
+  BBX_TRY(build_one(tp->x, n, p, nnz, c.rowptr, c.colidx, c.vals, false, K));
+  // transpose orientation from the CSR of X^T (built on the device, or on the
+  // host for 64-bit input)
+  BBX_TRY(fetch_host_csr(h, true, &store, &c));
+  BBX_TRY(build_one(tp->xt, p, n, nnz, c.rowptr, c.colidx, c.vals, true, K));
   return check_lds(tp);
 }
 
 // Rows of one orientation split by value (see HybridParts): the entries equal
 // to 1.0, and the others outside the dense columns.  `col_is_dense` is indexed
 // by the ORIGINAL column id: the row id for the transposed orientation.
-static void split_rows(int64_t R, const HostCsr& c, bool transpose,
+static void split_rows(int64_t R, const CsrRef& c, bool transpose,
                        const std::vector<uint8_t>& col_is_dense, HostCsr* ones,
                        HostCsr* rest) {
   ones->rowptr.assign((size_t)R + 1, 0);
@@ -1289,7 +1311,7 @@ static void split_rows(int64_t R, const HostCsr& c, bool transpose,
   ones->vals.clear();
   rest->vals.clear();
   for (int64_t r = 0; r < R; ++r) {
-    for (int32_t k = c.rowptr[(size_t)r]; k < c.rowptr[(size_t)r + 1]; ++k) {
+    for (int64_t k = c.rowptr[(size_t)r]; k < c.rowptr[(size_t)r + 1]; ++k) {
       const double v = c.vals[(size_t)k];
       const int32_t j = c.colidx[(size_t)k];
       if (v == 1.0) {
@@ -1299,8 +1321,8 @@ static void split_rows(int64_t R, const HostCsr& c, bool transpose,
         rest->vals.push_back(v);
       }
     }
-    ones->rowptr[(size_t)r + 1] = (int32_t)ones->colidx.size();
-    rest->rowptr[(size_t)r + 1] = (int32_t)rest->colidx.size();
+    ones->rowptr[(size_t)r + 1] = (int64_t)ones->colidx.size();
+    rest->rowptr[(size_t)r + 1] = (int64_t)rest->colidx.size();
   }
   if (ones->colidx.empty()) ones->colidx.push_back(0);
   if (rest->colidx.empty()) {
@@ -1315,8 +1337,9 @@ static void split_rows(int64_t R, const HostCsr& c, bool transpose,
 static int build_hybrid(bbx_design* h) {
   const int64_t n = h->n, p = h->p, nnz = h->nnz;
   if (h->binary || nnz == 0) return 1;
-  HostCsr cx;
-  BBX_TRY(fetch_host_csr(h, false, &cx));
+  HostCsr store;
+  CsrRef cx;
+  BBX_TRY(fetch_host_csr(h, false, &store, &cx));
   // per column: entries equal to 1.0 and other entries
   std::vector<int64_t> c_one((size_t)p, 0), c_val((size_t)p, 0);
   for (int64_t k = 0; k < nnz; ++k)
@@ -1375,7 +1398,7 @@ static int build_hybrid(bbx_design* h) {
     for (int s_ = 0; s_ < hp->kd; ++s_) slot_of[(size_t)dense_cols[(size_t)s_]] = s_;
     std::vector<double> D((size_t)hp->kd * (size_t)n, 0.);
     for (int64_t r = 0; r < n; ++r)
-      for (int32_t k = cx.rowptr[(size_t)r]; k < cx.rowptr[(size_t)r + 1]; ++k) {
+      for (int64_t k = cx.rowptr[(size_t)r]; k < cx.rowptr[(size_t)r + 1]; ++k) {
         const int32_t s_ = slot_of[(size_t)cx.colidx[(size_t)k]];
         // (duplicates of one (row, column) add up, like everywhere else)
         if (s_ >= 0 && cx.vals[(size_t)k] != 1.0)
@@ -1397,8 +1420,8 @@ static int build_hybrid(bbx_design* h) {
     BBX_TRY(hp->d_part.alloc(sizeof(double) * HYB_TDOT_CHUNKS * (size_t)hp->kd));
   }
   {  // transposed orientation of B and S
-    HostCsr ct;
-    BBX_TRY(fetch_host_csr(h, true, &ct));
+    CsrRef ct;
+    BBX_TRY(fetch_host_csr(h, true, &store, &ct));
     split_rows(p, ct, true, is_dense, &ones, &rest);
     BBX_TRY(build_one(hp->ones.xt, p, n, ones_nnz, ones.rowptr.data(),
                       ones.colidx.data(), nullptr, true, 1));
@@ -1471,8 +1494,9 @@ static int build_split_k(bbx_design* h, int K, void** slot) {
                       hipMemcpyDeviceToHost));
     for (int32_t j : cols) is_dense[(size_t)j] = 1;
   }
-  HostCsr c, ones, rest;
-  BBX_TRY(fetch_host_csr(h, false, &c));
+  HostCsr store, ones, rest;
+  CsrRef c;
+  BBX_TRY(fetch_host_csr(h, false, &store, &c));
   split_rows(n, c, false, is_dense, &ones, &rest);
   BBX_TRY(build_one(tp->x, n, p, hp->ones_nnz, ones.rowptr.data(),
                     ones.colidx.data(), nullptr, false, K));
@@ -1483,7 +1507,7 @@ static int build_split_k(bbx_design* h, int K, void** slot) {
     BBX_TRY(build_one(hp->rest_k->x, n, p, hp->rest_nnz, rest.rowptr.data(),
                       rest.colidx.data(), rest.vals.data(), false, K));
   }
-  BBX_TRY(fetch_host_csr(h, true, &c));
+  BBX_TRY(fetch_host_csr(h, true, &store, &c));
   split_rows(p, c, true, is_dense, &ones, &rest);
   BBX_TRY(build_one(tp->xt, p, n, hp->ones_nnz, ones.rowptr.data(),
                     ones.colidx.data(), nullptr, true, K));
@@ -1529,11 +1553,17 @@ int tiled_batch_predict(const bbx_design* h, int K, double* speedup) {
     return fail(BBX_ERR_STATE, "batched chains need the tiled format");
   if (K != 2 && K != 4) return fail(BBX_ERR_INVALID, "K must be 2 or 4");
   return no_throw([&]() -> int {
-    std::vector<int32_t> xp((size_t)h->n + 1), tp((size_t)h->p + 1);
-    BBX_HIP(hipMemcpy(xp.data(), h->indptr.ptr, sizeof(int32_t) * xp.size(),
+    if (!h->indptr.ptr || !h->t_indptr.ptr)
+      return fail(BBX_ERR_STATE,
+                  "a design of 2^31 or more stored entries runs one chain at a "
+                  "time (its reference-layout arrays are not kept)");
+    std::vector<int32_t> xp32((size_t)h->n + 1), tp32((size_t)h->p + 1);
+    BBX_HIP(hipMemcpy(xp32.data(), h->indptr.ptr, sizeof(int32_t) * xp32.size(),
                       hipMemcpyDeviceToHost));
-    BBX_HIP(hipMemcpy(tp.data(), h->t_indptr.ptr, sizeof(int32_t) * tp.size(),
+    BBX_HIP(hipMemcpy(tp32.data(), h->t_indptr.ptr, sizeof(int32_t) * tp32.size(),
                       hipMemcpyDeviceToHost));
+    const std::vector<int64_t> xp(xp32.begin(), xp32.end()),
+        tp(tp32.begin(), tp32.end());
     double c1 = 0., ck = 0.;
     for (int k : {1, K}) {
       const double cx = tiled_model_cost(h->n, h->p, h->nnz, xp.data(), k);

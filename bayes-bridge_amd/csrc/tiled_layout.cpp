@@ -415,8 +415,8 @@ static void bank_aware_order(const HalfRow* rows, int n_rows, int64_t col0,
   }
 }
 
-static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
-                        const int32_t* colidx, const double* vals, int W,
+static void build_panel(int64_t R, int64_t C, const int64_t* rowptr,
+                        const int32_t* colidx_all, const double* vals_all, int W,
                         int n_block, int PR, int G, int extra_budget,
                         int panel, bool packed, const TiledOptions& opt,
                         PanelBuild& pb) {
@@ -424,13 +424,19 @@ static void build_panel(int64_t R, int64_t C, const int32_t* rowptr,
   std::vector<uint64_t> groups;    // packed: groups of the tile's rows
   const int64_t row0 = (int64_t)panel * PR;
   const int rows_here = (int)std::min<int64_t>(PR, R - row0);
+  // Entry positions below are RELATIVE to the panel's first entry: a panel of
+  // <= TILE_PR_MAX rows holds far fewer than 2^31 entries, the matrix may hold
+  // more (64-bit row pointers, bbx_design_create_csr64).
+  const int64_t base = rowptr[row0];
+  const int32_t* colidx = colidx_all + base;
+  const double* vals = vals_all ? vals_all + base : nullptr;
   // pass 1: segment of every row in every column block
   std::vector<int32_t> seg_begin((size_t)rows_here * n_block),
       seg_len((size_t)rows_here * n_block);
   std::vector<int32_t> max_seg(rows_here, 0);
   for (int r = 0; r < rows_here; ++r) {
-    int32_t k = rowptr[row0 + r];
-    const int32_t e = rowptr[row0 + r + 1];
+    int32_t k = (int32_t)(rowptr[row0 + r] - base);
+    const int32_t e = (int32_t)(rowptr[row0 + r + 1] - base);
     for (int cb = 0; cb < n_block; ++cb) {
       const int64_t col_end = std::min<int64_t>((int64_t)(cb + 1) * W, C);
       const int32_t b = k;
@@ -839,7 +845,7 @@ static void choose_shape(int64_t R, int64_t C, int64_t nnz, int n_block, int W,
 // build_tiled_host decides before it touches the entries; also what
 // tiled_model_cost answers from (batch-width decisions need no built layout).
 static int choose_geometry(int64_t R, int64_t C, int64_t nnz,
-                           const int32_t* rowptr, const TiledOptions& opt,
+                           const int64_t* rowptr, const TiledOptions& opt,
                            TiledHost& m, const char** why) {
   const int K = opt.chains;
   if (K != 1 && K != 2 && K != 4) {
@@ -907,7 +913,7 @@ static int choose_geometry(int64_t R, int64_t C, int64_t nnz,
 }
 
 double tiled_model_cost(int64_t R, int64_t C, int64_t nnz,
-                        const int32_t* rowptr, int chains) {
+                        const int64_t* rowptr, int chains) {
   TiledOptions opt;
   opt.chains = chains;
   TiledHost m;
@@ -916,7 +922,7 @@ double tiled_model_cost(int64_t R, int64_t C, int64_t nnz,
   return m.model_cost_us;
 }
 
-int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
+int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int64_t* rowptr,
                      const int32_t* colidx, const double* vals,
                      const TiledOptions& opt, TiledHost* out, std::string* err) {
   TiledHost& m = *out;
@@ -972,15 +978,16 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
           const int64_t r0 = R * (int64_t)t / n_thr, r1 = R * (int64_t)(t + 1) / n_thr;
           int64_t a = 0, b = 0, c = 0;
           for (int64_t r = r0; r < r1; ++r) {
-            int32_t k = rowptr[r];
-            const int32_t e = rowptr[r + 1];
+            int64_t k = rowptr[r];
+            const int64_t e = rowptr[r + 1];
             while (k < e) {
               const int64_t cb = colidx[k] / m.W;
               const int64_t col_end = (cb + 1) * m.W;
-              const int32_t b0 = k;
+              const int64_t b0 = k;
               while (k < e && colidx[k] < col_end) ++k;
               a += (k - b0 + 3) / 4;
-              b += pack_groups(colidx, b0, k - b0, cb * m.W, Wl, nullptr);
+              b += pack_groups(colidx + b0, 0, (int32_t)(k - b0), cb * m.W, Wl,
+                               nullptr);
               ++c;
             }
           }
@@ -1398,6 +1405,100 @@ double tiled_mean_gather_cycles(const TiledHost& m) {
   return cycles / groups;
 }
 
+// ---- host-side CSR utilities of the 64-bit constructor ----------------------
+
+int check_csr64_host(int64_t R, int64_t C, int64_t nnz, const int64_t* rowptr,
+                     const int64_t* colidx, int max_threads) {
+  if (rowptr[0] != 0 || rowptr[R] != nnz) return 1;
+  unsigned n_thr = (unsigned)builder_threads(max_threads);
+  if ((int64_t)n_thr > R) n_thr = (unsigned)std::max<int64_t>(R, 1);
+  std::vector<int> bad(n_thr, 0);
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < n_thr; ++t)
+    pool.emplace_back([&, t]() {
+      const int64_t r0 = R * (int64_t)t / n_thr, r1 = R * (int64_t)(t + 1) / n_thr;
+      int b = 0;
+      for (int64_t r = r0; r < r1; ++r) {
+        const int64_t k0 = rowptr[r], k1 = rowptr[r + 1];
+        if (k0 < 0 || k1 < k0 || k1 > nnz) {
+          b |= 1;
+          continue;
+        }
+        int64_t prev = -1;
+        for (int64_t k = k0; k < k1; ++k) {
+          const int64_t c = colidx[k];
+          if (c < 0 || c >= C) b |= 2;
+          if (c < prev) b |= 4;
+          prev = c;
+        }
+      }
+      bad[t] = b;
+    });
+  for (auto& th : pool) th.join();
+  int b = 0;
+  for (int v : bad) b |= v;
+  return b;
+}
+
+void transpose_csr_host(int64_t R, int64_t C, const int64_t* rowptr,
+                        const int32_t* colidx, const double* vals,
+                        int max_threads, HostCsr* out) {
+  const int64_t nnz = rowptr[R];
+  // per-thread column counts: n_thr * C counters, kept under ~2 GB
+  unsigned n_thr = (unsigned)builder_threads(max_threads);
+  while (n_thr > 1 && (double)n_thr * (double)C * 8. > 2e9) n_thr /= 2;
+  if ((int64_t)n_thr > R) n_thr = (unsigned)std::max<int64_t>(R, 1);
+  // thread t owns a contiguous range of rows with ~nnz / n_thr entries
+  std::vector<int64_t> row_cut(n_thr + 1, R);
+  row_cut[0] = 0;
+  for (unsigned t = 1; t < n_thr; ++t) {
+    const int64_t target = nnz / n_thr * t;
+    row_cut[t] = std::lower_bound(rowptr, rowptr + R + 1, target) - rowptr;
+    if (row_cut[t] > R) row_cut[t] = R;
+    if (row_cut[t] < row_cut[t - 1]) row_cut[t] = row_cut[t - 1];
+  }
+  std::vector<std::vector<int64_t>> cnt(n_thr);
+  {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < n_thr; ++t)
+      pool.emplace_back([&, t]() {
+        cnt[t].assign((size_t)C, 0);
+        for (int64_t k = rowptr[row_cut[t]]; k < rowptr[row_cut[t + 1]]; ++k)
+          cnt[t][(size_t)colidx[k]] += 1;
+      });
+    for (auto& th : pool) th.join();
+  }
+  // column j of X = row j of X^T: its entries in thread order are in row order
+  out->rowptr.assign((size_t)C + 1, 0);
+  int64_t at = 0;
+  for (int64_t j = 0; j < C; ++j) {
+    out->rowptr[(size_t)j] = at;
+    for (unsigned t = 0; t < n_thr; ++t) {
+      const int64_t c = cnt[t][(size_t)j];
+      cnt[t][(size_t)j] = at;  // becomes thread t's write position in row j
+      at += c;
+    }
+  }
+  out->rowptr[(size_t)C] = at;
+  out->colidx.resize((size_t)std::max<int64_t>(nnz, 1));
+  out->vals.clear();
+  if (vals) out->vals.resize((size_t)std::max<int64_t>(nnz, 1));
+  {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < n_thr; ++t)
+      pool.emplace_back([&, t]() {
+        std::vector<int64_t>& pos = cnt[t];
+        for (int64_t r = row_cut[t]; r < row_cut[t + 1]; ++r)
+          for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+            const int64_t w = pos[(size_t)colidx[k]]++;
+            out->colidx[(size_t)w] = (int32_t)r;
+            if (vals) out->vals[(size_t)w] = vals[k];
+          }
+      });
+    for (auto& th : pool) th.join();
+  }
+}
+
 }  // namespace bbx
 
 #ifdef BBX_LAYOUT_CAPI
@@ -1427,7 +1528,9 @@ int bbx_layout_emulate(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
   if (max_threads > 0) opt.max_threads = max_threads;
   bbx::TiledHost m;
   std::string err;
-  if (bbx::build_tiled_host(R, C, nnz, rowptr, colidx, vals, opt, &m, &err) != 0) {
+  const std::vector<int64_t> rowptr64(rowptr, rowptr + R + 1);
+  if (bbx::build_tiled_host(R, C, nnz, rowptr64.data(), colidx, vals, opt, &m,
+                            &err) != 0) {
     fprintf(stderr, "bbx_layout_emulate: %s\n", err.c_str());
     return -1;
   }
@@ -1451,7 +1554,30 @@ int bbx_layout_emulate(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
 // the cost model's estimate (us) of one product in the layout for `chains`
 double bbx_layout_model_cost(int64_t R, int64_t C, int64_t nnz,
                              const int32_t* rowptr, int chains) {
-  return bbx::tiled_model_cost(R, C, nnz, rowptr, chains);
+  if (!rowptr) return bbx::tiled_model_cost(R, C, nnz, nullptr, chains);
+  const std::vector<int64_t> rowptr64(rowptr, rowptr + R + 1);
+  return bbx::tiled_model_cost(R, C, nnz, rowptr64.data(), chains);
+}
+
+// X^T of a CSR with 64-bit index arrays (tests: against scipy's transpose).
+// t_rowptr[C + 1], t_colidx[nnz], t_vals[nnz] or NULL.  Returns the structure
+// check's bits (0 = transposed), -1 on a column id beyond int32.
+int bbx_layout_transpose64(int64_t R, int64_t C, const int64_t* rowptr,
+                           const int64_t* colidx, const double* vals,
+                           int max_threads, int64_t* t_rowptr,
+                           int32_t* t_colidx, double* t_vals) {
+  const int64_t nnz = rowptr[R];
+  const int bad = bbx::check_csr64_host(R, C, nnz, rowptr, colidx, max_threads);
+  if (bad) return bad;
+  std::vector<int32_t> narrow((size_t)nnz);
+  for (int64_t k = 0; k < nnz; ++k) narrow[(size_t)k] = (int32_t)colidx[k];
+  bbx::HostCsr t;
+  bbx::transpose_csr_host(R, C, rowptr, narrow.data(), vals, max_threads, &t);
+  memcpy(t_rowptr, t.rowptr.data(), sizeof(int64_t) * (size_t)(C + 1));
+  if (nnz > 0) memcpy(t_colidx, t.colidx.data(), sizeof(int32_t) * (size_t)nnz);
+  if (vals && t_vals && nnz > 0)
+    memcpy(t_vals, t.vals.data(), sizeof(double) * (size_t)nnz);
+  return 0;
 }
 
 int bbx_layout_builder_threads(int max_threads) {

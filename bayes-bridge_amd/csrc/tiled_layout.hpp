@@ -146,7 +146,7 @@ struct TiledHost {
 // Builds the tiled form of an R x C CSR matrix (`vals` == nullptr: every
 // stored value is 1.0).  Returns 0, or -1 with *err set (too large for the
 // format's 32-bit offsets, tile does not fit in LDS, out of memory).
-int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
+int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int64_t* rowptr,
                      const int32_t* colidx, const double* vals,
                      const TiledOptions& opt, TiledHost* out, std::string* err);
 
@@ -154,7 +154,7 @@ int build_tiled_host(int64_t R, int64_t C, int64_t nnz, const int32_t* rowptr,
 // build_tiled_host would choose for `chains` right-hand sides; no layout is
 // built.  < 0 on bad arguments.
 double tiled_model_cost(int64_t R, int64_t C, int64_t nnz,
-                        const int32_t* rowptr, int chains);
+                        const int64_t* rowptr, int chains);
 
 // Worker threads of the builder: affinity mask, capped by the cgroup CPU quota,
 // divided by LOCAL_WORLD_SIZE, capped by max_threads (BBX_BUILD_THREADS overrides).
@@ -170,6 +170,30 @@ int builder_threads(int max_threads);
 // does the same additions in the same order for each of its K columns.)
 void emulate_tiled_spmv(const TiledHost& m, const double* x,
                         std::vector<double>* slab);
+
+// A CSR matrix in host memory as the builder reads it: 64-bit row pointers,
+// 32-bit column ids, values (empty: every stored value is 1.0).
+struct HostCsr {
+  std::vector<int64_t> rowptr;
+  std::vector<int32_t> colidx;
+  std::vector<double> vals;
+};
+
+// Structure check of a host CSR whose index arrays are 64-bit (what SciPy holds
+// once a matrix has 2^31 or more stored entries, or was built from int64
+// arrays): 0 = fine, else the bits validate_csr_kernel (api.hip) reports --
+// 1 row pointers not 0 ... nnz non-decreasing, 2 column id out of range,
+// 4 column ids of a row not ascending.
+int check_csr64_host(int64_t R, int64_t C, int64_t nnz, const int64_t* rowptr,
+                     const int64_t* colidx, int max_threads);
+
+// X^T of an R x C host CSR by a stable counting sort over the column ids (the
+// rows of X^T come out with ascending ids, duplicates in stored order: exactly
+// what the device transposition, a stable radix sort, produces).  `vals` may be
+// nullptr.  Throws std::bad_alloc.
+void transpose_csr_host(int64_t R, int64_t C, const int64_t* rowptr,
+                        const int32_t* colidx, const double* vals,
+                        int max_threads, HostCsr* out);
 
 // LDS bank statistics of the gathers: over every (slice, step, entry position,
 // 32-lane half) the number of LDS cycles a ds_read_b64 needs (1 = conflict

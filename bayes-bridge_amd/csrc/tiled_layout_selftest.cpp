@@ -24,7 +24,8 @@ struct Lcg {
 int run_case(int64_t R, int64_t C, double density, bool binary,
              int force_PR, int force_G, uint64_t seed, int packed = -1) {
   Lcg g{seed};
-  std::vector<int32_t> rowptr((size_t)R + 1, 0), colidx;
+  std::vector<int64_t> rowptr((size_t)R + 1, 0);
+  std::vector<int32_t> colidx;
   std::vector<double> vals;
   for (int64_t r = 0; r < R; ++r) {
     // skewed columns (hot ones recur), ascending, duplicates allowed
@@ -41,13 +42,13 @@ int run_case(int64_t R, int64_t C, double density, bool binary,
         vals.push_back(binary ? 1.0 : g.unit() - 0.5);
       }
     }
-    rowptr[(size_t)r + 1] = (int32_t)colidx.size();
+    rowptr[(size_t)r + 1] = (int64_t)colidx.size();
   }
   const int64_t nnz = (int64_t)colidx.size();
   std::vector<double> x((size_t)C), ref((size_t)R, 0.);
   for (auto& v : x) v = g.unit() - 0.5;
   for (int64_t r = 0; r < R; ++r)
-    for (int32_t k = rowptr[(size_t)r]; k < rowptr[(size_t)r + 1]; ++k)
+    for (int64_t k = rowptr[(size_t)r]; k < rowptr[(size_t)r + 1]; ++k)
       ref[(size_t)r] += vals[(size_t)k] * x[(size_t)colidx[(size_t)k]];
   bbx::TiledOptions opt;
   opt.force_PR = force_PR;

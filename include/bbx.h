@@ -33,11 +33,12 @@
 extern "C" {
 #endif
 
-/* 101: bbx_design_tiled_info takes nine pointers (`packed`, since round 4),
+/* 102: + bbx_design_create_csr64 (64-bit index arrays, 2^31 or more entries).
+ * 101: bbx_design_tiled_info takes nine pointers (`packed`, since round 4),
  *      bbx_setup_lock_acquire/_release, bbx_design_useful_bytes.  A binding
  *      compares bbx_version() with the BBX_VERSION it was written against
  *      (bayesbridge_amd/_lib.py does) instead of calling with a stale arity. */
-#define BBX_VERSION 101 /* 0.1.1 */
+#define BBX_VERSION 102 /* 0.1.2 */
 
 /* status codes */
 #define BBX_OK 0
@@ -122,6 +123,27 @@ int bbx_design_create_csr(int64_t n, int64_t p, int64_t nnz,
                           const double* data, const double* col_offset,
                           int add_intercept, int device, int format,
                           bbx_design** out);
+
+/*
+ * The same from 64-BIT index arrays: what scipy.sparse.csr_matrix holds once a
+ * matrix has 2^31 or more stored entries (SparseDesignMatrix keeps whatever
+ * SciPy built, design_matrix/sparse_matrix.py:49; scipy.sparse picks int64 by
+ * get_index_dtype), or when it was assembled from int64 arrays.  n and p must
+ * still fit int32 (column and row ids are stored as 32-bit or narrower).
+ *   nnz < 2^31: narrowed copies go through bbx_design_create_csr -- same
+ *     formats, same validation, same results bit for bit.
+ *   nnz >= 2^31: validation, the all-ones test and the transposition run on
+ *     the HOST (threads: bbx_builder_threads), the design is stored in the
+ *     LDS-tiled layout only -- format must be BBX_FORMAT_AUTO or
+ *     BBX_FORMAT_TILED (the reference-layout kernels index with int32), and
+ *     the layouts for batched chains (bbx_batch_*) are refused with
+ *     BBX_ERR_STATE: such a design runs one chain at a time.
+ */
+int bbx_design_create_csr64(int64_t n, int64_t p, int64_t nnz,
+                            const int64_t* indptr, const int64_t* indices,
+                            const double* data, const double* col_offset,
+                            int add_intercept, int device, int format,
+                            bbx_design** out);
 
 /* Same, but indptr/indices/data/col_offset are DEVICE pointers on `device`
  * (used when the matrix is generated on the GPU; the arrays are copied, the

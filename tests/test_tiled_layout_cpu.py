@@ -237,3 +237,73 @@ def test_cost_model_orders_the_batch_widths_like_the_measurements():
     small2, small4 = predicted(100000, 10000, .01, 2), predicted(100000, 10000, .01, 4)
     assert small4 > small2 > 1., (small2, small4)  # both pay on the small design
     assert lib.bbx_layout_model_cost(10, 10, 10, None, 3) < 0   # K = 3: no layout
+
+
+def _transpose64(lib, A, vals=True, threads=4, indptr=None, indices=None):
+    import ctypes
+    R, C = A.shape
+    indptr = np.ascontiguousarray(A.indptr if indptr is None else indptr,
+                                  dtype=np.int64)
+    indices = np.ascontiguousarray(A.indices if indices is None else indices,
+                                   dtype=np.int64)
+    data = np.ascontiguousarray(A.data, dtype=np.float64)
+    nnz = len(data)
+    t_ptr = np.empty(C + 1, dtype=np.int64)
+    t_idx = np.empty(max(nnz, 1), dtype=np.int32)
+    t_val = np.empty(max(nnz, 1), dtype=np.float64)
+    lib.bbx_layout_transpose64.argtypes = (
+        [ctypes.c_int64] * 2 + [ctypes.c_void_p] * 3 + [ctypes.c_int]
+        + [ctypes.c_void_p] * 3)
+    st = lib.bbx_layout_transpose64(
+        R, C, indptr.ctypes.data, indices.ctypes.data,
+        data.ctypes.data if vals else None, threads, t_ptr.ctypes.data,
+        t_idx.ctypes.data, t_val.ctypes.data if vals else None)
+    return st, t_ptr, t_idx[:nnz], t_val[:nnz]
+
+
+@pytest.mark.parametrize("shape,density,threads", [
+    ((1, 1), 1., 1), ((7, 3), .5, 4), ((300, 1000), .02, 3),
+    ((2000, 40), .3, 8), ((513, 129), .0, 2)])
+def test_host_transposition_of_64bit_csr_equals_scipys(shape, density, threads):
+    """bbx_design_create_csr64's host path (2^31 or more stored entries) builds
+    the CSR of X^T with a threaded stable counting sort (csrc/tiled_layout.cpp
+    transpose_csr_host): row pointers, row ids in ascending order and values
+    must be those of scipy's X.T.tocsr() -- what the reference's Tdot multiplies
+    with (design_matrix/sparse_matrix.py:103-129)."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, 'bayes-bridge_amd',
+                                   'libbbx_layout.so'))
+    rng = np.random.default_rng(5)
+    A = sparse.random(shape[0], shape[1], density=density, format='csr',
+                      random_state=rng, dtype=np.float64)
+    A.sort_indices()
+    st, t_ptr, t_idx, t_val = _transpose64(lib, A, threads=threads)
+    assert st == 0
+    T = A.T.tocsr()
+    T.sort_indices()
+    assert np.array_equal(t_ptr, T.indptr)
+    assert np.array_equal(t_idx, T.indices)
+    assert np.array_equal(t_val, T.data)
+    st, t_ptr, t_idx, _ = _transpose64(lib, A, vals=False, threads=threads)
+    assert st == 0 and np.array_equal(t_ptr, T.indptr)
+    assert np.array_equal(t_idx, T.indices)
+
+
+def test_host_structure_check_of_64bit_csr_reports_what_the_device_check_does():
+    """Bits of check_csr64_host = those of validate_csr_kernel (csrc/api.hip):
+    1 row pointers, 2 column id out of range, 4 columns of a row not ascending;
+    duplicates are allowed (SciPy's csr_matvec adds them up)."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, 'bayes-bridge_amd',
+                                   'libbbx_layout.so'))
+    A = sparse.csr_matrix(np.array([[1., 0, 2, 0], [0, 3, 0, 4], [5, 0, 0, 6]]))
+
+    def status(indptr=None, indices=None):
+        return _transpose64(lib, A, indptr=indptr, indices=indices)[0]
+    assert status() == 0
+    assert status(indptr=[1, 2, 4, 6]) & 1
+    assert status(indptr=[0, 4, 2, 6]) & 1
+    assert status(indices=[0, 2, 1, 4, 0, 3]) & 2
+    assert status(indices=[0, 2, 1, -1, 0, 3]) & 2
+    assert status(indices=[2, 0, 1, 3, 0, 3]) & 4
+    assert status(indices=[0, 0, 1, 3, 3, 3]) == 0     # duplicates
