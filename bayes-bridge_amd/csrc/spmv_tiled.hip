@@ -111,7 +111,7 @@ struct TiledPair {
 
 constexpr int HYB_TDOT_CHUNKS = 256;  // row chunks of the dense block's D^T w
 constexpr int HYB_FUSED_WAVE_KD = 1024; // widest dense block of the wave-per-row kernel
-constexpr int HYB_FUSED_MAX_KD = 4096;  // ... of the workgroup-per-row-block kernel (= the split's cap)
+constexpr int HYB_FUSED_MAX_KD = 8192;  // ... of the workgroup-per-row-block kernel (= the split's cap)
 
 // Mixed designs: X = B + D + S.
 //
@@ -1359,10 +1359,12 @@ static int build_hybrid(bbx_design* h) {
       dense_nnz += c_val[(size_t)j];
     }
   }
-  // a dense block beyond 8 GB or 4096 columns is not a "few continuous
-  // covariates" design: those entries stay in the valued tiled part
-  if ((double)dense_cols.size() * (double)n * 8. > 8e9 ||
-      dense_cols.size() > 4096) {
+  // a dense block beyond 32 GB (it is held twice: by column for the separate
+  // products, by row for the operator's single pass) or wider than the
+  // single-pass kernels reach (8192 columns: four column pairs per thread)
+  // stays in the valued tiled part
+  if ((double)dense_cols.size() * (double)n * 8. > 32e9 ||
+      dense_cols.size() > (size_t)HYB_FUSED_MAX_KD) {
     std::fill(is_dense.begin(), is_dense.end(), 0);
     dense_cols.clear();
     dense_nnz = 0;
@@ -1939,9 +1941,9 @@ __global__ __launch_bounds__(NT) void hyb_dense_fused_kernel(
   }
 }
 
-// The same pass for WIDER dense blocks (1024 < kd <= 4096 columns): a row no
+// The same pass for WIDER dense blocks (1024 < kd <= 8192 columns): a row no
 // longer fits the registers of one wave, so a 1024-thread workgroup takes RB rows
-// at a time (4 up to 2048 columns, 2 beyond: ~48 KB per barrier) -- thread t owns the column pairs t + 1024 k, k < G (1 KiB of
+// at a time (4 up to 2048 columns, 2 up to 4096, 1 beyond: 32-64 KB per barrier) -- thread t owns the column pairs t + 1024 k, k < G (1 KiB of
 // contiguous bytes per wave and load instruction) with its slices of v_D and of
 // D^T t in registers, the rows' inner products go through one LDS exchange and
 // ONE barrier per RB rows, the next RB are in flight meanwhile -- the shape of
@@ -2208,7 +2210,9 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
                      h->intercept, d_v, hp->addend.as<double>(), d_rowscale,   \
                      d_t, d_sum_part, twt_off, hp->dw_part.as<double>(),       \
                      h->skip_flag)
-        if (ldp <= 1024) BBX_HYB_WG(1, 4); else BBX_HYB_WG(2, 2);
+        if (ldp <= 1024) BBX_HYB_WG(1, 4);
+        else if (ldp <= 2048) BBX_HYB_WG(2, 2);
+        else BBX_HYB_WG(4, 1);
 #undef BBX_HYB_WG
         BBX_HIP(hipGetLastError());
         hp->dw_for = d_t;

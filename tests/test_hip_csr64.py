@@ -242,7 +242,19 @@ def test_a_design_of_more_than_2_31_stored_entries():
     gm = hip.gram_matvec(omega, v)
     ref_gm = block.Tdot((omega * ref_t).reshape(COPIES, N_A).sum(axis=0))
     assert np.abs(gm - ref_gm).max() <= 1e-9 * np.abs(ref_gm).max()
+    # the rate of the two products at this size (kernel stamps)
+    hip.set_timing(True)
+    for _ in range(5):
+        hip.gram_matvec(omega, v)
+    tm, by = hip.get_timing(), hip.timed_bytes
+    rate = {k: by[i] / (tm[k][1] / tm[k][0] * 1e-3) / 1e9
+            for i, k in enumerate(('dot', 'tdot'))}
+    hip.set_timing(False)
+    assert min(rate.values()) > 1000.        # GB/s: streaming, not crawling
     print("nnz %d: arrays in %.0f s, design built in %.0f s, storage %.1f GB, "
-          "tiled %s" % (nnz, t_gen, t_build, hip.storage_bytes / 1e9,
-                        {k: (d['W'], d['PR'], d['G'], d['packed'])
-                         for k, d in hip.tiled_info().items()}))
+          "tiled %s; X~ v %.2f ms = %.0f GB/s, X~^T w %.2f ms = %.0f GB/s"
+          % (nnz, t_gen, t_build, hip.storage_bytes / 1e9,
+             {k: (d['W'], d['PR'], d['G'], d['packed'])
+              for k, d in hip.tiled_info().items()},
+             tm['dot'][1] / tm['dot'][0], rate['dot'],
+             tm['tdot'][1] / tm['tdot'][0], rate['tdot']))

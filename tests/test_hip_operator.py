@@ -350,7 +350,7 @@ def test_mixed_design_of_the_reference_helper_is_stored_split():
 
 
 @pytest.mark.parametrize("n_dense", [1, 5, 8, 9, 20, 127, 130, 300, 700, 1500,
-                                     2100])
+                                     2100, 4500, 8192])
 def test_dense_columns_ride_in_the_dot_epilogue_of_an_operator_application(n_dense):
     """Binary covariates plus a few continuous ones (the OHDSI shape).  Inside
     ONE operator application X~^T (Omega (X~ v)) -- bbx_design_gram_matvec and
@@ -359,16 +359,18 @@ def test_dense_columns_ride_in_the_dot_epilogue_of_an_operator_application(n_den
     D^T (Omega t) for the transposed product), instead of three kernels of their
     own; 9 ... 1024 take ONE pass over a row-major copy of the dense block
     (hyb_dense_fused_kernel: a wave per row, 1 / 2 / 4 / 8 column pairs per
-    lane -- 127, 130, 300 and 700 columns cross those widths; 1025 ... 4096:
-    hyb_dense_fused_wg_kernel, a workgroup per row pair, 1 / 2 pairs per thread
-    -- 1500 and 2100), more the two separate kernels.  Against the two separate
+    lane -- 127, 130, 300 and 700 columns cross those widths; 1025 ... 8192:
+    hyb_dense_fused_wg_kernel, a workgroup per row block, 1 / 2 / 4 pairs per
+    thread -- 1500, 2100 and 4500 / 8192; the reference's generator default,
+    simulate_data.py:29 binary_frac=.5, at 10 000 columns is 5 000 of them),
+    more stay in the valued layout.  Against the two separate
     products (which never use the fused epilogue) and NumPy; a CG draw against
     the oracle; bitwise repeatable."""
     import scipy.sparse as sparse
     import oracle
     from bayesbridge_amd import HipCGSampler, HipSparseDesignMatrix, simulate
     from helpers import cg_inputs
-    n, p = 30000, 2500
+    n, p = (30000, 2500) if n_dense <= 2500 else (6000, n_dense + 500)
     rng = np.random.default_rng(40 + n_dense)
     Xb = simulate.simulate_binary_csr_fast(n, p, .01, seed=9)
     dense_block = rng.standard_normal((n, n_dense))

@@ -71,6 +71,17 @@ def test_tiled_kernels_do_not_spill(tmp_path):
         assert res["VGPRs Spill"] == 0, (name, res)
         assert res["SGPRs Spill"] == 0, (name, res)
         assert res["ScratchSize [bytes/lane]"] == 0, (name, res)
+    # a mixed design's dense block in one pass (wave per row: 1 / 2 / 4 / 8
+    # column pairs per lane; workgroup per row block: 1 / 2 / 4 pairs per
+    # thread, up to 8192 columns): rows of D, the slice of v_D and of D^T t in
+    # registers -- a spill would stream the block through scratch
+    dense = {k: v for k, v in table.items() if "hyb_dense_fused" in k}
+    assert len(dense) == 7, sorted(dense)
+    for name, res in dense.items():
+        # (the eight-pair form runs 512 threads: twice the registers per lane)
+        assert res["VGPRs"] <= (256 if "ELi512EE" in name else 128), (name, res)
+        assert res["VGPRs Spill"] == 0, (name, res)
+        assert res["ScratchSize [bytes/lane]"] == 0, (name, res)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
