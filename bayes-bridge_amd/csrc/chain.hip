@@ -9,6 +9,7 @@
 #include "chain.hpp"
 #include "philox.hpp"
 #include "samplers.hpp"
+#include "pg_queue.hpp"
 
 namespace bbx {
 
@@ -76,6 +77,10 @@ __global__ __launch_bounds__(256) void chain_prior_kernel(
 // the pass and the Polya-Gamma kernel, 10 us alone): they ask the wave scheduler
 // for priority.  (BBX_BRANCH_PRIO=0: A/B.)
 #define BBX_BRANCH_PRIO() do { if (prio) __builtin_amdgcn_s_setprio(3); } while (0)
+static int lscale_prio() {
+  static const int on = getenv("BBX_LSCALE_PRIO") ? atoi(getenv("BBX_LSCALE_PRIO")) : 1;
+  return on;
+}
 static int branch_prio() {
   static const int on = !(getenv("BBX_BRANCH_PRIO") && atoi(getenv("BBX_BRANCH_PRIO")) == 0);
   return on;
@@ -103,8 +108,30 @@ __device__ inline double log1pexp(double x) {
 }
 
 // Omega_i ~ PG(n_trial_i, psi_i) and the log-likelihood partials
-// (bayesbridge.py:405-408; logistic_model.py:49-55).
+// (bayesbridge.py:405-408; logistic_model.py:49-55).  E elements per lane:
+// pg_queue.hpp.
+template <int E>
 __global__ __launch_bounds__(256) void chain_pg_kernel(
+    int64_t n, uint64_t seed, uint64_t stream,
+    const double* __restrict__ n_success, const double* __restrict__ n_trial,
+    const double* __restrict__ psi, double* __restrict__ omega,
+    double* __restrict__ ll_part) {
+  __shared__ double s_z[E][256], s_x[E][256];
+  double acc = 0.;
+  for (int64_t base = (int64_t)blockIdx.x * (256 * E); base < n;
+       base += (int64_t)gridDim.x * (256 * E))
+    acc += polya_gamma_block<E>(
+        base, n, seed, stream, n_trial, psi, omega, s_z, s_x,
+        [&](int64_t i, double eta, double nt) {
+          return n_success[i] * eta - nt * log1pexp(eta);
+        });
+  const double tot = block_total_256(acc);
+  if (threadIdx.x == 0) ll_part[blockIdx.x] = tot;
+}
+
+// (one lane per draw with the sequential sampler: the kernel of rounds 1-4,
+// kept behind BBX_PG_ELEMS=0 for A/B runs)
+__global__ __launch_bounds__(256) void chain_pg_lane_kernel(
     int64_t n, uint64_t seed, uint64_t stream,
     const double* __restrict__ n_success, const double* __restrict__ n_trial,
     const double* __restrict__ psi, double* __restrict__ omega,
@@ -394,8 +421,11 @@ __device__ inline void tilted_stable_block(int64_t base, int64_t count,
 __global__ __launch_bounds__(TS_BLOCK) void chain_lscale_kernel(
     int64_t n_shrunk, int nu, double alpha, uint64_t seed, uint64_t stream,
     ChainScalars* __restrict__ sc, const double* __restrict__ coef,
-    double* __restrict__ lscale, int items, double cost_threshold) {
+    double* __restrict__ lscale, int items, double cost_threshold, int prio) {
   __shared__ double s_tilt[TS_BLOCK];
+  // (beside the Polya-Gamma kernel; three alternating pairs: config 2 36.6-36.9
+  // against 37.1-37.2 us per CG iteration, config 3 level; BBX_LSCALE_PRIO=0: A/B)
+  BBX_BRANCH_PRIO();
   const double g = sc->gscale;
   for (int64_t base = (int64_t)blockIdx.x * items; base < n_shrunk;
        base += (int64_t)gridDim.x * items) {
@@ -445,14 +475,16 @@ __global__ __launch_bounds__(256) void chain_kappa_kernel(
 
 // -------------------------------------------- stand-alone sampler kernels
 
+// (the chain's sampler, pg_queue.hpp: what the distribution tests draw from)
+template <int E>
 __global__ __launch_bounds__(256) void dev_pg_kernel(
     int64_t n, uint64_t seed, const int32_t* __restrict__ shape,
     const double* __restrict__ tilt, double* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * 256) {
-    Philox g(seed, STREAM_PG, (uint64_t)i);
-    out[i] = PolyaGamma::draw(g, shape[i], tilt[i]);
-  }
+  __shared__ double s_z[E][256], s_x[E][256];
+  for (int64_t base = (int64_t)blockIdx.x * (256 * E); base < n;
+       base += (int64_t)gridDim.x * (256 * E))
+    polya_gamma_block<E>(base, n, seed, STREAM_PG, shape, tilt, out, s_z, s_x,
+                         [](int64_t, double, double) { return 0.; });
 }
 
 __global__ __launch_bounds__(TS_BLOCK) void dev_ts_kernel(
@@ -525,6 +557,7 @@ static int chain_linear_predictor(bbx_chain* c) {
 static int chain_tail_hook(void* ctx) {
   return chain_linear_predictor(static_cast<bbx_chain*>(ctx));
 }
+
 static bool chain_tail_applies(const bbx_chain* c) {
   static const bool on = !(getenv("BBX_CHAIN_TAIL") && atoi(getenv("BBX_CHAIN_TAIL")) == 0);
   const bbx_design* h = c->h;
@@ -644,7 +677,7 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
                        0, s_b, n_shrunk, nu, c->bridge_exp, c->seed,
                        iter_stream(STREAM_LSCALE, c->iter), sc,
                        c->coef.as<double>(), c->lscale.as<double>(), items,
-                       ts_cost_threshold());
+                       ts_cost_threshold(), fork ? lscale_prio() : 0);
   }
   }  // POST_BRANCH
 
@@ -678,13 +711,27 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
     c->eta_iter = c->iter + 1;
   }
   // --- Omega | beta, continued
-  const int rg = grid_for(n, ROW_GRID);
+  int rg = grid_for(n, ROW_GRID);
   double* rp = c->row_part.as<double>();
   if (c->model == BBX_MODEL_LOGIT) {
-    hipLaunchKernelGGL(chain_pg_kernel, dim3(rg), dim3(256), 0, s, n, c->seed,
-                       iter_stream(STREAM_PG, c->iter),
-                       c->outcome.as<double>(), c->n_trial.as<double>(),
-                       c->psi.as<double>(), c->obs_prec.as<double>(), rp);
+    // elements per lane: by size; BBX_PG_ELEMS = 1 | 4 | 8 forces a width (the
+    // draws do not depend on it), 0 = the one-lane kernel of rounds 1-4
+    static const int pg_env =
+        getenv("BBX_PG_ELEMS") ? atoi(getenv("BBX_PG_ELEMS")) : -1;
+    const int elems = pg_env >= 0 ? pg_env : polya_gamma_elems(n);
+#define BBX_PG_LAUNCH(KERNEL, PER_BLOCK)                                       \
+  do {                                                                         \
+    rg = grid_for((n + (PER_BLOCK) - 1) / (PER_BLOCK) * 256, ROW_GRID);        \
+    hipLaunchKernelGGL(KERNEL, dim3(rg), dim3(256), 0, s, n, c->seed,          \
+                       iter_stream(STREAM_PG, c->iter),                        \
+                       c->outcome.as<double>(), c->n_trial.as<double>(),       \
+                       c->psi.as<double>(), c->obs_prec.as<double>(), rp);     \
+  } while (0)
+    if (elems == 0) BBX_PG_LAUNCH(chain_pg_lane_kernel, 256);
+    else if (elems >= 8) BBX_PG_LAUNCH(chain_pg_kernel<8>, 2048);
+    else if (elems >= 4) BBX_PG_LAUNCH(chain_pg_kernel<4>, 1024);
+    else BBX_PG_LAUNCH(chain_pg_kernel<1>, 256);
+#undef BBX_PG_LAUNCH
   } else {
     hipLaunchKernelGGL(chain_rss_kernel, dim3(rg), dim3(256), 0, s, n,
                        c->outcome.as<double>(), c->psi.as<double>(), rp);
@@ -723,6 +770,7 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
     c->h->tail_hook = chain_tail_hook;
     c->h->tail_ctx = c;
   }
+
   int st = cg_sample_device(
       c->h, c->obs_prec.as<double>(), c->phi.as<double>(), c->z.as<double>(),
       c->x0.as<double>(), c->sd.as<double>(), c->n_unshrunk,
@@ -1231,9 +1279,16 @@ static int bbx_device_polya_gamma_impl(int device, uint64_t seed, int64_t n_draw
                     hipMemcpyHostToDevice));
   BBX_HIP(hipMemcpy(dt.ptr, tilt, sizeof(double) * (size_t)n_draw,
                     hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(dev_pg_kernel, dim3(grid_for(n_draw, 4096)), dim3(256), 0,
-                     0, n_draw, seed, ds.as<int32_t>(), dt.as<double>(),
-                     dout.as<double>());
+  // (the draws do not depend on the elements per lane: the small width for
+  // short vectors, the chain's widest otherwise)
+  if (n_draw < 50000)
+    hipLaunchKernelGGL(dev_pg_kernel<1>, dim3(grid_for(n_draw, 4096)), dim3(256),
+                       0, 0, n_draw, seed, ds.as<int32_t>(), dt.as<double>(),
+                       dout.as<double>());
+  else
+    hipLaunchKernelGGL(dev_pg_kernel<8>, dim3(grid_for((n_draw + 7) / 8, 4096)),
+                       dim3(256), 0, 0, n_draw, seed, ds.as<int32_t>(),
+                       dt.as<double>(), dout.as<double>());
   BBX_HIP(hipGetLastError());
   BBX_HIP(hipMemcpy(out, dout.ptr, sizeof(double) * (size_t)n_draw,
                     hipMemcpyDeviceToHost));

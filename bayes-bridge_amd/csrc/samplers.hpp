@@ -188,6 +188,61 @@ struct PolyaGamma {
     }
   }
 
+  // ---- the device chain's forms of the two non-loop pieces (chain.hip
+  // chain_pg_kernel): the same quantities without the detour through
+  // logarithms, i.e. equal to right_mass / series_accept up to rounding --
+  // which moves a draw only when a uniform falls within ~1e-15 of a threshold.
+  // (The sequential jacobi() below, the host sampler pinned to the reference's
+  // stream, keeps the reference's arithmetic.)
+
+  // right_mass: mass_ig / mass_exp = (4 / pi) rate e^{rate kCut}
+  //   [e^{-z} Phi((kCut z - 1)/sqrt kCut) + e^{z} Phi(-(kCut z + 1)/sqrt kCut)]
+  // as products (two erfc, two exp instead of two erfc, three log, three exp);
+  // from z = 20 on (|psi| >= 40) the factors leave the double range long
+  // before their product does: the log form.
+  BBX_HD static inline double right_mass_direct(double z, double rate) {
+    if (z > 20.) return right_mass(z, rate);
+    constexpr double kInvSqrt2 = 0.70710678118654752440;
+    const double sq = sqrt(kCut);
+    const double a = (kCut * z - 1.) / sq, b = -(kCut * z + 1.) / sq;
+    const double c = rate * kCut;
+    const double r1 = exp(c - z) * (0.5 * erfc(-a * kInvSqrt2));
+    const double r2 = exp(c + z) * (0.5 * erfc(-b * kInvSqrt2));
+    return 1.0 / (1.0 + (4. / kPi) * rate * (r1 + r2));
+  }
+
+  // series_accept with the terms a_n(x) = pi (n + 1/2) f(x) e^{-g(x)(n + 1/2)^2}
+  // formed directly: f and g once per proposal, one exp per term.
+  template <class G>
+  BBX_HD static inline bool series_accept_direct(G& g, double x) {
+    double f, gx;
+    if (x <= kCut) {
+      const double y = 0.5 * x * kPi;
+      f = kPi / (y * sqrt(y));
+      gx = 2. / x;
+    } else {
+      f = kPi;
+      gx = 0.5 * x * kPi * kPi;
+    }
+    const double first = 0.5 * f * exp(-0.25 * gx);
+    const double u = g.uniform() * first;
+    double partial = first;
+    int n_summed = 1;
+    int sign = -1;
+    for (;;) {
+      const double h = n_summed + 0.5;
+      partial += sign * (h * f * exp(-gx * h * h));
+      n_summed += 1;
+      if (sign == -1) {
+        if (u <= partial) return true;
+      } else {
+        if (u > partial) return false;
+        if (n_summed >= kMaxTerms) return true;
+      }
+      sign = -sign;
+    }
+  }
+
   // Tilted Jacobi J*(1, z) (polya_gamma.pyx:86-111,139-162).
   template <class G>
   BBX_HD static inline double jacobi(G& g, double z) {

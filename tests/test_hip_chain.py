@@ -62,6 +62,36 @@ def test_device_polya_gamma_moments_and_ks():
                                          tilt))
 
 
+def test_device_polya_gamma_draws_do_not_depend_on_the_elements_per_lane():
+    """csrc/pg_queue.hpp: a lane takes E elements (1, 4 or 8 by vector length),
+    every piece of a draw has its own Philox sub-stream of the element -- so
+    the draw of element i depends on (seed, i, shape, tilt) only: a long vector
+    (8 per lane) starts with the draws of its short prefix (1 per lane), bit
+    for bit, binomial shapes (the sequential sampler) mixed in.  And across the
+    range of tilts -- the mixture weight formed from products below |psi| = 40
+    (samplers.hpp right_mass_direct), from logarithms beyond -- the draws pass
+    a two-sample KS test against the host sampler on the reference's stream
+    (random/polya_gamma/polya_gamma.pyx:40-74)."""
+    rng = np.random.default_rng(4)
+    n_long, n_short = 120000, 30000
+    shape = np.ones(n_long, dtype=np.int32)
+    shape[::7] = rng.integers(2, 6, size=len(shape[::7]))
+    tilt = rng.normal(0., 3., n_long)
+    tilt[::11] = rng.normal(0., 30., len(tilt[::11]))      # |psi| up to ~100
+    long_ = _dev_pg(9, shape, tilt)
+    short = _dev_pg(9, shape[:n_short], tilt[:n_short])
+    assert np.array_equal(long_[:n_short], short)
+    assert np.all(np.isfinite(long_)) and np.all(long_ > 0)
+    from bayesbridge_amd.hostrng import ReferenceRandom
+    host = ReferenceRandom(8)
+    for c in (.05, .7, 3., 8., 38., 45., 120.):
+        ones, t = np.ones(60000, dtype=np.int32), np.full(60000, c)
+        a, b_ = _dev_pg(21, ones, t), host.polya_gamma(ones, t)
+        assert stats.ks_2samp(a, b_).pvalue > 1e-3, c
+        mean = 1. / (2 * c) * np.tanh(c / 2)
+        assert abs(a.mean() - mean) < 6 * a.std() / np.sqrt(len(a)), c
+
+
 def test_device_tilted_stable_laplace_transform_and_ks():
     # X ~ exp(-lam x) f_a(x) / E, f_a positive stable with E exp(-s S) =
     # exp(-s^a):  E exp(-s X) = exp(-((s + lam)^a - lam^a))
