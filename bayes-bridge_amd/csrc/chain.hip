@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void chain_pg_lane_kernel(
     const double eta = psi[i];
     const double nt = n_trial[i];
     Philox g(seed, stream, (uint64_t)i);
-    omega[i] = PolyaGamma::draw(g, (int)nt, eta);
+    omega[i] = fabs(eta) <= 1.7e308 ? PolyaGamma::draw(g, (int)nt, eta) : eta - eta;
     acc += n_success[i] * eta - nt * log1pexp(eta);
   }
   const double tot = block_total_256(acc);

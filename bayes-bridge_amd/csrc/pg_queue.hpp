@@ -59,6 +59,12 @@ __device__ inline double polya_gamma_block(
     const double eta = psi[i];
     const double nt = (double)n_trial[i];
     acc += loglik(i, eta, nt);
+    if (!(fabs(eta) <= 1.7e308)) {
+      // a non-finite linear predictor (a failed draw upstream) must not spin in
+      // a rejection loop whose every comparison is false: it propagates
+      omega[i] = eta - eta;   // NaN
+      continue;
+    }
     if (nt != 1.) {
       // binomial outcomes: a sum of n_trial draws, the sequential sampler
       Philox g(seed, stream, (uint64_t)i);

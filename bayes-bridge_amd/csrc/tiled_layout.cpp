@@ -1457,12 +1457,13 @@ void transpose_csr_host(int64_t R, int64_t C, const int64_t* rowptr,
     if (row_cut[t] > R) row_cut[t] = R;
     if (row_cut[t] < row_cut[t - 1]) row_cut[t] = row_cut[t - 1];
   }
+  // (allocated here, not in the workers: a bad_alloc must reach the caller)
   std::vector<std::vector<int64_t>> cnt(n_thr);
+  for (auto& c : cnt) c.assign((size_t)C, 0);
   {
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < n_thr; ++t)
       pool.emplace_back([&, t]() {
-        cnt[t].assign((size_t)C, 0);
         for (int64_t k = rowptr[row_cut[t]]; k < rowptr[row_cut[t + 1]]; ++k)
           cnt[t][(size_t)colidx[k]] += 1;
       });

@@ -82,6 +82,14 @@ def test_device_polya_gamma_draws_do_not_depend_on_the_elements_per_lane():
     short = _dev_pg(9, shape[:n_short], tilt[:n_short])
     assert np.array_equal(long_[:n_short], short)
     assert np.all(np.isfinite(long_)) and np.all(long_ > 0)
+    # a non-finite tilt comes back as NaN (no rejection loop spins on it)
+    bad = tilt[:4096].copy()
+    bad[[5, 77, 900]] = [np.nan, np.inf, -np.inf]
+    out = _dev_pg(9, shape[:4096], bad)
+    assert np.all(np.isnan(out[[5, 77, 900]]))
+    keep = np.ones(4096, dtype=bool)
+    keep[[5, 77, 900]] = False
+    assert np.array_equal(out[keep], long_[:4096][keep])
     from bayesbridge_amd.hostrng import ReferenceRandom
     host = ReferenceRandom(8)
     for c in (.05, .7, 3., 8., 38., 45., 120.):
