@@ -79,6 +79,54 @@ int run_case(int64_t R, int64_t C, double density, bool binary,
   return worst <= 1e-10 ? 0 : 1;
 }
 
+// The 64-bit constructor's host utilities: the threaded transposition against
+// a serial one, the transposed matrix through the layout + emulator, and the
+// structure check on a broken copy.
+int run_transpose_case(int64_t R, int64_t C, double density, uint64_t seed) {
+  Lcg g{seed};
+  std::vector<int64_t> rowptr((size_t)R + 1, 0), col64;
+  std::vector<int32_t> colidx;
+  std::vector<double> vals;
+  for (int64_t r = 0; r < R; ++r) {
+    for (int64_t c = 0; c < C; ++c)
+      if (g.unit() < density) {
+        colidx.push_back((int32_t)c);
+        col64.push_back(c);
+        vals.push_back(g.unit() - .5);
+      }
+    rowptr[(size_t)r + 1] = (int64_t)colidx.size();
+  }
+  const int64_t nnz = (int64_t)colidx.size();
+  if (nnz == 0) return 0;
+  if (bbx::check_csr64_host(R, C, nnz, rowptr.data(), col64.data(), 8) != 0) return 1;
+  bbx::HostCsr t;
+  bbx::transpose_csr_host(R, C, rowptr.data(), colidx.data(), vals.data(), 8, &t);
+  // serial reference: entries of column j in row order
+  std::vector<int64_t> at((size_t)C + 1, 0);
+  for (int64_t k = 0; k < nnz; ++k) at[(size_t)colidx[(size_t)k] + 1] += 1;
+  for (int64_t j = 0; j < C; ++j) at[(size_t)j + 1] += at[(size_t)j];
+  int bad = 0;
+  for (int64_t j = 0; j <= C; ++j) bad += t.rowptr[(size_t)j] != at[(size_t)j];
+  std::vector<int64_t> pos(at.begin(), at.end() - 1);
+  for (int64_t r = 0; r < R; ++r)
+    for (int64_t k = rowptr[(size_t)r]; k < rowptr[(size_t)r + 1]; ++k) {
+      const int64_t w = pos[(size_t)colidx[(size_t)k]]++;
+      bad += t.colidx[(size_t)w] != (int32_t)r || t.vals[(size_t)w] != vals[(size_t)k];
+    }
+  // broken copies: a column id out of range, a row out of order
+  std::vector<int64_t> broken = col64;
+  broken[(size_t)(nnz / 2)] = C;
+  bad += (bbx::check_csr64_host(R, C, nnz, rowptr.data(), broken.data(), 8) & 2) == 0;
+  if (rowptr[1] >= 2) {
+    broken = col64;
+    std::swap(broken[0], broken[1]);
+    bad += (bbx::check_csr64_host(R, C, nnz, rowptr.data(), broken.data(), 8) & 4) == 0;
+  }
+  printf("transpose R=%lld C=%lld nnz=%lld: %s\n", (long long)R, (long long)C,
+         (long long)nnz, bad ? "MISMATCH" : "equal to the serial transposition");
+  return bad ? 1 : 0;
+}
+
 }  // namespace
 
 int main() {
@@ -96,6 +144,9 @@ int main() {
   bad += run_case(700, 40000, .002, true, 128, 2, 3, 1);
   bad += run_case(900, 33000, .0004, true, 0, 0, 8, 1);  // gaps beyond 4095 slots
   bad += run_case(1, 70000, .001, true, 0, 0, 7, 1);
+  bad += run_transpose_case(3000, 900, .05, 11);
+  bad += run_transpose_case(5, 40000, .01, 12);
+  bad += run_transpose_case(20000, 7, .3, 13);
   if (bad) fprintf(stderr, "%d case(s) FAILED\n", bad);
   return bad ? 1 : 0;
 }
