@@ -57,4 +57,35 @@ int bbx_host_tilted_stable(void* bitgen, int64_t n, const double* char_exp,
   return BBX_OK;
 }
 
+int bbx_host_pg_right_mass(int64_t n, const double* z, double* log_form,
+                           double* direct) {
+  if (!z || !log_form || !direct || n < 0) return BBX_ERR_INVALID;
+  for (int64_t i = 0; i < n; ++i) {
+    const double rate = 0.5 * z[i] * z[i] + 0.125 * bbx::kPi * bbx::kPi;
+    log_form[i] = bbx::PolyaGamma::right_mass(z[i], rate);
+    direct[i] = bbx::PolyaGamma::right_mass_direct(z[i], rate);
+  }
+  return BBX_OK;
+}
+
+namespace {
+struct OneUniform {   // hands the series test the uniform it is asked about
+  double u;
+  inline double uniform() { return u; }
+  inline double normal() { return 0.; }
+};
+}  // namespace
+
+int bbx_host_pg_series_accept(int64_t n, const double* x, const double* u,
+                              int32_t* sequential, int32_t* direct) {
+  if (!x || !u || !sequential || !direct || n < 0) return BBX_ERR_INVALID;
+  for (int64_t i = 0; i < n; ++i) {
+    if (!(x[i] > 0.) || !(u[i] > 0. && u[i] < 1.)) return BBX_ERR_INVALID;
+    OneUniform a{u[i]}, b{u[i]};
+    sequential[i] = bbx::PolyaGamma::series_accept(a, x[i]) ? 1 : 0;
+    direct[i] = bbx::PolyaGamma::series_accept_direct(b, x[i]) ? 1 : 0;
+  }
+  return BBX_OK;
+}
+
 }  // extern "C"

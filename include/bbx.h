@@ -568,6 +568,18 @@ int bbx_host_polya_gamma(void* bitgen, int64_t n, const int32_t* shape,
                          const double* tilt, double* out);
 int bbx_host_tilted_stable(void* bitgen, int64_t n, const double* char_exp,
                            const double* tilt, double* out);
+/* Checks of the device chain's Polya-Gamma arithmetic against the
+ * reference-following one, on the host (both are in csrc/samplers.hpp):
+ *   right_mass: log_form[i] = the mixture weight of the exponential piece at
+ *     z[i] as polya_gamma.pyx:115-128 forms it (sums of logarithms),
+ *     direct[i] = the device kernel's product form;
+ *   series_accept: the alternating-series test (polya_gamma.pyx:139-162) of the
+ *     proposal x[i] with the uniform u[i], 1 = accepted: sequential[i] with the
+ *     terms of polya_gamma.pyx:131-137, direct[i] with the kernel's. */
+int bbx_host_pg_right_mass(int64_t n, const double* z, double* log_form,
+                           double* direct);
+int bbx_host_pg_series_accept(int64_t n, const double* x, const double* u,
+                              int32_t* sequential, int32_t* direct);
 
 #ifdef __cplusplus
 }

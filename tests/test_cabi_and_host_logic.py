@@ -112,3 +112,43 @@ def test_fast_generator_distribution():
     assert X.has_sorted_indices
     # exactly distinct rows per column
     assert (X.T.tocsr().multiply(X.T.tocsr()) != X.T.tocsr()).nnz == 0
+
+
+def test_device_forms_of_the_polya_gamma_pieces_equal_the_reference_forms():
+    """The device chain's Polya-Gamma kernel (csrc/pg_queue.hpp) forms the
+    mixture weight of the exponential piece and the terms of the alternating
+    series directly -- products and one exp per term -- where the reference
+    sums logarithms (random/polya_gamma/polya_gamma.pyx:115-137).  Both forms
+    live in csrc/samplers.hpp and compile for the host: here they are compared
+    where it can be done exactly, without a GPU.  The weight agrees to a few
+    ulps across z = |psi| / 2 in [0, 20] (beyond, the kernel calls the log form
+    itself); the series test takes the same decision for every (proposal,
+    uniform) pair of a grid -- except, possibly, uniforms within rounding of a
+    partial sum, which the grid's 2e5 pairs never hit."""
+    from ctypes import c_void_p
+    from bayesbridge_amd import hostrng
+    lib = hostrng.load()
+    z = np.concatenate([np.linspace(0., 20., 4001), np.array([20.5, 30., 60.]),
+                        np.random.default_rng(0).random(2000) * 2.])
+    a, b = np.empty_like(z), np.empty_like(z)
+    assert lib.bbx_host_pg_right_mass(
+        len(z), c_void_p(z.ctypes.data), c_void_p(a.ctypes.data),
+        c_void_p(b.ctypes.data)) == 0
+    assert np.all((a >= 0) & (a < 1)) and np.all(np.isfinite(b))
+    assert np.all(a[z <= 30.] > 0)      # (at z = 60 the weight underflows: both 0)
+    # relative error (the weight falls to 1e-50 at z = 20)
+    ok = a > 0
+    assert np.max(np.abs(a[ok] - b[ok]) / a[ok]) < 1e-12
+    assert np.array_equal(a[z > 20.], b[z > 20.])      # the log form itself
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.random(100000) * .64, .64 + rng.exponential(.5, 100000),
+                        np.array([2. / np.pi, 1e-3, 1e-2, 25.])])
+    u = rng.random(len(x))
+    u[:2000] = 1. - 1e-4 * rng.random(2000)          # near the first partial sum
+    s, d = np.empty(len(x), dtype=np.int32), np.empty(len(x), dtype=np.int32)
+    assert lib.bbx_host_pg_series_accept(
+        len(x), c_void_p(x.ctypes.data), c_void_p(u.ctypes.data),
+        c_void_p(s.ctypes.data), c_void_p(d.ctypes.data)) == 0
+    assert np.array_equal(s, d)
+    assert .9 < s.mean() <= 1.      # the envelope is tight, and rejections exist
+    assert s.min() == 0
