@@ -366,8 +366,10 @@ class HipSparseDesignMatrix(HipDesignMatrix):
         which narrows them itself below that size."""
         fmt = {'auto': _lib.FORMAT_AUTO, 'csr': _lib.FORMAT_CSR,
                'tiled': _lib.FORMAT_TILED}[storage]
-        wide = (np.asarray(indptr).dtype == np.int64
-                and np.asarray(indices).dtype == np.int64)
+        # (either array 64-bit: both go over as int64 -- narrowing a row
+        # pointer past 2^31 here would wrap silently)
+        wide = (np.asarray(indptr).dtype.itemsize > 4
+                or np.asarray(indices).dtype.itemsize > 4)
         dtype = np.int64 if wide else np.int32
         indptr = np.ascontiguousarray(indptr, dtype=dtype)
         indices = np.ascontiguousarray(indices, dtype=dtype)
