@@ -87,7 +87,7 @@ def parse_args(argv=None):
                          "with 'first' block 0 alone paid for them, 4 %% at "
                          "config 2); the line's `roofline` is measured in block "
                          "0 and needs 'first' or 'all'")
-    ap.add_argument("--timing-every", type=int, default=16,
+    ap.add_argument("--timing-every", type=int, default=64,
                     help="one launch in N carries kernel stamps")
     ap.add_argument("--repeat", type=int, default=5,
                     help="how many times the K-step block is run in all for "
@@ -518,8 +518,9 @@ def main():
         # the first gather of a process group sets up the point-to-point
         # connections (RCCL does that lazily, 100s of ms)
         chains.gather_chain_samples(d_coef, dst=0)
-    # kernel stamps / brackets on one launch in 16 (timing every launch costs
-    # ~10% of the iteration; DESIGN.md "Measurement"); switched on before the
+    # kernel stamps / brackets on one launch in --timing-every (64: a stamped
+    # launch costs ~8 us, one in 16 was 1 % of `value` -- LABNOTES R5.11; timing
+    # every launch costs ~10 % of the iteration); switched on before the
     # warm-up so that the event pool exists and the warm-up runs the same code
     timing_on = args.timing_blocks != "none"
     if timing_on:
@@ -685,11 +686,11 @@ def main():
             useful_what="the launch's bytes without the padding of the id "
                         "steps and without the schedules: stored entries x "
                         "index bytes + row ids + vector in + output",
-            timing="kernel begin/end stamps (hipExtLaunchKernelGGL events) on "
-                   "the launching stream, one launch in 16, inside the timed "
-                   "region" if design.storage_format == "tiled" else
-                   "hipEventRecord bracket on the launching stream, one launch "
-                   "in 16, inside the timed region",
+            timing=("kernel begin/end stamps (hipExtLaunchKernelGGL events) on "
+                    "the launching stream, one launch in %d, inside the timed "
+                    "region" if design.storage_format == "tiled" else
+                    "hipEventRecord bracket on the launching stream, one launch "
+                    "in %d, inside the timed region") % args.timing_every,
             operator_frac=round(op_gbs / HBM_PEAK_GBS, 4),
             operator=dict(avg_ms=round(op_avg, 5), bytes=int(op_bytes),
                           gbs=round(op_gbs, 1), launches=op_cnt,
