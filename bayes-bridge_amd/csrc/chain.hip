@@ -929,6 +929,21 @@ int bbx_chain_create(bbx_design* design, int model, const double* outcome,
     init.obs_prec = 1.;
     BBX_HIP(hipMemcpyAsync(c->scalars.ptr, &init, sizeof(init),
                            hipMemcpyHostToDevice, h->stream));
+    // Every state vector is DEFINED from here on: a chain that is run without
+    // bbx_chain_set_state / bbx_chain_init_obs_prec starts from coef = 0, unit
+    // scales and, for the logit model, the Polya-Gamma mean at that coefficient
+    // (psi = 0: logistic_model.py:80-87) -- not from whatever the allocator
+    // returned (non-finite Omega -> "non-finite residual inside CG").
+    for (DevMem* m : {&c->phi, &c->x0, &c->sd, &c->z})
+      BBX_HIP(hipMemsetAsync(m->ptr, 0, Pb, h->stream));
+    BBX_HIP(hipMemsetAsync(c->psi.ptr, 0, nb, h->stream));
+    if (model == BBX_MODEL_LOGIT)
+      hipLaunchKernelGGL(chain_pg_mean_kernel, dim3(grid_for(n, ROW_GRID)),
+                         dim3(256), 0, h->stream, n, c->n_trial.as<double>(),
+                         c->psi.as<double>(), c->obs_prec.as<double>());
+    else
+      BBX_HIP(hipMemsetAsync(c->obs_prec.ptr, 0, nb, h->stream));
+    BBX_HIP(hipGetLastError());
     BBX_HIP(hipStreamSynchronize(h->stream));
     return BBX_OK;
   };

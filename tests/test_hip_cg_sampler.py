@@ -227,6 +227,31 @@ def test_cg_sample_wide_design_with_column_groups_in_the_dot():
     _assert_close(*out)
 
 
+def test_cg_sample_with_more_row_panels_than_partial_sum_slots(monkeypatch):
+    """Past ~1M rows the X layout has more row panels (workgroups) than the 256
+    partial-sum slots of bbx_design::part: the X~ v kernel then leaves the sums
+    of t and <t, Omega t> to separate kernels and the CG loop keeps
+    cg_update_kernel (launch_dot_tiled: `n_panel <= NPART`).  Reached here at
+    40 000 rows by forcing 128-row panels (313 workgroups); against the oracle,
+    and against the same design with the builder's own panels."""
+    from bayesbridge_amd import HipSparseDesignMatrix, simulate
+    X = simulate.simulate_binary_csr_fast(40000, 1500, .02, seed=6)
+    n, P = X.shape[0], X.shape[1] + 1
+    inputs = cg_inputs(n, P, seed=3, lam_log_sd=.3)
+    plain = _run_both(X, inputs, storage='tiled')
+    monkeypatch.setenv('BBX_TILED_PR', '128')
+    hip = HipSparseDesignMatrix(X, center_predictor=True, add_intercept=True,
+                                storage='tiled')
+    assert hip.tiled_info()['X']['grid'] > 256
+    del hip
+    forced = _run_both(X, inputs, storage='tiled')
+    monkeypatch.delenv('BBX_TILED_PR')
+    _assert_close(*forced)
+    assert abs(forced[1]['n_iter'] - plain[1]['n_iter']) <= 1
+    assert np.abs(forced[0] - plain[0]).max() <= 1e-6 * max(
+        1., np.abs(plain[0]).max())
+
+
 @pytest.mark.parametrize("shape", [(6000, 900, .05), (9000, 20000, .004),
                                    (20000, 1000, .02),
                                    (200000, 30000, .002)])

@@ -197,6 +197,39 @@ def test_device_chain_is_reproducible_and_resumable(model):
     assert np.allclose(sb['global_scale'], s1['global_scale'], rtol=1e-12)
 
 
+def test_a_chain_run_straight_after_creation_starts_from_a_defined_state():
+    """bbx_chain_create leaves every state vector defined: coef = 0, unit
+    scales and -- logit -- Omega = the Polya-Gamma mean at psi = 0
+    (logistic_model.py:80-87), so a chain that is run without set_state /
+    init_obs_prec does not read whatever the allocator returned (a recycled
+    buffer full of NaN gave "non-finite residual inside CG").  Two chains
+    created around a poisoned allocation draw the same, finite samples."""
+    import torch
+    from bayesbridge_amd import (HipGibbsChain, HipSparseDesignMatrix,
+                                 simulate)
+    n, p = 60000, 400
+    X = simulate.simulate_binary_csr_fast(n, p, .03, seed=4)
+    y = (np.random.default_rng(1).random(n) < .3).astype(np.float64)
+    hip = HipSparseDesignMatrix(X, center_predictor=False, add_intercept=True)
+    outs = []
+    for _ in range(2):
+        # recycle device memory holding NaN through the allocators
+        junk = [torch.full((n,), float('nan'), dtype=torch.float64,
+                           device='cuda') for _ in range(6)]
+        del junk
+        torch.cuda.empty_cache()
+        chain = HipGibbsChain(hip, 'logit', y, sd_unshrunk=[2.], slab_size=2.,
+                              seed=7)
+        coef, obs, ls, g = chain.get_state()
+        assert np.all(coef == 0.) and np.all(ls == 1.) and g == 1.
+        assert np.all(obs == .5)          # n_trial / 2 at psi = 0, as the reference
+        out, n_bad = chain.run(3)
+        assert n_bad == 0 and np.all(np.isfinite(out['coef']))
+        outs.append(out['coef'])
+        chain.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_device_chain_agrees_with_reference_stream_chain():
     """Same posterior, different random streams: posterior means of the large
     coefficients and of log tau agree within Monte Carlo error."""

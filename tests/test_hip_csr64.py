@@ -242,6 +242,18 @@ def test_a_design_of_more_than_2_31_stored_entries():
     gm = hip.gram_matvec(omega, v)
     ref_gm = block.Tdot((omega * ref_t).reshape(COPIES, N_A).sum(axis=0))
     assert np.abs(gm - ref_gm).max() <= 1e-9 * np.abs(ref_gm).max()
+    # a device chain runs on it: three Gibbs iterations of the logit model
+    from bayesbridge_amd import HipGibbsChain
+    y = (rng.random(n) < .3).astype(np.float64)
+    chain = HipGibbsChain(hip, 'logit', y, sd_unshrunk=[], slab_size=1.,
+                          seed=3)
+    chain.set_state(np.zeros(P_BIG), None, np.ones(P_BIG), .01)
+    chain.init_obs_prec()
+    out, n_unconverged = chain.run(3)
+    assert n_unconverged == 0 and np.all(out['n_cg_iter'] > 0)
+    assert np.all(np.isfinite(out['coef'])) and np.all(np.isfinite(out['logp']))
+    n_cg = out['n_cg_iter']
+    del chain
     # the rate of the two products at this size (kernel stamps)
     hip.set_timing(True)
     for _ in range(5):
@@ -252,9 +264,10 @@ def test_a_design_of_more_than_2_31_stored_entries():
     hip.set_timing(False)
     assert min(rate.values()) > 1000.        # GB/s: streaming, not crawling
     print("nnz %d: arrays in %.0f s, design built in %.0f s, storage %.1f GB, "
-          "tiled %s; X~ v %.2f ms = %.0f GB/s, X~^T w %.2f ms = %.0f GB/s"
+          "tiled %s; chain n_cg %s; X~ v %.2f ms = %.0f GB/s, X~^T w %.2f ms = "
+          "%.0f GB/s"
           % (nnz, t_gen, t_build, hip.storage_bytes / 1e9,
              {k: (d['W'], d['PR'], d['G'], d['packed'])
-              for k, d in hip.tiled_info().items()},
+              for k, d in hip.tiled_info().items()}, n_cg.astype(int).tolist(),
              tm['dot'][1] / tm['dot'][0], rate['dot'],
              tm['tdot'][1] / tm['tdot'][0], rate['tdot']))
