@@ -87,8 +87,12 @@ def parse_args(argv=None):
                          "with 'first' block 0 alone paid for them, 4 %% at "
                          "config 2); the line's `roofline` is measured in block "
                          "0 and needs 'first' or 'all'")
-    ap.add_argument("--timing-every", type=int, default=64,
-                    help="one launch in N carries kernel stamps")
+    ap.add_argument("--timing-every", type=int, default=0,
+                    help="one launch in N carries kernel stamps; 0 (default): "
+                         "chosen after the warm-up so that a K-step block "
+                         "holds ~24 stamped launches per kernel, between one "
+                         "in 8 and one in 64 (a stamped launch costs ~8 us: "
+                         "LABNOTES R5.11)")
     ap.add_argument("--repeat", type=int, default=5,
                     help="how many times the K-step block is run in all for "
                          "the `repeat` object (the first is the timed region "
@@ -524,10 +528,15 @@ def main():
     # warm-up so that the event pool exists and the warm-up runs the same code
     timing_on = args.timing_blocks != "none"
     if timing_on:
-        design.set_timing(True, every=args.timing_every)
+        design.set_timing(True, every=args.timing_every or 16)
     ncg_w = chain.run_device(W, d_coef_ptr=d_buf.data_ptr())[2] \
         if W > 0 else np.zeros(0)
     if timing_on:
+        if not args.timing_every:
+            # ~24 stamped launches per kernel and K-step block
+            per_block = K * (float(np.mean(ncg_w)) if len(ncg_w) else 30.)
+            args.timing_every = int(min(64, max(8, per_block // 24)))
+            design.set_timing(True, every=args.timing_every)
         design.reset_timing()
     chains.barrier()
     torch.cuda.synchronize()
