@@ -349,8 +349,8 @@ def test_mixed_design_of_the_reference_helper_is_stored_split():
     assert np.abs(c_h - c_o).max() <= tol * max(1., np.abs(c_o).max())
 
 
-@pytest.mark.parametrize("n_dense", [1, 5, 8, 9, 20, 127, 130, 300, 700, 1500,
-                                     2100, 4500, 8192])
+@pytest.mark.parametrize("n_dense", [1, 5, 8, 9, 20, 127, 130, 300, 700, 1501,
+                                     2100, 4501, 8192])
 def test_dense_columns_ride_in_the_dot_epilogue_of_an_operator_application(n_dense):
     """Binary covariates plus a few continuous ones (the OHDSI shape).  Inside
     ONE operator application X~^T (Omega (X~ v)) -- bbx_design_gram_matvec and
@@ -361,7 +361,7 @@ def test_dense_columns_ride_in_the_dot_epilogue_of_an_operator_application(n_den
     (hyb_dense_fused_kernel: a wave per row, 1 / 2 / 4 / 8 column pairs per
     lane -- 127, 130, 300 and 700 columns cross those widths; 1025 ... 8192:
     hyb_dense_fused_wg_kernel, a workgroup per row block, 1 / 2 / 4 pairs per
-    thread -- 1500, 2100 and 4500 / 8192; the reference's generator default,
+    thread -- 1501, 2100 and 4501 / 8192 (odd widths: the last pair is half used); the reference's generator default,
     simulate_data.py:29 binary_frac=.5, at 10 000 columns is 5 000 of them),
     more stay in the valued layout.  Against the two separate
     products (which never use the fused epilogue) and NumPy; a CG draw against
