@@ -24,7 +24,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for path in (ROOT, os.path.join(ROOT, "bayes-bridge_amd")):
+# (BBX_PACKAGE_DIR: another build of the package, for A/B runs of two libraries)
+for path in (ROOT, os.environ.get("BBX_PACKAGE_DIR",
+                                  os.path.join(ROOT, "bayes-bridge_amd"))):
     if path not in sys.path:
         sys.path.insert(0, path)
 
