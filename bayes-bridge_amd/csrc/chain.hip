@@ -43,9 +43,18 @@ __global__ __launch_bounds__(256) void chain_prior_kernel(
     const double* __restrict__ sd_unshrunk, const double* __restrict__ mean,
     const double* __restrict__ square, const double* __restrict__ zbase,
     double* __restrict__ phi, double* __restrict__ x0, double* __restrict__ sd,
-    double* __restrict__ z) {
+    double* __restrict__ z, int store_idx, double* __restrict__ samp_gs,
+    double* __restrict__ samp_lp) {
   const double g = sc->gscale;
   const double zs = (model == BBX_MODEL_LINEAR) ? sc->obs_prec : 1.;
+  // global scale and log posterior of the PREVIOUS iteration, if it was kept
+  // (chain_save_sample defers them to here: the scalars are untouched between
+  // the end of an iteration and this kernel, and a launch of its own for two
+  // stores sat on the serial stretch in front of every solve)
+  if (store_idx >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    samp_gs[store_idx] = g;
+    samp_lp[store_idx] = sc->logp();
+  }
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < P;
        j += (int64_t)gridDim.x * 256) {
     double prior_sd, guess = mean[j];
@@ -589,7 +598,9 @@ int chain_pre_draw(bbx_chain* c) {
                      c->sd_unshrunk.as<double>(), c->mean.as<double>(),
                      c->square.as<double>(), c->zbase.as<double>(),
                      c->phi.as<double>(), c->x0.as<double>(),
-                     c->sd.as<double>(), c->z.as<double>());
+                     c->sd.as<double>(), c->z.as<double>(), c->pending_store,
+                     c->samp_gscale.as<double>(), c->samp_logp.as<double>());
+  c->pending_store = -1;
   if (c->model == BBX_MODEL_LINEAR)
     hipLaunchKernelGGL(chain_fill_obs_prec_kernel, dim3(grid_for(n, ROW_GRID)),
                        dim3(256), 0, s, n, sc, c->obs_prec.as<double>());
@@ -764,8 +775,13 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
   const bool have_eta = c->eta_iter == (long long)it && c->eta1_next.ptr;
   struct TailScope {
     bbx_design* h;
-    ~TailScope() { h->tail_hook = nullptr; h->tail_ctx = nullptr; }
+    ~TailScope() {
+      h->tail_hook = nullptr;
+      h->tail_ctx = nullptr;
+      h->coef_copy = nullptr;
+    }
   } tail_scope{c->h};
+  c->h->coef_copy = c->coef_sample;
   if (chain_tail_applies(c)) {
     c->h->tail_hook = chain_tail_hook;
     c->h->tail_ctx = c;
@@ -788,6 +804,8 @@ static int chain_step(bbx_chain* c, int maxiter, double atol, int* n_cg_iter) {
 }
 
 int chain_begin_run(bbx_chain* c, int n_sample) {
+  c->pending_store = -1;   // (a run that ended in an error may have left one)
+  c->coef_sample = nullptr;
   BBX_TRY(c->samp_gscale.alloc(sizeof(double) * (size_t)(n_sample + 1)));
   BBX_TRY(c->samp_logp.alloc(sizeof(double) * (size_t)(n_sample + 1)));
   return BBX_OK;
@@ -798,10 +816,12 @@ int chain_save_sample(bbx_chain* c, int idx, double* d_coef, double* d_lscale,
   bbx_design* h = c->h;
   const int64_t P = h->P, n = h->n;
   const int64_t n_shrunk = P - c->n_unshrunk;
-  if (d_coef)
+  // (coef_sample: the CG loop's finish kernel has written this sample already)
+  if (d_coef && c->coef_sample != d_coef + (size_t)idx * P)
     BBX_HIP(hipMemcpyAsync(d_coef + (size_t)idx * P, c->coef.ptr,
                            sizeof(double) * (size_t)P,
                            hipMemcpyDeviceToDevice, h->stream));
+  c->coef_sample = nullptr;
   if (d_lscale && n_shrunk > 0)
     BBX_HIP(hipMemcpyAsync(d_lscale + (size_t)idx * n_shrunk, c->lscale.ptr,
                            sizeof(double) * (size_t)n_shrunk,
@@ -816,15 +836,22 @@ int chain_save_sample(bbx_chain* c, int idx, double* d_coef, double* d_lscale,
           d_obs_prec + idx, &c->scalars.as<ChainScalars>()->obs_prec,
           sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   }
-  hipLaunchKernelGGL(chain_store_scalars_kernel, dim3(1), dim3(64), 0,
-                     h->stream, c->scalars.as<ChainScalars>(), idx,
-                     c->samp_gscale.as<double>(), c->samp_logp.as<double>());
-  BBX_HIP(hipGetLastError());
+  // global scale and log posterior: stored by the next iteration's
+  // chain_prior_kernel, or by chain_end_run after the last one
+  c->pending_store = idx;
   return BBX_OK;
 }
 
 int chain_end_run(bbx_chain* c, int n_sample, double* gscale, double* logp) {
   bbx_design* h = c->h;
+  if (c->pending_store >= 0) {
+    hipLaunchKernelGGL(chain_store_scalars_kernel, dim3(1), dim3(64), 0,
+                       h->stream, c->scalars.as<ChainScalars>(),
+                       c->pending_store, c->samp_gscale.as<double>(),
+                       c->samp_logp.as<double>());
+    BBX_HIP(hipGetLastError());
+    c->pending_store = -1;
+  }
   if (gscale && n_sample > 0)
     BBX_HIP(hipMemcpyAsync(gscale, c->samp_gscale.ptr,
                            sizeof(double) * (size_t)n_sample,
@@ -1195,12 +1222,16 @@ static int bbx_chain_run_impl(bbx_chain* c, int n_iter, int n_burnin, int thin,
   int n_unconverged = 0;
   for (int it = 1; it <= n_iter; ++it) {
     int ncg = 0;
+    const bool kept = it > n_burnin && (it - n_burnin) % thin == 0 &&
+                      (it - n_burnin) / thin - 1 < n_sample;
+    const int idx = kept ? (it - n_burnin) / thin - 1 : -1;  // gibbs_util.py:170
+    // a kept iteration's coefficients go to their sample slot straight from the
+    // CG loop's finish kernel (one D2D copy less on the stretch between solves)
+    c->coef_sample = (kept && d_coef) ? d_coef + (size_t)idx * P : nullptr;
     int info = chain_step(c, maxiter, atol, &ncg);
     if (info < 0) return info;
     if (info > 0) ++n_unconverged;
-    if (it <= n_burnin || (it - n_burnin) % thin != 0) continue;
-    const int idx = (it - n_burnin) / thin - 1;  // gibbs_util.py:170
-    if (idx >= n_sample) continue;
+    if (!kept) continue;
     BBX_TRY(chain_save_sample(c, idx, d_coef, d_lscale, d_obs_prec));
     if (n_cg_iter) n_cg_iter[idx] = (double)ncg;
   }

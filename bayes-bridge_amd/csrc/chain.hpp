@@ -54,6 +54,12 @@ struct bbx_chain {
   bbx::DevMem eta1_next, eta2_next;     // n, P
   long long eta_iter = -1;
   bbx::DevMem samp_gscale, samp_logp;   // per kept sample (device)
+  // deferred bookkeeping of a kept iteration: its scalars are stored by the
+  // next chain_prior_kernel (pending_store = sample index, -1: none); its
+  // coefficients by the CG loop's finish kernel when the run loop announced the
+  // slot beforehand (coef_sample, else chain_save_sample copies)
+  int pending_store = -1;
+  double* coef_sample = nullptr;
   void* pinned = nullptr;
   // second stream for the tau / lambda branch of an iteration
   hipStream_t stream2 = nullptr;

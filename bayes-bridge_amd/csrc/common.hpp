@@ -243,6 +243,9 @@ struct bbx_design {
   // Work the caller wants enqueued right behind a look at the stop flag, before
   // the host waits: it runs iff the rule has fired (skip flag = &CGState::running;
   // cg_sampler.hip).  tail_ran: it was enqueued at the look that found `done`.
+  // Second destination of the draw (cg_finish_kernel writes coef there too): a
+  // chain's sample slot for a kept iteration.  Set around ONE solve.
+  double* coef_copy = nullptr;
   int (*tail_hook)(void*) = nullptr;
   void* tail_ctx = nullptr;
   bool tail_ran = false;

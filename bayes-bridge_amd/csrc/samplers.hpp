@@ -39,6 +39,37 @@ constexpr double kPi = 3.14159265358979323846;
 // sampler whose device stream only has to match in distribution.
 BBX_HD inline double pos_pow(double x, double y) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(BBX_POS_POW_GENERIC)
+  // The exponents of the tilted-stable sampler are functions of a = alpha / 2
+  // alone -- a, 1 - a, 1 / (1 - a), (1 - a) / a, -1 / a -- i.e. constants of a
+  // launch (uniform, scalar compares).  For the reference's default bridge
+  // exponent alpha = 1/2 (a = 1/4: 1/4, 3/4, 4/3, +-3, +-4) and for alpha = 1
+  // (a = 1/2: 1/2, +-1, +-2) every one of them is a root or a small integer
+  // power: a few multiplications and square / cube roots, correctly rounded or
+  // nearly so, instead of exp(y log x) -- 40 % of the lambda kernel's arithmetic
+  // (profiles/r05_lscale_pow.txt).
+  if (y == 0.25) return sqrt(sqrt(x));
+  if (y == 0.75) {
+    const double r = sqrt(x);
+    return r * sqrt(r);
+  }
+  if (y == 0.5) return sqrt(x);
+  if (y == 3.) return x * x * x;
+  if (y == -3.) return 1. / (x * x * x);
+  if (y == 4. / 3.) return x * cbrt(x);
+  if (y == 4.) {
+    const double q = x * x;
+    return q * q;
+  }
+  if (y == -4.) {
+    const double q = x * x;
+    return 1. / (q * q);
+  }
+  if (y == 1.) return x;
+  if (y == -1.) return 1. / x;
+  if (y == 2.) return x * x;
+  if (y == -2.) return 1. / (x * x);
+#endif
   return exp(y * log(x));
 #else
   return pow(x, y);

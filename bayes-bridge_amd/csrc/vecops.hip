@@ -278,12 +278,17 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_update_kernel(
 }
 
 // coef = s .* x   (cg_sampler.py:89)
+// `copy`: a second destination (bbx_design::coef_copy: the sample slot of a
+// chain's kept iteration, instead of a D2D copy after the solve).
 __global__ __launch_bounds__(VEC_BLOCK) void cg_finish_kernel(
     int64_t P, const double* __restrict__ s, const double* __restrict__ x,
-    double* __restrict__ coef) {
+    double* __restrict__ coef, double* __restrict__ copy) {
   for (int64_t jj = (int64_t)blockIdx.x * VEC_BLOCK + threadIdx.x; jj < P;
-       jj += (int64_t)gridDim.x * VEC_BLOCK)
-    coef[jj] = s[jj] * x[jj];
+       jj += (int64_t)gridDim.x * VEC_BLOCK) {
+    const double v = s[jj] * x[jj];
+    coef[jj] = v;
+    if (copy) copy[jj] = v;
+  }
 }
 
 int launch_cg_setup(bbx_design* h, int n_unshrunk, const double* phi,
@@ -319,7 +324,7 @@ int launch_cg_update(bbx_design* h, int k, CGState* st, const double* pq_part,
 int launch_cg_finish(bbx_design* h, const double* s, const double* x,
                      double* coef) {
   hipLaunchKernelGGL(cg_finish_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
-                     h->stream, h->P, s, x, coef);
+                     h->stream, h->P, s, x, coef, h->coef_copy);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }
