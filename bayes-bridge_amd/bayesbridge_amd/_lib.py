@@ -12,7 +12,7 @@ from ctypes import (POINTER, byref, c_char_p, c_double, c_int, c_int32,
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libbbx.so")
 
-ABI_VERSION = 102          # BBX_VERSION of include/bbx.h
+ABI_VERSION = 103          # BBX_VERSION of include/bbx.h
 FORMAT_AUTO, FORMAT_CSR, FORMAT_TILED = 0, 1, 2
 F64, F32 = 0, 1
 MODEL_LINEAR, MODEL_LOGIT = 0, 1
@@ -86,6 +86,9 @@ def _declare(lib):
             [hp, POINTER(c_int64), POINTER(c_int64)], c_int),
         "bbx_design_fused_operator_bytes": ([hp, POINTER(c_int64)], c_int),
         "bbx_design_cg_launches": ([hp, POINTER(c_int)], c_int),
+        "bbx_design_cg_stats": ([hp, POINTER(c_int64), POINTER(c_int64),
+                                 c_int], c_int),
+        "bbx_launch_count": ([], c_uint64),
         "bbx_design_set_cg_fold": ([hp, c_int], c_int),
         "bbx_design_hybrid_info": (
             [hp, POINTER(c_int), POINTER(c_int64), POINTER(c_int64),

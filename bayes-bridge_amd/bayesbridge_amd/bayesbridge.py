@@ -29,7 +29,7 @@ from . import _lib
 from .device_chain import HipGibbsChain
 from .hostrng import ReferenceRandom
 from .model import LogisticModel
-from .prior import RegressionCoefPrior
+from .prior import RegressionCoefPrior, unit_magnitude
 from .reg_coef_sampler import (HipRegressionCoefficientSampler,
                                RegressionCoeffficientPosteriorSummarizer)
 
@@ -157,10 +157,15 @@ class BayesBridge():
               init={'global_scale': 0.1},
               params_to_save=('coef', 'global_scale', 'logp'),
               coef_sampler_type=None, n_status_update=0, options=None,
-              _resume_from=None):
+              _resume_from=None, _device_out=None):
         """Generate posterior samples (bayesbridge.py:109-277).  Returns
         (samples, mcmc_info); `samples['coef']` is (n_pred, n_sample) with the
-        MCMC index last."""
+        MCMC index last.
+
+        _device_out (device-RNG mode; chains.run_chains): {name: torch CUDA
+        tensor, float64, contiguous, SAMPLE-major [n_sample, dim]} for names
+        out of 'coef', 'local_scale', 'obs_prec' -- those samples are left in
+        HBM (ready for the RCCL gather) and are absent from `samples`."""
         if not isinstance(options, SamplerOptions):
             options = SamplerOptions.pick_default_and_create(
                 coef_sampler_type, options, self.model.name, self.model.design)
@@ -169,15 +174,29 @@ class BayesBridge():
                               'obs_prec')
         start_time = time.time()
         if options.rng == 'reference':
+            if _device_out:
+                raise ValueError("_device_out needs the device-RNG mode")
             out = self._gibbs_reference_rng(
                 n_iter, n_burnin, thin, seed, init, params_to_save, options,
                 n_status_update, _resume_from)
         else:
             out = self._gibbs_device(
                 n_iter, n_burnin, thin, seed, init, params_to_save, options,
-                _resume_from)
-        return self._package(out, n_iter, n_burnin, thin, seed, params_to_save,
-                             options, time.time() - start_time)
+                _resume_from, _device_out)
+        samples, mcmc_info = self._package(
+            out, n_iter, n_burnin, thin, seed, params_to_save, options,
+            time.time() - start_time)
+        if _device_out and 'local_scale' in _device_out \
+                and self.prior._gscale_paramet == 'coef_magnitude':
+            # the rescaling of bayesbridge.py:244-251, where the samples are
+            # (a true division, as NumPy's on the host samples: torch turns
+            # division by a Python scalar into a multiplication by 1 / m)
+            t = _device_out['local_scale']
+            t.div_(t.new_full((1,), unit_magnitude(self.prior.bridge_exp)))
+        return samples, mcmc_info
+
+    # what chains.run_chains looks for before it hands out device buffers
+    supports_device_samples = True
 
     def _package(self, out, n_iter, n_burnin, thin, seed, params_to_save,
                  options, runtime):
@@ -620,7 +639,7 @@ class BayesBridge():
         self._chain_seed = seed
 
     def _gibbs_device(self, n_iter, n_burnin, thin, seed, init,
-                      params_to_save, options, resume_from):
+                      params_to_save, options, resume_from, device_out=None):
         model, prior = self.model, self.prior
         bridge_exp = prior.bridge_exp
         if resume_from is not None:
@@ -637,14 +656,39 @@ class BayesBridge():
         chain = self._chain
         init_used, optim_info = self._device_setup(chain, seed, init, options,
                                                    resume_from)
-        samples, _ = self._pre_allocate(n_iter - n_burnin, thin,
-                                        params_to_save)
-        kept, n_unconv = chain.run(
-            n_iter, n_burnin, thin, maxiter=500, atol=0.,
-            save=[k for k in ('coef', 'local_scale', 'obs_prec')
-                  if k in samples])
+        device_out = dict(device_out or {})
+        host_params = tuple(k for k in params_to_save if k not in device_out)
+        samples, _ = self._pre_allocate(n_iter - n_burnin, thin, host_params)
+        if device_out:
+            n_sample = (n_iter - n_burnin) // thin
+            dims = {'coef': self.n_pred,
+                    'local_scale': self.n_pred - self.n_unshrunk,
+                    'obs_prec': self.n_obs if model.name == 'logit' else 1}
+            for name, t in device_out.items():
+                want = (n_sample, dims[name])
+                if name not in params_to_save or not t.is_cuda \
+                        or not t.is_contiguous() or str(t.dtype) != \
+                        'torch.float64' or t.numel() != want[0] * want[1] \
+                        or t.device.index != model.design.device:
+                    raise ValueError(
+                        "_device_out[%r] must be a contiguous float64 tensor "
+                        "of %d x %d on the design's device" % ((name,) + want))
+            if any(k in samples for k in ('coef', 'local_scale', 'obs_prec')):
+                raise ValueError("vector samples go either all to the device "
+                                 "or all to the host")
+            gs, lp, ncg, n_unconv = chain.run_device(
+                n_iter, n_burnin=n_burnin, thin=thin, maxiter=500, atol=0.,
+                **{'d_%s_ptr' % {'coef': 'coef', 'local_scale': 'lscale',
+                                 'obs_prec': 'obs_prec'}[k]: t.data_ptr()
+                   for k, t in device_out.items()})
+            kept = {'global_scale': gs, 'logp': lp, 'n_cg_iter': ncg}
+        else:
+            kept, n_unconv = chain.run(
+                n_iter, n_burnin, thin, maxiter=500, atol=0.,
+                save=[k for k in ('coef', 'local_scale', 'obs_prec')
+                      if k in samples])
         return self._device_collect(chain, seed, kept, n_unconv, n_iter,
-                                    n_burnin, thin, params_to_save, init_used,
+                                    n_burnin, thin, host_params, init_used,
                                     optim_info)
 
     def _device_setup(self, chain, seed, init, options, resume_from=None):

@@ -206,15 +206,49 @@ def run_chains(bridge, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
     mine = split_chains(n_chain, world, rank)
     per_rank = -(-n_chain // world)               # ranks pad to equal counts
     init = {'global_scale': .1} if init is None else init
+    if params_to_save == 'all':
+        params_to_save = ('coef', 'local_scale', 'global_scale', 'logp',
+                          'obs_prec')
+    n_sample = (n_iter - n_burnin) // thin
     kept, infos = {}, []
+    # Vector-valued samples never visit the host on their way to the
+    # collective: a chain writes them (bbx_chain_run's device buffers) into
+    # its slot of ONE device tensor per parameter, [per_rank, n_sample, dim],
+    # and that tensor is what RCCL gathers.  (A bridge without the hook -- the
+    # CPU stand-in of the gloo tests -- and batched chains hand over host
+    # arrays, which are put into the same slots.)
+    dev_names = ()
+    rng_mode = options.get('rng', 'device') if isinstance(options, dict) \
+        else getattr(options, 'rng', 'device')
+    if getattr(bridge, 'supports_device_samples', False) \
+            and torch.cuda.is_available() and rng_mode != 'reference':
+        dev_names = tuple(k for k in ('coef', 'local_scale', 'obs_prec')
+                          if k in params_to_save)
+    slabs = {}
+    if dev_names:
+        design = bridge.model.design
+        dims = {'coef': bridge.n_pred,
+                'local_scale': bridge.n_pred - bridge.n_unshrunk,
+                'obs_prec': bridge.n_obs if bridge.model.name == 'logit'
+                else 1}
+        for name in dev_names:
+            slabs[name] = torch.zeros(
+                (per_rank, n_sample, dims[name]), dtype=torch.float64,
+                device='cuda:%d' % design.device)
 
     def keep(k, samples, info):
+        slot = len(infos)
         info['chain'] = k
         infos.append(info)
         samples = dict(samples)
         samples['n_cg_iter'] = info['_reg_coef_sampling_info']['n_cg_iter']
         for name, arr in samples.items():
-            kept.setdefault(name, []).append(np.asarray(arr, dtype=np.float64))
+            arr = np.asarray(arr, dtype=np.float64)
+            if name in slabs:     # host copy of a batched chain: into its slot
+                slabs[name][slot].copy_(torch.from_numpy(
+                    np.ascontiguousarray(arr.T).reshape(n_sample, -1)))
+            else:
+                kept.setdefault(name, []).append(arr)
     # batch != False: this rank's chains go through the design in BATCHES that
     # share every pass over X (BayesBridge.gibbs_batch) instead of one after
     # the other; what does not fill a batch runs alone.  A chain's seed (hence
@@ -249,10 +283,14 @@ def run_chains(bridge, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
                 keep(k, samples, info)
         else:
             k = todo.pop(0)
+            extra = {}
+            if slabs:
+                extra['_device_out'] = {name: slab[len(infos)]
+                                        for name, slab in slabs.items()}
             samples, info = bridge.gibbs(
                 n_iter, n_burnin, thin, seed=chain_seed(seed, k),
                 init=copy.deepcopy(init), params_to_save=params_to_save,
-                coef_sampler_type='cg', options=options)
+                coef_sampler_type='cg', options=options, **extra)
             info['batch'] = {'requested': batch or False, 'width': 1, 'slot': 0}
             keep(k, samples, info)
     names = sorted(kept) if kept else None
@@ -263,6 +301,28 @@ def run_chains(bridge, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
         dist.broadcast_object_list(box, src=src_rank)
         names = box[0]
     merged = {}
+
+    def place(got, shape):
+        # [world, per_rank, ...] -> [n_chain, ...] in chain order
+        out = np.empty((n_chain,) + tuple(shape))
+        for r in range(got.shape[0]):
+            for slot, k in enumerate(split_chains(n_chain, got.shape[0], r)):
+                out[k] = got[r, slot]
+        return out
+    # (1) the device slabs: straight into the collective
+    for name in dev_names:
+        got = gather_chain_samples(slabs[name], dst=dst)
+        if got is None:
+            continue
+        got = got.cpu().numpy()                   # [world, per_rank, n_sample, dim]
+        out = place(got, got.shape[2:])
+        out = np.ascontiguousarray(np.swapaxes(out, 1, 2))  # MCMC index last
+        if name == 'obs_prec' and out.shape[1] == 1 \
+                and bridge.model.name == 'linear':
+            out = out[:, 0]
+        merged[name] = out
+    # (2) whatever lives on the host (the per-sample scalars; everything for a
+    # bridge without device buffers), one gather per parameter
     for name in names:
         have = kept.get(name, [])
         if have:
@@ -281,12 +341,7 @@ def run_chains(bridge, n_chain, n_iter, n_burnin=0, thin=1, seed=0,
         got = gather_chain_samples(torch.from_numpy(padded), dst=dst)
         if got is None:
             continue
-        got = got.numpy()                          # [world, per_rank, ...]
-        out = np.empty((n_chain,) + tuple(shape))
-        for r in range(got.shape[0]):
-            for slot, k in enumerate(split_chains(n_chain, got.shape[0], r)):
-                out[k] = got[r, slot]
-        merged[name] = out
+        merged[name] = place(got.numpy(), shape)
     if world > 1 and rank != dst:
         return None, infos
     return merged, infos

@@ -198,18 +198,23 @@ class HipGibbsChain():
         return out, n_unconv
 
     def run_device(self, n_iter, d_coef_ptr=None, n_burnin=0, thin=1,
-                   maxiter=500, atol=0.):
-        """Same, but the kept coefficient samples go to a DEVICE buffer
-        (raw pointer, sample-major [n_sample, P]); nothing but the per-sample
-        scalars crosses PCIe.  Returns (global_scale, logp, n_cg_iter,
-        n_unconverged)."""
+                   maxiter=500, atol=0., d_lscale_ptr=None,
+                   d_obs_prec_ptr=None):
+        """Same, but the kept samples go to DEVICE buffers (raw pointers,
+        sample-major: coef [n_sample, P], local_scale [n_sample, P -
+        n_unshrunk], obs_prec [n_sample, n] (logit) or [n_sample] (linear));
+        nothing but the per-sample scalars crosses PCIe.  Returns
+        (global_scale, logp, n_cg_iter, n_unconverged)."""
         n_sample = (n_iter - n_burnin) // thin
         rows = max(n_sample, 1)
         gs, lp, ncg = np.zeros(rows), np.zeros(rows), np.zeros(rows)
+
+        def dev(p):
+            return c_void_p(int(p)) if p else None
         n_unconv = _lib.check(self._lib.bbx_chain_run(
             self._c, int(n_iter), int(n_burnin), int(thin), int(maxiter),
-            float(atol), c_void_p(d_coef_ptr) if d_coef_ptr else None, None,
-            None, _ptr(gs), _ptr(lp), _ptr(ncg)))
+            float(atol), dev(d_coef_ptr), dev(d_lscale_ptr),
+            dev(d_obs_prec_ptr), _ptr(gs), _ptr(lp), _ptr(ncg)))
         return gs[:n_sample], lp[:n_sample], ncg[:n_sample], n_unconv
 
 

@@ -192,6 +192,14 @@ int design_alloc_work(bbx_design* h) {
   BBX_TRY(h->stage_n.alloc(sizeof(double) * (size_t)h->n * 2));
   BBX_TRY(h->stage_P.alloc(sizeof(double) * (size_t)h->P * 6));
   BBX_HIP(hipHostMalloc(&h->host_pinned, 256, hipHostMallocDefault));
+  // the CG loop's progress word: coherent host memory the device writes
+  void* word = nullptr;
+  BBX_HIP(hipHostMalloc(&word, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  h->cg_word_host = static_cast<unsigned long long*>(word);
+  *h->cg_word_host = 0;
+  void* dword = nullptr;
+  BBX_HIP(hipHostGetDevicePointer(&dword, word, 0));
+  h->cg_word_dev = static_cast<unsigned long long*>(dword);
   return BBX_OK;
 }
 
@@ -264,7 +272,7 @@ __global__ void validate_csr_kernel(int64_t n, int64_t p, int64_t nnz,
 static int validate_csr(bbx_design* h) {
   int* d_flag = static_cast<int*>(h->cg_state.ptr);  // scratch
   BBX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), h->stream));
-  hipLaunchKernelGGL(validate_csr_kernel, dim3(4096), dim3(256), 0, h->stream,
+  BBX_LAUNCH(validate_csr_kernel, dim3(4096), dim3(256), 0, h->stream,
                      h->n, h->p, h->nnz, h->indptr.as<int32_t>(),
                      h->indices.as<int32_t>(), d_flag);
   BBX_HIP(hipGetLastError());
@@ -351,7 +359,7 @@ static int finish_csr(bbx_design* h, int format) {
     int* d_flag = static_cast<int*>(h->cg_state.ptr);  // scratch
     int one = 1;
     BBX_HIP(hipMemcpy(d_flag, &one, sizeof(int), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(all_ones_kernel, dim3(2048), dim3(256), 0, h->stream,
+    BBX_LAUNCH(all_ones_kernel, dim3(2048), dim3(256), 0, h->stream,
                        h->nnz, h->data.as<double>(), d_flag);
     BBX_HIP(hipGetLastError());
     BBX_HIP(hipStreamSynchronize(h->stream));
@@ -707,10 +715,10 @@ static int bbx_hbm_probe_impl(int device, int64_t bytes, int reps, double* read_
     for (int it = -2; it < reps; ++it) {  // two untimed warm-up launches
       if (it == 0) BBX_PROBE(hipEventRecord(e0, stream));
       if (pass == 0)
-        hipLaunchKernelGGL(hbm_read_kernel, dim3(grid), dim3(256), 0, stream,
+        BBX_LAUNCH(hbm_read_kernel, dim3(grid), dim3(256), 0, stream,
                            (const v4u_probe*)src, n16, (unsigned*)dst);
       else
-        hipLaunchKernelGGL(hbm_copy_kernel, dim3(grid), dim3(256), 0, stream,
+        BBX_LAUNCH(hbm_copy_kernel, dim3(grid), dim3(256), 0, stream,
                            (const v4u_probe*)src, (v4u_probe*)dst, n16);
     }
     BBX_PROBE(hipGetLastError());
@@ -776,6 +784,7 @@ int bbx_design_destroy(bbx_design* h) {
   }
   if (h->ev_poll) (void)hipEventDestroy(h->ev_poll);
   if (h->host_pinned) (void)hipHostFree(h->host_pinned);
+  if (h->cg_word_host) (void)hipHostFree(h->cg_word_host);
   destroy_tiled(h);
   hipStream_t s = h->stream;
   delete h;  // frees every DevMem
@@ -1202,6 +1211,19 @@ int bbx_design_useful_bytes(const bbx_design* h, int64_t* dot_bytes,
 int bbx_design_set_cg_fold(bbx_design* h, int on) {
   BBX_TRY(check_handle(h));
   h->cg_fold = on < 0 ? -1 : (on ? 1 : 0);
+  return BBX_OK;
+}
+
+uint64_t bbx_launch_count(void) {
+  return bbx::g_launch_count.load(std::memory_order_relaxed);
+}
+
+int bbx_design_cg_stats(bbx_design* h, int64_t* solves, int64_t* empty_launches,
+                        int reset) {
+  BBX_TRY(check_handle(h));
+  if (solves) *solves = h->cg_solves;
+  if (empty_launches) *empty_launches = h->cg_empty_launches;
+  if (reset) h->cg_solves = h->cg_empty_launches = 0;
   return BBX_OK;
 }
 

@@ -373,19 +373,19 @@ __global__ __launch_bounds__(VEC_BLOCK) void b_finish_kernel(
 #define BBX_KC_LAUNCH(K, KERNEL, STREAM, ...)                                  \
   do {                                                                         \
     if ((K) == 2)                                                              \
-      hipLaunchKernelGGL((KERNEL<2>), dim3(NPART, 1), dim3(VEC_BLOCK), 0,      \
+      BBX_LAUNCH((KERNEL<2>), dim3(NPART, 1), dim3(VEC_BLOCK), 0,      \
                          STREAM, __VA_ARGS__);                                 \
     else                                                                       \
-      hipLaunchKernelGGL((KERNEL<4>), dim3(NPART, (K) / 4), dim3(VEC_BLOCK),   \
+      BBX_LAUNCH((KERNEL<4>), dim3(NPART, (K) / 4), dim3(VEC_BLOCK),   \
                          0, STREAM, __VA_ARGS__);                              \
   } while (0)
 #define BBX_KC_LAUNCH_MODE(K, KERNEL, MODE, STREAM, ...)                       \
   do {                                                                         \
     if ((K) == 2)                                                              \
-      hipLaunchKernelGGL((KERNEL<2, MODE>), dim3(NPART, 1), dim3(VEC_BLOCK),   \
+      BBX_LAUNCH((KERNEL<2, MODE>), dim3(NPART, 1), dim3(VEC_BLOCK),   \
                          0, STREAM, __VA_ARGS__);                              \
     else                                                                       \
-      hipLaunchKernelGGL((KERNEL<4, MODE>), dim3(NPART, (K) / 4),              \
+      BBX_LAUNCH((KERNEL<4, MODE>), dim3(NPART, (K) / 4),              \
                          dim3(VEC_BLOCK), 0, STREAM, __VA_ARGS__);             \
   } while (0)
 

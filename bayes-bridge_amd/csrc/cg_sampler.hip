@@ -27,7 +27,9 @@ int launch_cg_setup(bbx_design* h, int n_unshrunk, const double* phi,
 int launch_cg_direction(bbx_design* h, int k, CGState* st,
                         const double* rr_part, const double* r, double* pvec,
                         const double* s, double* sp, double* c_part,
-                        const double* d = nullptr, double* pdp_part = nullptr);
+                        const double* d = nullptr, double* pdp_part = nullptr,
+                        unsigned long long* word = nullptr,
+                        unsigned long long tag = 0);
 int launch_cg_update(bbx_design* h, int k, CGState* st, const double* pq_part,
                      const double* pvec, const double* q, double* x, double* r,
                      double* rr_part);
@@ -63,7 +65,7 @@ int launch_fill_normal(bbx_design* h, int64_t len, uint64_t seed,
   int64_t nb = (len + 255) / 256;
   if (nb > 4096) nb = 4096;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)nb), dim3(256), 0,
+  BBX_LAUNCH(fill_normal_kernel, dim3((unsigned)nb), dim3(256), 0,
                      on ? on : h->stream, len, seed, stream, d_out,
                      prio ? 1 : 0);
   BBX_HIP(hipGetLastError());
@@ -186,7 +188,7 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     int* d_flag = &st->pad;  // scratch word of the state cg_setup just reset
     int* h_flag = reinterpret_cast<int*>(host_st);
     BBX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL(any_nonzero_kernel, dim3(NPART), dim3(256), 0,
+    BBX_LAUNCH(any_nonzero_kernel, dim3(NPART), dim3(256), 0,
                        h->stream, h->P, d_x0, d_flag);
     BBX_HIP(hipGetLastError());
     BBX_HIP(hipMemcpyAsync(h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost,
@@ -249,24 +251,41 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
   // sync between the set-up and the loop -- the GPU used to idle ~30 us here
   // while the host woke up and refilled the queue)
 
-  int k = 0;
-  bool done = false;
-  bool finished_at_poll = false;
-  // From here on the operator kernels look at the stop flag and exit at entry
-  // once it is set, so an iteration enqueued past the stopping one costs a few
-  // microseconds of empty launches instead of two passes over the matrix.
-  // That makes running ahead cheap: enqueue a little MORE than the previous
-  // solve needed before the first look at the flag (a look is a stream sync:
-  // the GPU idles until the host has refilled the queue), then every other
-  // iteration.
+  // ---- the loop.  The host only enqueues; what it knows of the solve it
+  // reads from the PROGRESS WORD (common.hpp cg_word_store): the kernel that
+  // carries the stop test of iteration k -- the direction kernel, or the X~ v
+  // kernel of the folded iteration -- writes "k + 1 tests passed" or "done
+  // after k iterations" into 8 bytes of coherent host memory, and the host
+  // polls that address.  No read-back copy, no event, no stream
+  // synchronisation inside a solve (rounds 2-5 looked at the flag through a
+  // hipMemcpyAsync + event wait, first at (previous count + 2), then every
+  // other iteration: an early look that failed left the GPU idle until the
+  // host had woken up and refilled the queue, a late one cost four empty
+  // launches per iteration enqueued in vain).
+  //   * free run: iterations below the smallest count of the last solves are
+  //     enqueued without looking (a solve rarely stops earlier: its kernels
+  //     then return at entry, ~2 us each);
+  //   * then iteration k is enqueued as soon as test k - AHEAD has passed: the
+  //     queue always holds the rest of an iteration or more (no bubble), and
+  //     when the rule fires at most AHEAD * launches-per-iteration empty
+  //     launches sit between the stop and the finish kernel;
+  //   * the finish kernel and the caller's tail (the chain's pass for X~ beta)
+  //     go out the moment `done` is seen, and the call returns without waiting
+  //     for them: `ev_poll` is recorded behind the finish kernel for whoever
+  //     reads coef from another stream (coef_in_flight).
+  // From here on the operator kernels look at CGState::done and exit at entry
+  // once it is set.
   struct SkipScope {
     bbx_design* h;
     ~SkipScope() { h->skip_flag = nullptr; }
   } skip_scope{h};
   h->skip_flag = &st->done;
-  int next_poll = h->last_cg_iter > 2 ? h->last_cg_iter + 2 : 1;
   double* pdp = part_slot(h, PS_PDP);
   bool merged = false;
+  h->cg_serial += 1;
+  const unsigned long long tag = (h->cg_serial & 0xFFFFFFull) << CG_WORD_TAG_SHIFT;
+  unsigned long long* const word = h->cg_word_dev;
+  volatile unsigned long long* const hword = h->cg_word_host;
   // one CG iteration after its direction kernel: q = A p and the update
   struct TagScope {
     bbx_design* h;
@@ -286,6 +305,8 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
   auto folded_iteration = [&](int kk) -> int {
     h->timer.cur_tag = kk;
     DotFold fa;
+    fa.word = word;
+    fa.tag = tag;
     fa.st = st;
     fa.k = kk;
     fa.intercept = h->intercept;
@@ -318,104 +339,95 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     BBX_TRY(launch_tdot(h, h->w_n[0].as<double>(), part_slot(h, PS_SUMW), ep, q));
     return timer_end(h, 2);
   };
-  // The caller's work behind a look at the stop flag (bbx_design::tail_hook):
-  // enqueued before the host waits, it runs iff the rule has fired -- its
-  // kernels take &running as their skip flag -- so that the GPU does not idle
-  // while the host wakes up and launches what follows the draw.  Not timed, and
-  // a product that returned at entry is not counted.
-  h->tail_ran = false;
-  auto speculative_tail = [&]() -> int {
-    if (!h->tail_hook) return 0;
-    const bool timing = h->timer.enabled;
-    h->timer.enabled = false;
-    h->skip_flag = &st->running;
-    const int rc = h->tail_hook(h->tail_ctx);
-    h->skip_flag = &st->done;
-    h->timer.enabled = timing;
-    return rc < 0 ? rc : 1;
+  auto iteration = [&](int kk) -> int {
+    if (fold) return folded_iteration(kk);
+    BBX_TRY(launch_cg_direction(h, kk, st, part_slot(h, PS_RR), r, pvec, s, sp,
+                                part_slot(h, PS_C), d, pdp, word, tag));
+    return operator_and_update(kk);
   };
-  // The host waits for the READ-BACK of the state (an event behind the copy),
-  // not for the tail behind it: what follows the draw is launched while the
-  // tail runs.  Without a hook this is the stream sync it always was.
-  int tail = 0;
-  auto wait_for_look = [&]() -> int {
-    tail = 0;
-    if (!h->tail_hook) {
-      BBX_HIP(hipStreamSynchronize(h->stream));
-      return BBX_OK;
+  // how far ahead of the last passed test the host enqueues: one iteration
+  // where an iteration outlasts the host's launches by far, more on small
+  // designs (launch-bound: the host must not wait for every test)
+  static const int ahead_env = getenv("BBX_CG_AHEAD") ? atoi(getenv("BBX_CG_AHEAD")) : 0;
+  const int ahead = ahead_env >= 1 ? (ahead_env < 64 ? ahead_env : 64)
+                    : h->n >= 250000 ? 1 : h->n >= 50000 ? 2 : 4;
+  int free_run = 0;
+  if (h->cg_recent_n > 0) {
+    free_run = h->cg_recent[0];
+    for (int i = 1; i < h->cg_recent_n; ++i)
+      free_run = h->cg_recent[i] < free_run ? h->cg_recent[i] : free_run;
+    free_run -= 1;   // (the solve that stops AT the smallest count is common)
+  }
+  if (free_run > maxiter) free_run = maxiter;
+  *hword = tag;      // this solve: nothing passed yet (host store, before any launch)
+  int k = 0;
+  for (; k < free_run; ++k) BBX_TRY(iteration(k));
+  bool done = false, bad = false;
+  int n_iter = 0;
+  unsigned spins = 0;
+  while (true) {
+    const unsigned long long w = *hword;
+    int passed = 0;
+    if ((w >> CG_WORD_TAG_SHIFT) == (tag >> CG_WORD_TAG_SHIFT)) {
+      if (w & CG_WORD_DONE) {
+        done = true;
+        bad = (w & CG_WORD_BAD) != 0;
+        n_iter = (int)(w & 0xFFFFFFFFull);
+        break;
+      }
+      passed = (int)(w & 0xFFFFFFFFull);
     }
+    if (k >= maxiter) break;       // exhausted: SciPy has no test after the last
+    if (k < passed + ahead) {
+      BBX_TRY(iteration(k));
+      ++k;
+      spins = 0;
+      continue;
+    }
+    if (++spins > (1u << 14)) {
+      // (a wedged queue shows up as a HIP error here instead of a host that
+      // spins for ever; costs one driver call per ~16k polls)
+      const hipError_t qe = hipStreamQuery(h->stream);
+      if (qe != hipSuccess && qe != hipErrorNotReady) BBX_HIP(qe);
+      spins = 0;
+    }
+    __builtin_ia32_pause();
+  }
+  h->timer.cur_tag = -1;
+  h->tail_ran = false;
+  h->coef_in_flight = false;
+  BBX_TRY(launch_cg_finish(h, s, x, d_coef));
+  if (done) {
     if (!h->ev_poll)
       BBX_HIP(hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming));
     BBX_HIP(hipEventRecord(h->ev_poll, h->stream));
-    tail = speculative_tail();
-    if (tail < 0) return tail;
-    BBX_HIP(hipEventSynchronize(h->ev_poll));
-    return BBX_OK;
-  };
-  while (fold && !done) {
-    const int stop = (next_poll < maxiter) ? next_poll : maxiter;
-    for (; k < stop; ++k) BBX_TRY(folded_iteration(k));
-    if (k >= maxiter) break;
-    // iteration k's X~ v kernel runs the stop test of SciPy's loop top; if the
-    // rule fires, its three launches return at entry and x is final
-    BBX_TRY(folded_iteration(k));
-    ++k;
-    BBX_TRY(launch_cg_finish(h, s, x, d_coef));
-    BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,
-                           h->stream));
-    const int64_t dots_before = h->n_dot;
-    BBX_TRY(wait_for_look());
-    if (host_st->done) {
-      done = true;
-      finished_at_poll = true;
-      h->tail_ran = tail == 1;
-      break;
+    h->coef_in_flight = true;
+    if (h->tail_hook) {
+      // (not timed, like the rest of the chain's kernels)
+      const bool timing = h->timer.enabled;
+      h->timer.enabled = false;
+      h->skip_flag = nullptr;
+      const int rc = h->tail_hook(h->tail_ctx);
+      h->timer.enabled = timing;
+      if (rc < 0) return rc;
+      h->tail_ran = true;
     }
-    h->n_dot = dots_before;   // (the tail's product returned at entry)
-    next_poll = k + 2;
-  }
-  while (!fold && !done) {
-    const int stop = (next_poll < maxiter) ? next_poll : maxiter;
-    for (; k < stop; ++k) {
-      BBX_TRY(launch_cg_direction(h, k, st, part_slot(h, PS_RR), r, pvec, s, sp,
-                                  part_slot(h, PS_C), d, pdp));
-      BBX_TRY(operator_and_update(k));
-    }
-    if (k >= maxiter) break;
-    // Stop test of iteration k (SciPy checks at the loop top) rides along
-    // with the next direction kernel; peek at the flag it left behind.
-    BBX_TRY(launch_cg_direction(h, k, st, part_slot(h, PS_RR), r, pvec, s, sp,
-                                part_slot(h, PS_C), d, pdp));
-    // coef = s .* x goes out BEFORE the look at the flag: if the rule has
-    // fired (the common case: the first look comes a little after the
-    // previous solve's count) the draw is complete when the host wakes up and
-    // nothing more has to be launched or waited for; if not, it is simply
-    // overwritten at the end.
-    BBX_TRY(launch_cg_finish(h, s, x, d_coef));
-    BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,
-                           h->stream));
-    const int64_t dots_before = h->n_dot;
-    BBX_TRY(wait_for_look());
-    if (host_st->done) {
-      done = true;
-      finished_at_poll = true;  // host_st is final: later kernels exit at entry
-      h->tail_ran = tail == 1;
-      break;
-    }
-    h->n_dot = dots_before;   // (the tail's product returned at entry)
-    // direction(k) already ran: finish iteration k, then continue.
-    BBX_TRY(operator_and_update(k));
-    ++k;
-    next_poll = k + 2;
-  }
-  if (!finished_at_poll) {
-    BBX_TRY(launch_cg_finish(h, s, x, d_coef));
+  } else {
+    // maxiter exhausted (rare: a warning to the user): the device state says
+    // how it ended
     BBX_HIP(hipMemcpyAsync(host_st, st, sizeof(CGState), hipMemcpyDeviceToHost,
                            h->stream));
     BBX_HIP(hipStreamSynchronize(h->stream));
+    // (the test of the last enqueued iteration may have fired after the
+    // host's last look)
+    done = host_st->done != 0;
+    bad = host_st->bad != 0;
+    n_iter = host_st->n_iter;
   }
-  const int n_iter = host_st->n_iter;
-  h->timer.cur_tag = -1;
+  // launches enqueued in vain: iterations n_iter .. k-1 minus the kernel that
+  // ran the firing test
+  if (k > n_iter) h->cg_empty_launches += (int64_t)(k - n_iter) * (fold ? 3 : 4) - 1;
+  h->cg_solves += 1;
   timer_drop_skipped(h, n_iter);
   // Operator applications enqueued past the stopping iteration exited at entry
   // (their kernels see `done`): they are not matvecs and do not count
@@ -424,9 +436,15 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     h->n_dot -= (k - n_iter);
     h->n_tdot -= (k - n_iter);
   }
-  int info = host_st->done ? 0 : maxiter;
-  if (host_st->bad) info = -1;
+  int info = done ? 0 : maxiter;
+  if (bad) info = -1;
   h->last_cg_iter = n_iter;
+  if (h->cg_recent_n < 8) {
+    h->cg_recent[h->cg_recent_n++] = n_iter;
+  } else {
+    for (int i = 0; i < 7; ++i) h->cg_recent[i] = h->cg_recent[i + 1];
+    h->cg_recent[7] = n_iter;
+  }
   if (n_iter_out) *n_iter_out = n_iter;
   if (info_out) *info_out = info;
   if (info < 0)

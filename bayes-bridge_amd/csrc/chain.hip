@@ -592,7 +592,7 @@ int chain_pre_draw(bbx_chain* c) {
   const int64_t P = h->P, n = h->n;
   ChainScalars* sc = c->scalars.as<ChainScalars>();
   // --- beta | Omega, tau, lambda  (bayesbridge.py:372-395)
-  hipLaunchKernelGGL(chain_prior_kernel, dim3(NPART), dim3(256), 0, s, P,
+  BBX_LAUNCH(chain_prior_kernel, dim3(NPART), dim3(256), 0, s, P,
                      c->n_unshrunk, c->model, c->slab,
                      (long long)c->n_averaged, sc, c->lscale.as<double>(),
                      c->sd_unshrunk.as<double>(), c->mean.as<double>(),
@@ -602,7 +602,7 @@ int chain_pre_draw(bbx_chain* c) {
                      c->samp_gscale.as<double>(), c->samp_logp.as<double>());
   c->pending_store = -1;
   if (c->model == BBX_MODEL_LINEAR)
-    hipLaunchKernelGGL(chain_fill_obs_prec_kernel, dim3(grid_for(n, ROW_GRID)),
+    BBX_LAUNCH(chain_fill_obs_prec_kernel, dim3(grid_for(n, ROW_GRID)),
                        dim3(256), 0, s, n, sc, c->obs_prec.as<double>());
   BBX_HIP(hipGetLastError());
   return BBX_OK;
@@ -623,11 +623,12 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
   // kernels, the last one ~0.1 ms of latency-bound rejection sampling on p
   // coefficients) runs beside it on a second stream.  Each branch writes its
   // own half of ChainScalars; Philox streams are keyed by element, so the
-  // draws do not depend on the interleaving.  beta is final here (the CG
-  // solve ended with a stream sync: cg_sample_device's postcondition), so the
-  // second stream needs no event to start; the summary kernel, which reads the
-  // OLD tau and lambda, leads that branch.  The design's stream waits for the
-  // branch at the end.  Measured: config 3 +1.6 %, config 2 +2.5 %, config 4
+  // draws do not depend on the interleaving.  beta is final in the ORDER OF
+  // THE DESIGN'S STREAM only: cg_sample_device returns with its finish kernel
+  // enqueued and `ev_poll` recorded behind it (coef_in_flight), so the second
+  // stream waits on that event before its first kernel (the summary kernel,
+  // which reads beta and the OLD tau and lambda).  The design's stream waits
+  // for the branch at the end.  Measured: config 3 +1.6 %, config 2 +2.5 %, config 4
   // +-0; tiny problems keep one stream, and so should processes that SHARE a
   // GPU (two ranks on one device ran 3x slower with a second queue each:
   // chains.py sets BBX_CHAIN_FORK=0 then).  BBX_CHAIN_FORK=0 / 1 forces one /
@@ -644,6 +645,11 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
   if (fork && c->ev_join == nullptr)
     BBX_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   hipStream_t s_b = !fork ? s : owner->stream2;
+  if (h->coef_in_flight) {
+    if (fork && (phases & POST_BRANCH))
+      BBX_HIP(hipStreamWaitEvent(s_b, h->ev_poll, 0));
+    h->coef_in_flight = false;
+  }
 
   // --- Omega | beta  (bayesbridge.py:397-410).  Launch order = what has to
   // start first: the pass over the matrix, then the whole second branch (it
@@ -655,7 +661,7 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
   if (phases & POST_BRANCH) {
   // --- running summaries of beta (with the tau and lambda it was drawn
   // under), then tau | beta, then lambda | tau, beta, then log posterior
-  hipLaunchKernelGGL(chain_summary_kernel, dim3(NPART), dim3(256), 0, s_b, P,
+  BBX_LAUNCH(chain_summary_kernel, dim3(NPART), dim3(256), 0, s_b, P,
                      nu, c->slab, (long long)c->n_averaged, sc,
                      c->lscale.as<double>(), c->coef.as<double>(),
                      c->mean.as<double>(), c->square.as<double>(),
@@ -663,12 +669,12 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
   c->n_averaged += 1;
   // the chain's own partial slots: the branches of a batch's chains run side by side
   double* pp = c->misc_part.as<double>();
-  hipLaunchKernelGGL(chain_coef_sums_kernel, dim3(NPART), dim3(256), 0, s_b, P,
+  BBX_LAUNCH(chain_coef_sums_kernel, dim3(NPART), dim3(256), 0, s_b, P,
                      nu, c->bridge_exp, c->slab, c->coef.as<double>(),
                      c->sd_unshrunk.as<double>(), pp, pp + NPART,
                      pp + 2 * NPART, fork ? branch_prio() : 0);
   const double lower_bd = .001 / power_exp_ave_magnitude(c->bridge_exp);
-  hipLaunchKernelGGL(chain_gscale_kernel, dim3(1), dim3(256), 0, s_b, n_shrunk,
+  BBX_LAUNCH(chain_gscale_kernel, dim3(1), dim3(256), 0, s_b, n_shrunk,
                      nu, c->bridge_exp, c->shape0, c->rate0, lower_bd,
                      c->gscale_update, c->seed,
                      iter_stream(STREAM_GSCALE, c->iter), pp, pp + NPART,
@@ -684,7 +690,7 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
                       : (n_shrunk / TS_BLOCK < 1024) ? 128 : TS_BLOCK;
     int64_t nb = (n_shrunk + items - 1) / items;
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(chain_lscale_kernel, dim3((unsigned)nb), dim3(TS_BLOCK),
+    BBX_LAUNCH(chain_lscale_kernel, dim3((unsigned)nb), dim3(TS_BLOCK),
                        0, s_b, n_shrunk, nu, c->bridge_exp, c->seed,
                        iter_stream(STREAM_LSCALE, c->iter), sc,
                        c->coef.as<double>(), c->lscale.as<double>(), items,
@@ -733,7 +739,7 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
 #define BBX_PG_LAUNCH(KERNEL, PER_BLOCK)                                       \
   do {                                                                         \
     rg = grid_for((n + (PER_BLOCK) - 1) / (PER_BLOCK) * 256, ROW_GRID);        \
-    hipLaunchKernelGGL(KERNEL, dim3(rg), dim3(256), 0, s, n, c->seed,          \
+    BBX_LAUNCH(KERNEL, dim3(rg), dim3(256), 0, s, n, c->seed,          \
                        iter_stream(STREAM_PG, c->iter),                        \
                        c->outcome.as<double>(), c->n_trial.as<double>(),       \
                        c->psi.as<double>(), c->obs_prec.as<double>(), rp);     \
@@ -744,10 +750,10 @@ int chain_post_draw(bbx_chain* c, bool have_psi, int phases,
     else BBX_PG_LAUNCH(chain_pg_kernel<1>, 256);
 #undef BBX_PG_LAUNCH
   } else {
-    hipLaunchKernelGGL(chain_rss_kernel, dim3(rg), dim3(256), 0, s, n,
+    BBX_LAUNCH(chain_rss_kernel, dim3(rg), dim3(256), 0, s, n,
                        c->outcome.as<double>(), c->psi.as<double>(), rp);
   }
-  hipLaunchKernelGGL(chain_obs_finish_kernel, dim3(1), dim3(256), 0, s,
+  BBX_LAUNCH(chain_obs_finish_kernel, dim3(1), dim3(256), 0, s,
                      c->model, 0, n, c->seed,
                      iter_stream(STREAM_OBSVAR, c->iter), rp, rg, sc);
 
@@ -845,7 +851,7 @@ int chain_save_sample(bbx_chain* c, int idx, double* d_coef, double* d_lscale,
 int chain_end_run(bbx_chain* c, int n_sample, double* gscale, double* logp) {
   bbx_design* h = c->h;
   if (c->pending_store >= 0) {
-    hipLaunchKernelGGL(chain_store_scalars_kernel, dim3(1), dim3(64), 0,
+    BBX_LAUNCH(chain_store_scalars_kernel, dim3(1), dim3(64), 0,
                        h->stream, c->scalars.as<ChainScalars>(),
                        c->pending_store, c->samp_gscale.as<double>(),
                        c->samp_logp.as<double>());
@@ -933,7 +939,7 @@ int bbx_chain_create(bbx_design* design, int model, const double* outcome,
     // Omega cancels) or X~^T y (linear; scaled by obs_prec each iteration).
     const double* src = c->outcome.as<double>();
     if (model == BBX_MODEL_LOGIT) {
-      hipLaunchKernelGGL(chain_kappa_kernel, dim3(grid_for(n, ROW_GRID)),
+      BBX_LAUNCH(chain_kappa_kernel, dim3(grid_for(n, ROW_GRID)),
                          dim3(256), 0, h->stream, n, c->outcome.as<double>(),
                          c->n_trial.as<double>(), c->kappa.as<double>());
       src = c->kappa.as<double>();
@@ -965,7 +971,7 @@ int bbx_chain_create(bbx_design* design, int model, const double* outcome,
       BBX_HIP(hipMemsetAsync(m->ptr, 0, Pb, h->stream));
     BBX_HIP(hipMemsetAsync(c->psi.ptr, 0, nb, h->stream));
     if (model == BBX_MODEL_LOGIT)
-      hipLaunchKernelGGL(chain_pg_mean_kernel, dim3(grid_for(n, ROW_GRID)),
+      BBX_LAUNCH(chain_pg_mean_kernel, dim3(grid_for(n, ROW_GRID)),
                          dim3(256), 0, h->stream, n, c->n_trial.as<double>(),
                          c->psi.as<double>(), c->obs_prec.as<double>());
     else
@@ -1189,14 +1195,14 @@ int bbx_chain_init_obs_prec(bbx_chain* c) {
   BBX_TRY(chain_linear_predictor(c));
   const int rg = grid_for(h->n, ROW_GRID);
   if (c->model == BBX_MODEL_LOGIT) {
-    hipLaunchKernelGGL(chain_pg_mean_kernel, dim3(rg), dim3(256), 0, h->stream,
+    BBX_LAUNCH(chain_pg_mean_kernel, dim3(rg), dim3(256), 0, h->stream,
                        h->n, c->n_trial.as<double>(), c->psi.as<double>(),
                        c->obs_prec.as<double>());
   } else {
     double* rp = c->row_part.as<double>();
-    hipLaunchKernelGGL(chain_rss_kernel, dim3(rg), dim3(256), 0, h->stream,
+    BBX_LAUNCH(chain_rss_kernel, dim3(rg), dim3(256), 0, h->stream,
                        h->n, c->outcome.as<double>(), c->psi.as<double>(), rp);
-    hipLaunchKernelGGL(chain_obs_finish_kernel, dim3(1), dim3(256), 0,
+    BBX_LAUNCH(chain_obs_finish_kernel, dim3(1), dim3(256), 0,
                        h->stream, c->model, 1, h->n, c->seed, 0, rp, rg,
                        c->scalars.as<ChainScalars>());
   }
@@ -1328,11 +1334,11 @@ static int bbx_device_polya_gamma_impl(int device, uint64_t seed, int64_t n_draw
   // (the draws do not depend on the elements per lane: the small width for
   // short vectors, the chain's widest otherwise)
   if (n_draw < 50000)
-    hipLaunchKernelGGL(dev_pg_kernel<1>, dim3(grid_for(n_draw, 4096)), dim3(256),
+    BBX_LAUNCH(dev_pg_kernel<1>, dim3(grid_for(n_draw, 4096)), dim3(256),
                        0, 0, n_draw, seed, ds.as<int32_t>(), dt.as<double>(),
                        dout.as<double>());
   else
-    hipLaunchKernelGGL(dev_pg_kernel<8>, dim3(grid_for((n_draw + 7) / 8, 4096)),
+    BBX_LAUNCH(dev_pg_kernel<8>, dim3(grid_for((n_draw + 7) / 8, 4096)),
                        dim3(256), 0, 0, n_draw, seed, ds.as<int32_t>(),
                        dt.as<double>(), dout.as<double>());
   BBX_HIP(hipGetLastError());
@@ -1363,7 +1369,7 @@ static int bbx_device_tilted_stable_impl(int device, uint64_t seed, int64_t n_dr
   BBX_TRY(dout.alloc(sizeof(double) * (size_t)n_draw));
   BBX_HIP(hipMemcpy(dt.ptr, tilt, sizeof(double) * (size_t)n_draw,
                     hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(dev_ts_kernel, dim3(grid_for(n_draw, 4096)), dim3(256), 0,
+  BBX_LAUNCH(dev_ts_kernel, dim3(grid_for(n_draw, 4096)), dim3(256), 0,
                      0, n_draw, seed, char_exp, dt.as<double>(),
                      dout.as<double>(), bbx::ts_cost_threshold());
   BBX_HIP(hipGetLastError());
@@ -1388,7 +1394,7 @@ static int bbx_device_gamma_impl(int device, uint64_t seed, int64_t n_draw, doub
   if (!out || !(shape > 0.)) return fail(BBX_ERR_INVALID, "bad argument");
   DevMem dout;
   BBX_TRY(dout.alloc(sizeof(double) * (size_t)n_draw));
-  hipLaunchKernelGGL(dev_gamma_kernel, dim3(grid_for(n_draw, 4096)), dim3(256),
+  BBX_LAUNCH(dev_gamma_kernel, dim3(grid_for(n_draw, 4096)), dim3(256),
                      0, 0, n_draw, seed, shape, dout.as<double>());
   BBX_HIP(hipGetLastError());
   BBX_HIP(hipMemcpy(out, dout.ptr, sizeof(double) * (size_t)n_draw,
@@ -1420,7 +1426,7 @@ static int bbx_device_normal_impl(int device, uint64_t seed, uint64_t stream,
   if (!out) return fail(BBX_ERR_INVALID, "out is NULL");
   DevMem dout;
   BBX_TRY(dout.alloc(sizeof(double) * (size_t)n_draw));
-  hipLaunchKernelGGL(dev_normal_kernel, dim3(grid_for(n_draw, 4096)),
+  BBX_LAUNCH(dev_normal_kernel, dim3(grid_for(n_draw, 4096)),
                      dim3(256), 0, 0, n_draw, seed, stream, dout.as<double>());
   BBX_HIP(hipGetLastError());
   BBX_HIP(hipMemcpy(out, dout.ptr, sizeof(double) * (size_t)n_draw,

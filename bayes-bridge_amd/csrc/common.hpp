@@ -12,6 +12,24 @@
 
 #include "../../include/bbx.h"
 
+// Every kernel launch of the library goes through these two and is counted
+// (bbx_launch_count: bench.py reports launches per second and rank -- what an
+// 8-rank node asks of its host cores).
+#include <atomic>
+namespace bbx {
+extern std::atomic<unsigned long long> g_launch_count;
+}
+#define BBX_LAUNCH(...)                                                   \
+  do {                                                                    \
+    bbx::g_launch_count.fetch_add(1, std::memory_order_relaxed);          \
+    hipLaunchKernelGGL(__VA_ARGS__);                                      \
+  } while (0)
+#define BBX_LAUNCH_EXT(...)                                               \
+  do {                                                                    \
+    bbx::g_launch_count.fetch_add(1, std::memory_order_relaxed);          \
+    hipExtLaunchKernelGGL(__VA_ARGS__);                                   \
+  } while (0)
+
 namespace bbx {
 
 constexpr int WAVE = 64;
@@ -236,6 +254,20 @@ struct bbx_design {
 
   int64_t n_dot = 0, n_tdot = 0;
   int last_cg_iter = 0;  // iterations of the previous solve (poll scheduling)
+  // The CG loop's PROGRESS WORD: 8 bytes of host memory mapped into the device
+  // (fine-grained), written by the kernel that carries the stop test of an
+  // iteration (cg_word_pack below) and polled by the host -- no read-back copy,
+  // no event, no stream synchronisation inside a solve (cg_sampler.hip).
+  unsigned long long* cg_word_host = nullptr;
+  unsigned long long* cg_word_dev = nullptr;
+  unsigned long long cg_serial = 0;   // solves so far: the word's tag
+  int cg_recent[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // iteration counts of the last solves
+  int cg_recent_n = 0;
+  // the last solve returned with its finish kernel enqueued, not waited for:
+  // `ev_poll` is recorded behind it (another stream that reads coef waits on it)
+  bool coef_in_flight = false;
+  // what the last solve enqueued past its stopping iteration (bench.py)
+  int64_t cg_empty_launches = 0, cg_solves = 0;
   // Set around the dot + Tdot of ONE operator application (apply_operator,
   // gram_matvec): the Tdot's input is the dot's scaled output, so a mixed
   // design's dense block can ride in the dot kernel's epilogue for both
@@ -249,7 +281,7 @@ struct bbx_design {
   int (*tail_hook)(void*) = nullptr;
   void* tail_ctx = nullptr;
   bool tail_ran = false;
-  hipEvent_t ev_poll = nullptr;   // the look's read-back has landed (the tail may still run)
+  hipEvent_t ev_poll = nullptr;   // recorded behind the draw's finish kernel (the tail may still run)
   bool in_operator = false;
   // counts operator applications: what the dot kernel of ONE application leaves
   // for its Tdot (a mixed design's D^T t partials) is tagged with it, so that
@@ -352,7 +384,21 @@ struct TdotEpilogue {
 // reduction inside a launch.  (Round 4's first form filled the slices with
 // s.*r + beta s.*p_old -- two vector reads per slice -- and lost 7 us in the
 // X~ v kernel for the 6.6 us it saved: LABNOTES.md R4.1.)
+// Progress word of a solve (bbx_design::cg_word_*): [tag:24 | bad | done | value:32],
+// value = stop tests passed so far (the rule has not fired: iterations 0 .. value-1
+// are under way) or, with `done`, the solve's iteration count.
+constexpr unsigned long long CG_WORD_DONE = 1ull << 32;
+constexpr unsigned long long CG_WORD_BAD = 1ull << 33;
+constexpr int CG_WORD_TAG_SHIFT = 40;
+__device__ inline void cg_word_store(unsigned long long* word,
+                                     unsigned long long v) {
+  // system scope: the host polls this address
+  __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct DotFold {
+  unsigned long long* word = nullptr;   // progress word (device address) and
+  unsigned long long tag = 0;           // this solve's tag, already shifted
   CGState* st = nullptr;
   int k = 0;
   int intercept = 0;
@@ -533,10 +579,13 @@ int timer_arm(bbx_design* h, int which, hipEvent_t* a, hipEvent_t* b);
 void timer_drop_skipped(bbx_design* h, int n_iter);
 
 // ---- CG sampler (cg_sampler.hip) -------------------------------------------
-// POSTCONDITION every caller may rely on (chain_step's second stream does: it
-// starts reading d_coef without an event): on return -- success, not converged
-// or error after the first launch -- h->stream is idle (the solve ends with
-// hipStreamSynchronize on every path) and d_coef is final.
+// POSTCONDITION: on return d_coef is final IN THE ORDER OF h->stream -- the
+// finish kernel is enqueued, not waited for, and the stream may also hold the
+// caller's tail (read-only with respect to coef).  When the stop rule fired
+// (the normal case) h->coef_in_flight is set and h->ev_poll is recorded right
+// behind the finish kernel: work on ANOTHER stream that reads d_coef must wait
+// on that event (chain_post_draw does).  When maxiter was exhausted the solve
+// ends with hipStreamSynchronize.  n_iter_out / info_out are final on return.
 int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
                      const double* d_z, const double* d_x0,
                      const double* d_sd, int n_unshrunk, const double* d_eta1,

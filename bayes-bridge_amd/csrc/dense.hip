@@ -830,7 +830,7 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
   h->n_tdot += 1;
   BBX_TRY(timer_begin(h, 0));
 #define BBX_FUSED_LAUNCH(TT, KQ, RB)                                           \
-  hipLaunchKernelGGL((dense_fused_kernel<TT, KQ, RB>), dim3(wgs), dim3(1024),  \
+  BBX_LAUNCH((dense_fused_kernel<TT, KQ, RB>), dim3(wgs), dim3(1024),  \
                      0, h->stream, h->n, h->P, h->dense_ld, rows_per_wg,       \
                      h->dense.as<TT>(), d_v, d_rowscale,                       \
                      h->dense_fused_slab.as<double>(), h->skip_flag,           \
@@ -842,7 +842,7 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
     BBX_HIP(hipFuncSetAttribute(                                               \
         reinterpret_cast<const void*>(&dense_fused_ring_kernel<KQ, RB, D>),    \
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
-    hipLaunchKernelGGL((dense_fused_ring_kernel<KQ, RB, D>), dim3(wgs),        \
+    BBX_LAUNCH((dense_fused_ring_kernel<KQ, RB, D>), dim3(wgs),        \
                        dim3(1024), lb, h->stream, h->n, h->P, h->dense_ld,     \
                        rows_per_wg, h->dense.as<float>(), d_v, d_rowscale,     \
                        h->dense_fused_slab.as<double>(), h->skip_flag,         \
@@ -854,7 +854,7 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
   // f64 storage: pairs of doubles per thread and group (see the kernels); a
   // stage of the ring is one row of <= 8192 doubles or two of <= 4096 (64 KB)
 #define BBX_F64_LAUNCH(GG)                                                     \
-  hipLaunchKernelGGL((dense_fused_f64_kernel<GG>), dim3(wgs), dim3(1024), 0,   \
+  BBX_LAUNCH((dense_fused_f64_kernel<GG>), dim3(wgs), dim3(1024), 0,   \
                      h->stream, h->n, h->P, h->dense_ld, rows_per_wg,          \
                      h->dense.as<double>(), d_v, d_rowscale,                   \
                      h->dense_fused_slab.as<double>(), h->skip_flag,           \
@@ -865,7 +865,7 @@ int launch_operator_dense_fused(bbx_design* h, const double* d_v,
     BBX_HIP(hipFuncSetAttribute(                                               \
         reinterpret_cast<const void*>(&dense_fused_f64_ring_kernel<GG, RB, D>), \
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
-    hipLaunchKernelGGL((dense_fused_f64_ring_kernel<GG, RB, D>), dim3(wgs),    \
+    BBX_LAUNCH((dense_fused_f64_ring_kernel<GG, RB, D>), dim3(wgs),    \
                        dim3(1024), lb, h->stream, h->n, h->P, h->dense_ld,     \
                        rows_per_wg, h->dense.as<double>(), d_v, d_rowscale,    \
                        h->dense_fused_slab.as<double>(), h->skip_flag,         \
@@ -937,15 +937,15 @@ int launch_dot_dense(bbx_design* h, const double* d_v,
       getenv("BBX_DENSE_MFMA") && atoi(getenv("BBX_DENSE_MFMA")) == 1;
   BBX_TRY(timer_begin(h, 0));
   if (h->dense_dtype == BBX_F32 && use_mfma)
-    hipLaunchKernelGGL(dense_dot_mfma_kernel, dim3(1024), dim3(256),
+    BBX_LAUNCH(dense_dot_mfma_kernel, dim3(1024), dim3(256),
                        lds + 16 * sizeof(double), h->stream, h->n, h->P,
                        h->dense_ld, h->dense.as<float>(), d_v, d_rowscale, d_t);
   else if (h->dense_dtype == BBX_F32)
-    hipLaunchKernelGGL(dense_dot_kernel<float>, dim3((unsigned)nb), dim3(256),
+    BBX_LAUNCH(dense_dot_kernel<float>, dim3((unsigned)nb), dim3(256),
                        lds, h->stream, h->n, h->P, h->dense_ld,
                        h->dense.as<float>(), d_v, d_rowscale, d_t, h->skip_flag);
   else
-    hipLaunchKernelGGL(dense_dot_kernel<double>, dim3((unsigned)nb), dim3(256),
+    BBX_LAUNCH(dense_dot_kernel<double>, dim3((unsigned)nb), dim3(256),
                        lds, h->stream, h->n, h->P, h->dense_ld,
                        h->dense.as<double>(), d_v, d_rowscale, d_t,
                        h->skip_flag);
@@ -961,11 +961,11 @@ static int launch_tdot_slabs_dense(bbx_design* h, const double* d_w) {
   const dim3 grid((unsigned)((ld / 4 + 255) / 256), (unsigned)chunks);
   BBX_TRY(timer_begin(h, 1));
   if (h->dense_dtype == BBX_F32)
-    hipLaunchKernelGGL(dense_tdot_kernel<float>, grid, dim3(256), 0, h->stream,
+    BBX_LAUNCH(dense_tdot_kernel<float>, grid, dim3(256), 0, h->stream,
                        h->n, ld, rows_per_chunk, h->dense.as<float>(), d_w,
                        h->dense_slab.as<double>(), h->skip_flag);
   else
-    hipLaunchKernelGGL(dense_tdot_kernel<double>, grid, dim3(256), 0,
+    BBX_LAUNCH(dense_tdot_kernel<double>, grid, dim3(256), 0,
                        h->stream, h->n, ld, rows_per_chunk,
                        h->dense.as<double>(), d_w, h->dense_slab.as<double>(),
                        h->skip_flag);
@@ -1062,19 +1062,19 @@ static int create_dense_common(int64_t n, int64_t p, const void* X,
     BBX_HIP(hipDeviceSynchronize());
     const dim3 grid(4096), block(256);
     if (in_dtype == BBX_F32 && storage_dtype == BBX_F32)
-      hipLaunchKernelGGL((dense_ingest_kernel<float, float>), grid, block, 0,
+      BBX_LAUNCH((dense_ingest_kernel<float, float>), grid, block, 0,
                          h->stream, n, p, h->dense_ld, h->intercept,
                          (const float*)src, off, h->dense.as<float>());
     else if (in_dtype == BBX_F32)
-      hipLaunchKernelGGL((dense_ingest_kernel<float, double>), grid, block, 0,
+      BBX_LAUNCH((dense_ingest_kernel<float, double>), grid, block, 0,
                          h->stream, n, p, h->dense_ld, h->intercept,
                          (const float*)src, off, h->dense.as<double>());
     else if (storage_dtype == BBX_F32)
-      hipLaunchKernelGGL((dense_ingest_kernel<double, float>), grid, block, 0,
+      BBX_LAUNCH((dense_ingest_kernel<double, float>), grid, block, 0,
                          h->stream, n, p, h->dense_ld, h->intercept,
                          (const double*)src, off, h->dense.as<float>());
     else
-      hipLaunchKernelGGL((dense_ingest_kernel<double, double>), grid, block, 0,
+      BBX_LAUNCH((dense_ingest_kernel<double, double>), grid, block, 0,
                          h->stream, n, p, h->dense_ld, h->intercept,
                          (const double*)src, off, h->dense.as<double>());
     BBX_HIP(hipGetLastError());

@@ -600,7 +600,7 @@ static int ensure_dense_transpose_t(bbx_design* h) {
   BBX_HIP(hipMemsetAsync(h->dense_xt.ptr, 0,
                          sizeof(T) * (size_t)rows * (size_t)ldn, h->stream));
   const dim3 grid((unsigned)(ldn / 64), (unsigned)((h->dense_ld + 63) / 64));
-  hipLaunchKernelGGL(dense_transpose_kernel<T>, grid, dim3(256), 0, h->stream,
+  BBX_LAUNCH(dense_transpose_kernel<T>, grid, dim3(256), 0, h->stream,
                      h->n, h->dense_ld, ldn, rows, h->dense.as<T>(),
                      h->dense_xt.as<T>());
   BBX_HIP(hipGetLastError());
@@ -646,7 +646,7 @@ int launch_dot_dense_k(bbx_design* h, int K, const double* d_v,
   h->n_dot += 1;
   BBX_TRY(timer_begin(h, 0));
 #define DK_LAUNCH_DOT(T, NG)                                                  \
-  hipLaunchKernelGGL((dense_dot_kd_kernel<T, NG>), dim3(DK_DOT_WGS),          \
+  BBX_LAUNCH((dense_dot_kd_kernel<T, NG>), dim3(DK_DOT_WGS),          \
                      dim3(DKD_WAVES* WAVE), DKD_IMG, h->stream, K, h->n, h->P, \
                      h->dense_xt_ld, h->dense_xt.as<T>(), d_v, ba.rowscale,   \
                      ba.out, ba.out_stride, d_twt_part, h->skip_flag)
@@ -681,7 +681,7 @@ int launch_tdot_dense_k(bbx_design* h, int K, const double* d_w,
   h->n_tdot += 1;
   BBX_TRY(timer_begin(h, 1));
 #define DK_LAUNCH_TDOT(T, NG)                                                 \
-  hipLaunchKernelGGL((dense_tdot_kd_kernel<T, NG>),                           \
+  BBX_LAUNCH((dense_tdot_kd_kernel<T, NG>),                           \
                      dim3((unsigned)(n_colblk * DK_TDOT_CHUNKS)),             \
                      dim3(DKD_WAVES* WAVE), (dkd_img<T, NG>()), h->stream, K, h->n, \
                      h->dense_ld, rows_per_wave, h->dense.as<T>(), d_w,       \

@@ -312,7 +312,7 @@ static void launch_csr_dot_g(bbx_design* h, int G, int grid, const double* d_v,
   const double* da = h->data.as<double>();
   const double* cp = part_slot(h, PS_C);
 #define BBX_LAUNCH_G(GG)                                                       \
-  hipLaunchKernelGGL((csr_dot_kernel<GG, BIN>), dim3(grid), dim3(256), 0,      \
+  BBX_LAUNCH((csr_dot_kernel<GG, BIN>), dim3(grid), dim3(256), 0,      \
                      h->stream, h->n, ip, ix, da, d_v, h->intercept, cp,       \
                      d_rowscale, d_t, h->skip_flag)
   switch (G) {
@@ -363,7 +363,7 @@ int launch_tdot_finalize(bbx_design* h, const double* d_gfull, int n_slab,
                          const double* d_sumw_part, const TdotEpilogue& ep,
                          double* d_out) {
 #define BBX_FIN(MODE, FF)                                                      \
-  hipLaunchKernelGGL((tdot_finalize_kernel<MODE, FF>), dim3(NPART),            \
+  BBX_LAUNCH((tdot_finalize_kernel<MODE, FF>), dim3(NPART),            \
                      dim3(VEC_BLOCK), 0, h->stream, h->p, h->intercept,        \
                      h->t_row_chunk_ptr.as<int32_t>(),                         \
                      h->t_partial.as<double>(), d_gfull, n_slab, h->p,         \
@@ -383,7 +383,7 @@ int launch_tdot_finalize_dense(bbx_design* h, const TdotEpilogue& ep,
                                double* d_out, const double* d_slab,
                                int n_slab) {
 #define BBX_FIN(MODE, FF)                                                      \
-  hipLaunchKernelGGL((tdot_finalize_kernel<MODE, FF>), dim3(NPART),            \
+  BBX_LAUNCH((tdot_finalize_kernel<MODE, FF>), dim3(NPART),            \
                      dim3(VEC_BLOCK), 0, h->stream, h->P, 0, nullptr, nullptr, \
                      d_slab ? d_slab : h->dense_slab.as<double>(),             \
                      d_slab ? n_slab : h->dense_chunks, h->dense_ld,           \
@@ -402,7 +402,7 @@ static int launch_tdot_chunks_csr(bbx_design* h, const double* d_w) {
   if (h->n_tchunk > 0) {
     const int64_t nb = (h->n_tchunk + 3) / 4;
     if (h->binary)
-      hipLaunchKernelGGL(csr_tdot_chunk_kernel<true>, dim3((unsigned)nb),
+      BBX_LAUNCH(csr_tdot_chunk_kernel<true>, dim3((unsigned)nb),
                          dim3(256), 0, h->stream, h->n_tchunk,
                          h->t_chunk_row.as<int32_t>(),
                          h->t_chunk_begin.as<int32_t>(),
@@ -410,7 +410,7 @@ static int launch_tdot_chunks_csr(bbx_design* h, const double* d_w) {
                          h->t_data.as<double>(), d_w,
                          h->t_partial.as<double>(), h->skip_flag);
     else
-      hipLaunchKernelGGL(csr_tdot_chunk_kernel<false>, dim3((unsigned)nb),
+      BBX_LAUNCH(csr_tdot_chunk_kernel<false>, dim3((unsigned)nb),
                          dim3(256), 0, h->stream, h->n_tchunk,
                          h->t_chunk_row.as<int32_t>(),
                          h->t_chunk_begin.as<int32_t>(),
@@ -493,9 +493,9 @@ int build_transpose_csr(bbx_design* h) {
     BBX_TRY(perm_in.alloc(sizeof(int32_t) * (size_t)nnz));
     BBX_TRY(perm_out.alloc(sizeof(int32_t) * (size_t)nnz));
     BBX_TRY(col_sorted.alloc(sizeof(int32_t) * (size_t)nnz));
-    hipLaunchKernelGGL(expand_rows_kernel, dim3(2048), dim3(256), 0, h->stream,
+    BBX_LAUNCH(expand_rows_kernel, dim3(2048), dim3(256), 0, h->stream,
                        n, h->indptr.as<int32_t>(), rowid.as<int32_t>());
-    hipLaunchKernelGGL(iota_kernel, dim3(2048), dim3(256), 0, h->stream, nnz,
+    BBX_LAUNCH(iota_kernel, dim3(2048), dim3(256), 0, h->stream, nnz,
                        perm_in.as<int32_t>());
     int end_bit = 1;
     while (end_bit < 31 && ((int64_t)1 << end_bit) < p) ++end_bit;
@@ -509,11 +509,11 @@ int build_transpose_csr(bbx_design* h) {
         tmp.ptr, tmp_bytes, h->indices.as<int32_t>(), col_sorted.as<int32_t>(),
         perm_in.as<int32_t>(), perm_out.as<int32_t>(), (int)nnz, 0, end_bit,
         h->stream));
-    hipLaunchKernelGGL(gather_perm_kernel, dim3(2048), dim3(256), 0, h->stream,
+    BBX_LAUNCH(gather_perm_kernel, dim3(2048), dim3(256), 0, h->stream,
                        nnz, perm_out.as<int32_t>(), rowid.as<int32_t>(),
                        h->data.as<double>(), h->t_indices.as<int32_t>(),
                        h->binary ? nullptr : h->t_data.as<double>());
-    hipLaunchKernelGGL(lower_bound_kernel, dim3((unsigned)((p + 256) / 256)),
+    BBX_LAUNCH(lower_bound_kernel, dim3((unsigned)((p + 256) / 256)),
                        dim3(256), 0, h->stream, p, nnz,
                        col_sorted.as<int32_t>(), h->t_indptr.as<int32_t>());
     BBX_HIP(hipGetLastError());

@@ -50,6 +50,17 @@
 #ifndef BBX_TILED_INSTRUMENT
 #define BBX_TILED_INSTRUMENT 0
 #endif
+// The experiment arguments of tiled_spmv_kernel (`ablate`: timing-only removal
+// of the gathers / slice loads / barriers; `dbg`: per-wave phase stamps) exist
+// in the instrumented build ONLY: the shipped kernel has neither the
+// arguments nor a branch on them.
+#if BBX_TILED_INSTRUMENT
+#define BBX_INSTR_PARAMS int ablate, unsigned long long* dbg,
+#define BBX_INSTR_ARGS ablate, dbg,
+#else
+#define BBX_INSTR_PARAMS
+#define BBX_INSTR_ARGS
+#endif
 // Register ring of the value-free kernel: RING slots of BATCH steps each.
 // With non-temporal id loads the kernel is insensitive to the bytes a wave has
 // in flight (even ONE 1 KiB step in flight per wave runs as fast); shallow and
@@ -362,14 +373,18 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     const double* __restrict__ rowscale, double* __restrict__ out,
     double* __restrict__ slab, int n_acc,
     const int32_t* __restrict__ panel_fold, const FoldDesc* __restrict__ folds,
-    double* __restrict__ out_sum_part, int twt_off, int ablate,
-    unsigned long long* dbg, const int* __restrict__ skip_flag,
+    double* __restrict__ out_sum_part, int twt_off,
+    BBX_INSTR_PARAMS const int* __restrict__ skip_flag,
     ChainPtrs rowscale_k, ChainOut out_k, int out_stride, int part_stride,
     const double* __restrict__ addend, DotFold fa, DenseEpi de) {
   static_assert(!FOLD || (KP == 0 && WIDE), "the folded direction step is single-chain");
   static_assert(!DENSEP || (KP == 0 && !FOLD), "dense epilogue: single chain, plain loop");
   static_assert(!PACK || (KP == 0 && !VALS), "packed groups: value-free, one right-hand side");
   constexpr int K = KP > 0 ? 2 * KP : 1;
+#if !BBX_TILED_INSTRUMENT
+  constexpr int ablate = 0;                      // (compile-time: every
+  constexpr unsigned long long* dbg = nullptr;   // `if (dbg)` below folds away)
+#endif
   // (scalar load, issued first; checked below once the descriptor loads that
   // every launch needs anyway have been issued, so it adds no round trip)
   const int skip = skip_flag ? *skip_flag : 0;
@@ -503,9 +518,15 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
         fa.st->done = 1;
         fa.st->running = 0;
         if (!finite) fa.st->bad = 1;
+        if (fa.word)
+          cg_word_store(fa.word, fa.tag | CG_WORD_DONE |
+                                     (finite ? 0ull : CG_WORD_BAD) |
+                                     (unsigned long long)fa.k);
       }
       return;
     }
+    if (fa.word && bid == 0 && tid == 0)
+      cg_word_store(fa.word, fa.tag | (unsigned long long)(fa.k + 1));
     const double beta = fa.k > 0 ? rho / f_rho_prev : 0.;
     // wave-uniform scalars; c = v0 - <offset, v[1:]> of v = s.*r
     f_beta = lane_value(beta, 0);
@@ -541,12 +562,10 @@ __global__ __launch_bounds__(TILE_THREADS, BBX_TILE_MIN_WAVES) void tiled_spmv_k
     B0[q] = v2d{0., 0.};
     B1[q] = v2d{0., 0.};
   }
-  // BBX_TILED_DEBUG: per-wave cycle stamps (start, time in tile switches,
-  // end of the stream loop, end of the kernel); dbg is null in production.
+  // BBX_TILED_DEBUG (instrumented build): per-wave cycle stamps (start, time
+  // in tile switches, end of the stream loop, end of the kernel).
   // 32-bit tick counts (durations only: s_memtime bases differ across XCDs)
   unsigned t_start = 0, t_switch = 0, t_loop = 0, t_skew = 0, t_drain = 0;
-  if (!BBX_TILED_INSTRUMENT) dbg = nullptr;  // folds every timer away
-
   if (dbg) t_start = (unsigned)__builtin_amdgcn_s_memtime();
 
 #define BBX_ISSUE(K)                                                          \
@@ -1623,7 +1642,6 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
   static const int dbg_at =
       getenv("BBX_TILED_DEBUG") ? atoi(getenv("BBX_TILED_DEBUG")) : -1;
 #else
-  constexpr int ablate = 0;
   constexpr int dbg_at = -1;
 #endif
   static int dbg_count = 0;
@@ -1643,7 +1661,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
 #define BBX_TILED_LAUNCH_W(VV, WW, KK, VALPTR)                                 \
   BBX_TILED_LAUNCH_D(VV, WW, KK, false, false, false, VALPTR)
 #define BBX_TILED_LAUNCH_D(VV, WW, KK, FF, DD, PP, VALPTR)                     \
-  hipExtLaunchKernelGGL((tiled_spmv_kernel<VV, WW, KK, FF, DD, PP>),           \
+  BBX_LAUNCH_EXT((tiled_spmv_kernel<VV, WW, KK, FF, DD, PP>),           \
                      dim3(grid),                                               \
                      dim3(TILE_THREADS), (unsigned)lb, h->stream, ev_begin,    \
                      ev_end, 0u, m.R, m.C, m.W, m.PR,                          \
@@ -1654,7 +1672,7 @@ static int launch_tiled(bbx_design* h, const TiledMatrix& m, const double* x,
                      m.ids.as<uint4>(), VALPTR, x, c_part, x0_ptr, rowscale,   \
                      out, slab, m.PR + m.n_extra,                              \
                      m.panel_fold.as<int32_t>(), m.folds.as<FoldDesc>(),       \
-                     out_sum_part, twt_off, ablate, dbg, h->skip_flag,         \
+                     out_sum_part, twt_off, BBX_INSTR_ARGS h->skip_flag,       \
                      bb.rowscale, bb.out, bb.out_stride, bb.part_stride,       \
                      addend, fa, de)
 // value-free, one right-hand side: plain ids or packed groups (m.packed)
@@ -2203,7 +2221,7 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
       if (hp->kd > HYB_FUSED_WAVE_KD) {
         // a row of more than 1024 columns: the workgroup-per-row-pair kernel
 #define BBX_HYB_WG(GG, RR)                                                     \
-  hipLaunchKernelGGL((hyb_dense_fused_wg_kernel<GG, RR>), dim3(NPART),         \
+  BBX_LAUNCH((hyb_dense_fused_wg_kernel<GG, RR>), dim3(NPART),         \
                      dim3(1024),                                               \
                      0, h->stream, h->n, hp->kd, hp->ld_rm,                    \
                      hp->D_rm.as<double>(), hp->dense_cols.as<int32_t>(),      \
@@ -2236,7 +2254,7 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
       const size_t lds =
           sizeof(double) * (size_t)((nt / WAVE) * 2 * WAVE * gw + 2 * (nt / WAVE));
 #define BBX_HYB_FUSED(GG, RR, NN)                                              \
-  hipLaunchKernelGGL((hyb_dense_fused_kernel<GG, RR, NN>), dim3(NPART),        \
+  BBX_LAUNCH((hyb_dense_fused_kernel<GG, RR, NN>), dim3(NPART),        \
                      dim3(NN), lds, h->stream, h->n, hp->kd, hp->ld_rm,        \
                      hp->D_rm.as<double>(), hp->dense_cols.as<int32_t>(),      \
                      h->intercept, d_v, hp->addend.as<double>(), d_rowscale,   \
@@ -2264,7 +2282,7 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
     rest_slab = ms.slab.as<double>();
     G_rest = ms.G;
   }
-  hipLaunchKernelGGL(hyb_addend_kernel, dim3(1024), dim3(256),
+  BBX_LAUNCH(hyb_addend_kernel, dim3(1024), dim3(256),
                      sizeof(double) * (size_t)(hp->kd + 1), h->stream, h->n,
                      hp->kd, h->intercept, hp->D.as<double>(),
                      hp->dense_cols.as<int32_t>(), d_v, rest_slab, G_rest,
@@ -2275,7 +2293,7 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
     // several column groups: slabs, then the finalize kernel adds the addend
     BBX_TRY(launch_tiled(h, mb, x, nullptr, nullptr, nullptr, nullptr,
                          mb.slab.as<double>(), nullptr));
-    hipLaunchKernelGGL(tiled_dot_finalize_kernel, dim3(1024), dim3(256), 0,
+    BBX_LAUNCH(tiled_dot_finalize_kernel, dim3(1024), dim3(256), 0,
                        h->stream, mb.R, mb.G, mb.slab.as<double>(),
                        part_slot(h, PS_C), x0, d_rowscale, d_t,
                        hp->addend.as<double>());
@@ -2324,7 +2342,7 @@ static int launch_tdot_hybrid(bbx_design* h, const double* d_w,
       hp->dw_serial == h->operator_serial) {
     // the preceding X~ v kernel of this operator application left the partials
     // of D^T w, one row per workgroup: only the fixed-order sum is left to do
-    hipLaunchKernelGGL(hyb_dense_scatter_kernel, dim3((unsigned)hp->kd),
+    BBX_LAUNCH(hyb_dense_scatter_kernel, dim3((unsigned)hp->kd),
                        dim3(WAVE), 0, h->stream, hp->kd, hp->dw_chunks,
                        hp->dense_cols.as<int32_t>(), hp->dw_part.as<double>(),
                        slab + (size_t)at * (size_t)h->p, h->skip_flag);
@@ -2332,12 +2350,12 @@ static int launch_tdot_hybrid(bbx_design* h, const double* d_w,
     at += 1;
   } else if (hp->kd > 0) {
     const int64_t n_task = (int64_t)hp->kd * HYB_TDOT_CHUNKS;
-    hipLaunchKernelGGL(hyb_dense_tdot_kernel,
+    BBX_LAUNCH(hyb_dense_tdot_kernel,
                        dim3((unsigned)((n_task + 3) / 4)), dim3(256), 0,
                        h->stream, h->n, hp->kd, HYB_TDOT_CHUNKS,
                        hp->D.as<double>(), d_w, hp->d_part.as<double>(),
                        h->skip_flag);
-    hipLaunchKernelGGL(hyb_dense_scatter_kernel, dim3((unsigned)hp->kd),
+    BBX_LAUNCH(hyb_dense_scatter_kernel, dim3((unsigned)hp->kd),
                        dim3(WAVE), 0, h->stream, hp->kd, HYB_TDOT_CHUNKS,
                        hp->dense_cols.as<int32_t>(), hp->d_part.as<double>(),
                        slab + (size_t)at * (size_t)h->p, h->skip_flag);
@@ -2386,7 +2404,7 @@ int launch_dot_tiled(bbx_design* h, const double* d_v,
   BBX_TRY(timer_begin(h, 0));
   BBX_TRY(launch_tiled(h, m, x, nullptr, nullptr, nullptr, nullptr,
                        m.slab.as<double>(), nullptr));
-  hipLaunchKernelGGL(tiled_dot_finalize_kernel, dim3(1024), dim3(256), 0,
+  BBX_LAUNCH(tiled_dot_finalize_kernel, dim3(1024), dim3(256), 0,
                      h->stream, m.R, m.G, m.slab.as<double>(),
                      part_slot(h, PS_C), x0, d_rowscale, d_t, nullptr);
   BBX_HIP(hipGetLastError());
@@ -2533,7 +2551,7 @@ int launch_dot_tiled_k(bbx_design* h, int K, const double* d_v,
     }
     const size_t lds = sizeof(double) * (size_t)(hp->kd * K + 1);
 #define BBX_ADDEND_K(KK)                                                       \
-  hipLaunchKernelGGL(hyb_addend_k_kernel<KK>, dim3(1024), dim3(256), lds,      \
+  BBX_LAUNCH(hyb_addend_k_kernel<KK>, dim3(1024), dim3(256), lds,      \
                      h->stream, h->n, hp->kd, h->intercept, hp->D.as<double>(), \
                      hp->dense_cols.as<int32_t>(), d_v, rest_slab, G_rest,     \
                      hp->addend_k.as<double>(), h->skip_flag)
@@ -2557,7 +2575,7 @@ int launch_dot_tiled_k(bbx_design* h, int K, const double* d_v,
                        m.slab.as<double>(), nullptr, nullptr, nullptr, 0,
                        &slab_only));
 #define BBX_DOT_FIN(KK)                                                        \
-  hipLaunchKernelGGL(tiled_dot_finalize_k_kernel<KK>, dim3(NPART), dim3(256),  \
+  BBX_LAUNCH(tiled_dot_finalize_k_kernel<KK>, dim3(NPART), dim3(256),  \
                      0, h->stream, m.R, m.G, m.slab.as<double>(), d_c_part,    \
                      x0, ba.rowscale, ba.out, ba.out_stride, ba.part_stride,   \
                      d_sum_part, twt_off, addend)
@@ -2596,12 +2614,12 @@ int launch_tdot_tiled_k(bbx_design* h, int K, const double* d_w,
       double* row = sl + (size_t)at * (size_t)h->p * (size_t)K;
 #define BBX_DENSE_TDOT_K(KK)                                                   \
   do {                                                                         \
-    hipLaunchKernelGGL(hyb_dense_tdot_k_kernel<KK>,                            \
+    BBX_LAUNCH(hyb_dense_tdot_k_kernel<KK>,                            \
                        dim3((unsigned)((n_task + 3) / 4)), dim3(256), 0,       \
                        h->stream, h->n, hp->kd, HYB_TDOT_CHUNKS,               \
                        hp->D.as<double>(), d_w, hp->d_part_k.as<double>(),     \
                        h->skip_flag);                                          \
-    hipLaunchKernelGGL(hyb_dense_scatter_k_kernel<KK>, dim3((unsigned)hp->kd), \
+    BBX_LAUNCH(hyb_dense_scatter_k_kernel<KK>, dim3((unsigned)hp->kd), \
                        dim3(WAVE), 0, h->stream, hp->kd, HYB_TDOT_CHUNKS,      \
                        hp->dense_cols.as<int32_t>(),                           \
                        hp->d_part_k.as<double>(), row, h->skip_flag);          \

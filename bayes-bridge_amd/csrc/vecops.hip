@@ -6,6 +6,9 @@
 
 namespace bbx {
 
+std::atomic<unsigned long long> g_launch_count{0};
+
+
 __device__ inline double wave_sum_v(double x) { return wave_allsum(x); }
 
 __device__ inline void block_store_partial(double x, double* part) {
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void sqrt_scale_kernel(
 
 int launch_prep_v(bbx_design* h, const double* d_x, const double* d_s,
                   double* d_v, double* d_c_part, const int* d_skip) {
-  hipLaunchKernelGGL(prep_v_kernel, dim3(NPART), dim3(VEC_BLOCK), 0, h->stream,
+  BBX_LAUNCH(prep_v_kernel, dim3(NPART), dim3(VEC_BLOCK), 0, h->stream,
                      h->P, h->intercept, d_x, d_s, h->offset.as<double>(), d_v,
                      d_c_part, d_skip);
   BBX_HIP(hipGetLastError());
@@ -125,7 +128,7 @@ int launch_prep_v(bbx_design* h, const double* d_x, const double* d_s,
 
 int launch_sum_n(bbx_design* h, const double* d_w, int64_t len,
                  double* d_part) {
-  hipLaunchKernelGGL(sum_n_kernel, dim3(NPART), dim3(VEC_BLOCK), 0, h->stream,
+  BBX_LAUNCH(sum_n_kernel, dim3(NPART), dim3(VEC_BLOCK), 0, h->stream,
                      len, d_w, d_part);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
@@ -134,7 +137,7 @@ int launch_sum_n(bbx_design* h, const double* d_w, int64_t len,
 int launch_sqrt_scale(bbx_design* h, const double* d_omega,
                       const double* d_eta, double* d_w, double* d_part,
                       const double* d_minus, bool negate) {
-  hipLaunchKernelGGL(sqrt_scale_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
+  BBX_LAUNCH(sqrt_scale_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
                      h->stream, h->n, d_omega, d_eta, d_w, d_part, d_minus,
                      negate ? 1 : 0);
   BBX_HIP(hipGetLastError());
@@ -184,7 +187,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_direction_kernel(
     double* __restrict__ pvec, const double* __restrict__ s,
     const double* __restrict__ offset, double* __restrict__ sp,
     double* __restrict__ c_part, const double* __restrict__ d,
-    double* __restrict__ pdp_part) {
+    double* __restrict__ pdp_part, unsigned long long* word,
+    unsigned long long tag) {
   // every load that does not depend on another one goes out first
   const PartLoad pl = part_issue(rr_part);
   const int64_t stride = (int64_t)gridDim.x * VEC_BLOCK;
@@ -209,9 +213,16 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_direction_kernel(
       st->done = 1;
       st->running = 0;
       if (!finite) st->bad = 1;
+      // the host learns it from here: iteration count = k (SciPy's callbacks)
+      if (word)
+        cg_word_store(word, tag | CG_WORD_DONE | (finite ? 0ull : CG_WORD_BAD) |
+                                (unsigned long long)k);
     }
     return;
   }
+  // stop test k passed: the host may enqueue the next iteration(s)
+  if (word && blockIdx.x == 0 && threadIdx.x == 0)
+    cg_word_store(word, tag | (unsigned long long)(k + 1));
   const double beta = (k > 0) ? rho / rho_prev : 0.;
   double acc = 0., acc_d = 0.;
   if (has0) {
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void cg_finish_kernel(
 int launch_cg_setup(bbx_design* h, int n_unshrunk, const double* phi,
                     const double* sd, const double* x0, double* s, double* d,
                     double* xs, CGState* st, double atol) {
-  hipLaunchKernelGGL(cg_setup_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
+  BBX_LAUNCH(cg_setup_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
                      h->stream, h->P, n_unshrunk, phi, sd, x0, s, d, xs, st,
                      atol);
   BBX_HIP(hipGetLastError());
@@ -304,10 +315,11 @@ int launch_cg_setup(bbx_design* h, int n_unshrunk, const double* phi,
 int launch_cg_direction(bbx_design* h, int k, CGState* st,
                         const double* rr_part, const double* r, double* pvec,
                         const double* s, double* sp, double* c_part,
-                        const double* d, double* pdp_part) {
-  hipLaunchKernelGGL(cg_direction_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
+                        const double* d, double* pdp_part,
+                        unsigned long long* word, unsigned long long tag) {
+  BBX_LAUNCH(cg_direction_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
                      h->stream, h->P, h->intercept, k, st, rr_part, r, pvec, s,
-                     h->offset.as<double>(), sp, c_part, d, pdp_part);
+                     h->offset.as<double>(), sp, c_part, d, pdp_part, word, tag);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
 }
@@ -315,7 +327,7 @@ int launch_cg_direction(bbx_design* h, int k, CGState* st,
 int launch_cg_update(bbx_design* h, int k, CGState* st, const double* pq_part,
                      const double* pvec, const double* q, double* x, double* r,
                      double* rr_part) {
-  hipLaunchKernelGGL(cg_update_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
+  BBX_LAUNCH(cg_update_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
                      h->stream, h->P, k, st, pq_part, pvec, q, x, r, rr_part);
   BBX_HIP(hipGetLastError());
   return BBX_OK;
@@ -323,7 +335,7 @@ int launch_cg_update(bbx_design* h, int k, CGState* st, const double* pq_part,
 
 int launch_cg_finish(bbx_design* h, const double* s, const double* x,
                      double* coef) {
-  hipLaunchKernelGGL(cg_finish_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
+  BBX_LAUNCH(cg_finish_kernel, dim3(NPART), dim3(VEC_BLOCK), 0,
                      h->stream, h->P, s, x, coef, h->coef_copy);
   BBX_HIP(hipGetLastError());
   return BBX_OK;

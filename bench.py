@@ -36,8 +36,9 @@ CONFIGS = {
     "config3": (1000000, 50000, .002),
     # BASELINE config 4: linear model, dense N(0,1) design stored in f32
     "config4": (200000, 8000, None),
-    # small smoke configuration (launcher dry runs, tests)
+    # small smoke configurations (launcher dry runs, tests)
     "tiny": (20000, 1000, .02),
+    "tiny-dense": (6000, 400, None),
     # between configs 2 and 3 (A/Bs of size-dependent choices)
     "mid": (400000, 20000, .005),
 }
@@ -63,8 +64,11 @@ def parse_args(argv=None):
     ap.add_argument("--config", default="config3", choices=sorted(CONFIGS))
     ap.add_argument("--storage", default="auto",
                     choices=["auto", "csr", "tiled"])
-    ap.add_argument("--cpu-baseline-iters", type=int, default=5,
-                    help="Gibbs iterations of each CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=None,
+                    help="Gibbs iterations of each CPU baseline (0 = skip; "
+                         "default 5, 2 for the dense configs: one config-4 "
+                         "iteration is ~110 operator applications of two "
+                         "12.8 GB dgemv each)")
     ap.add_argument("--seed", type=int, default=111)
     ap.add_argument("--dense-storage", default="float32",
                     choices=["float32", "float64"],
@@ -233,6 +237,76 @@ def cpu_baselines(prob, state, n_iters, seed):
     port = run("port", 1, use_scipy_cg=True)
     omp = run("port-omp", omp_cores, omp_threads=omp_cores)
     return port, omp
+
+
+def cpu_baseline_dense(x_host, offset, y, state, n_iters, seed):
+    """Config 4's CPU leg: the oracle chain on what the reference's dense path
+    runs -- `X.dot(v)` / `X.T.dot(w)` of a C-ordered float64 array (two BLAS
+    dgemv per operator application, dense_matrix.py:42,52) and
+    scipy.sparse.linalg.cg -- for `n_iters` Gibbs iterations from the GPU
+    chain's post-warm-up state.  X is the SAME matrix (the f32-representable
+    entries the GPU generated), centred, with the intercept column, in f64 as
+    the reference holds it; BLAS threads = the cores this container can keep
+    busy (threadpoolctl), stated in `cores`."""
+    import numpy as np
+    from threadpoolctl import threadpool_info, threadpool_limits
+    from oracle.design_matrix import OracleDenseDesign
+    from oracle.gibbs import OracleGibbs
+    from oracle.omp_baseline import usable_cores
+    from oracle.rng import OracleRandom
+    from oracle.summarizer import CoefSummarizer
+    n, p = x_host.shape
+    cores = usable_cores()
+    t0 = time.perf_counter()
+    Xf = np.empty((n, p + 1))
+    Xf[:, 0] = 1.
+    step = max(1, (64 << 20) // (8 * p))
+    for r0 in range(0, n, step):       # centre while widening, chunk by chunk
+        Xf[r0:r0 + step, 1:] = x_host[r0:r0 + step]
+        Xf[r0:r0 + step, 1:] -= offset
+    prep_s = time.perf_counter() - t0
+    coef0, obs0, ls0, g0, mean, square, n_avg = state
+    with threadpool_limits(limits=cores):
+        blas = sorted({"%s %s" % (i.get("internal_api"), i.get("num_threads"))
+                       for i in threadpool_info()
+                       if i.get("user_api") == "blas"})
+        chain = OracleGibbs(y, OracleDenseDesign.from_full(Xf), 'linear',
+                            bridge_exponent=ALPHA, regularizing_slab_size=SLAB,
+                            use_scipy_cg=True)
+        chain.rng = OracleRandom(seed)
+        summ = CoefSummarizer(chain.P, chain.nu, chain.slab)
+        summ.set_state({'mean': mean, 'square': square, 'n_averaged': n_avg})
+        d = chain.design
+        v, w = np.ones(p + 1), np.ones(n)
+        d.dot(v), d.Tdot(w)
+        t1 = time.perf_counter()
+        d.dot(v)
+        t2 = time.perf_counter()
+        d.Tdot(w)
+        t3 = time.perf_counter()
+        coef, obs_prec, lscale, gscale = coef0, obs0, ls0, g0
+        n_cg = []
+        t0 = time.perf_counter()
+        for _ in range(n_iters):
+            coef, info = chain.draw_coef(obs_prec, gscale, lscale, summ)
+            obs_prec = chain.draw_obs_prec(coef)
+            gscale = chain.draw_gscale(coef[chain.nu:])
+            lscale = chain.draw_lscale(gscale, coef[chain.nu:])
+            chain.logp(coef, gscale, obs_prec)
+            n_cg.append(info['n_iter'])
+        dt = time.perf_counter() - t0
+    return dict(
+        value=round(n_iters / dt, 5), unit="Gibbs iters/sec", cores=cores,
+        kind="port",
+        sample="%d Gibbs iterations of the CPU oracle chain (NumPy X.dot / "
+               "X.T.dot = BLAS dgemv on a C-ordered float64 %dx%d array, "
+               "scipy.sparse.linalg.cg, linear model) on the same matrix "
+               "from the GPU chain's post-warm-up state; mean n_cg=%.1f; "
+               "%.1f s (+ %.1f s to widen and centre the matrix)"
+               % (n_iters, n, p + 1, float(np.mean(n_cg)), dt, prep_s),
+        blas=blas, host_cores=os.cpu_count(),
+        dot_gbs=round(8. * n * (p + 1) / (t2 - t1) / 1e9, 1),
+        tdot_gbs=round(8. * n * (p + 1) / (t3 - t2) / 1e9, 1))
 
 
 def iteration_bytes(mean_ncg, op_bytes, dot_bytes, tdot_bytes, n, P,
@@ -446,7 +520,11 @@ def main():
         dist.all_gather_object(ids, dev_index)
         assert len(set(ids)) == world, ids
 
-    dense = args.config == "config4"
+    dense = CONFIGS[args.config][2] is None
+    if args.cpu_baseline_iters is None:
+        args.cpu_baseline_iters = 2 if dense else 5
+    solo = rank == 0 and world == 1 and env_world is None
+    x_host = None
     unit = math.gamma(2 / ALPHA) / math.gamma(1 / ALPHA)   # prior.py:163-167
     seed_k = chains.chain_seed(args.seed, rank)
     if dense:
@@ -458,6 +536,9 @@ def main():
             n, p, prob["X"].data_ptr(), prob["offset"].data_ptr(),
             add_intercept=True, device=dev_index, in_dtype='float32',
             storage_dtype=args.dense_storage)
+        if solo and args.cpu_baseline_iters > 0:
+            # the CPU leg runs on the same matrix (f32 here, widened there)
+            x_host = prob["X"].cpu().numpy()
         del prob["X"]
         outcome = prob["y"].cpu().numpy()
         def make_chain(seed):
@@ -515,9 +596,7 @@ def main():
     if widths is None:
         widths = "4,8,16,32" if dense else "2,4"
     widths = [int(v) for v in widths.split(",") if int(v) > 1]
-    solo = rank == 0 and world == 1 and env_world is None
-    want_state = solo and ((args.cpu_baseline_iters > 0 and not dense)
-                           or bool(widths))
+    want_state = solo and (args.cpu_baseline_iters > 0 or bool(widths))
     d_buf = torch.empty((max(K, W, 1), P), dtype=torch.float64, device=device)
     d_coef = d_buf[:max(K, 1)]          # (the warm-up may keep more samples)
     if grouped:
@@ -540,11 +619,20 @@ def main():
             args.timing_every = int(min(64, max(8, per_block // 24)))
             design.set_timing(True, every=args.timing_every)
         design.reset_timing()
+    lib = _lib.load()
+    has_stats = hasattr(design, "cg_stats")      # (A/B against an older build)
+    if has_stats:
+        design.cg_stats(reset=True)
     chains.barrier()
     torch.cuda.synchronize()
+    launches0 = lib.bbx_launch_count() if has_stats else 0
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     gs, lp, ncg, _ = chain.run_device(K, d_coef_ptr=d_coef.data_ptr())
     t_run = time.perf_counter()
+    own_cpu = time.process_time() - cpu0
+    launches = (lib.bbx_launch_count() - launches0) if has_stats else None
+    cg_solves, cg_empty = design.cg_stats() if has_stats else (0, 0)
     gathered = chains.gather_chain_samples(d_coef, dst=0)
     if grouped:
         torch.cuda.synchronize()
@@ -553,6 +641,18 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     own_elapsed, own_run, own_gather = elapsed, t_run - t0, t_gather - t_run
+    # the host side of this rank's K iterations: CPU seconds this process
+    # burnt (enqueueing + polling the CG loop's progress word), kernel
+    # launches, and the launches enqueued past a solve's stopping iteration
+    host_side = dict(
+        cpu_s_per_step=round(own_cpu / max(K, 1), 6),
+        cpu_busy_frac=round(own_cpu / own_run, 3) if own_run > 0 else None,
+        launches_per_step=round(launches / max(K, 1), 1)
+        if launches is not None else None,
+        launches_per_sec=round(launches / own_run, 0)
+        if launches is not None and own_run > 0 else None,
+        empty_launches_per_draw=round(cg_empty / max(cg_solves, 1), 2)
+        if has_stats else None)
     elapsed = chains.max_over_ranks(elapsed)
     progress("timed region done (%.3f s)" % elapsed)
     timing = design.get_timing() if timing_on else {
@@ -607,6 +707,10 @@ def main():
             iters_per_sec=round(K / own_run, 2) if own_run > 0 else None,
             mean_n_cg_iter=round(float(ncg.mean()), 2),
             burnin_ms_per_step=round(burnin_ms, 4),
+            host_cpu_s_per_step=host_side["cpu_s_per_step"],
+            host_cpu_busy_frac=host_side["cpu_busy_frac"],
+            launches_per_sec=host_side["launches_per_sec"],
+            empty_launches_per_draw=host_side["empty_launches_per_draw"],
             device_index=dev_index,
             device_name=torch.cuda.get_device_name(dev_index),
             pid=os.getpid())
@@ -616,7 +720,11 @@ def main():
             "one entry per rank: timed_s = this rank's barrier-to-barrier "
             "seconds before the MAX over ranks, run_s = its K Gibbs "
             "iterations alone, gather_ms = its share of the one gather of "
-            "the kept samples, iters_per_sec = K / run_s")
+            "the kept samples, iters_per_sec = K / run_s; host_cpu_s_per_step "
+            "= CPU seconds of this process per Gibbs iteration "
+            "(time.process_time), host_cpu_busy_frac = that / run_s (1.0 = "
+            "one core: the host polls the CG loop's progress word), "
+            "launches_per_sec = kernel launches of this rank per second")
 
     if rank == 0:
         assert gathered is not None and gathered.shape[0] == world
@@ -781,6 +889,8 @@ def main():
                 # the timed region's counts (what the solve's look-ahead for
                 # the stop flag has to predict)
                 "n_cg_iter_timed": [int(v) for v in ncg[:64]],
+                # this rank's host side of the timed K iterations
+                "host": host_side,
                 # set-up cost per rank (an 8-rank launch runs 8 generators and 8
                 # host-side layout builders side by side): seconds from process
                 # start to a ready chain and this rank's peak host RSS
@@ -845,6 +955,10 @@ def main():
                                       args.seed)
             line["cpu_baseline"] = port
             line["cpu_baseline_omp"] = omp
+        elif state is not None and args.cpu_baseline_iters > 0:
+            line["cpu_baseline"] = cpu_baseline_dense(
+                x_host, prob["offset"].cpu().numpy(), outcome, state,
+                args.cpu_baseline_iters, args.seed)
         else:
             line["cpu_baseline"] = None
         sys.stdout.flush()

@@ -33,12 +33,14 @@
 extern "C" {
 #endif
 
-/* 102: + bbx_design_create_csr64 (64-bit index arrays, 2^31 or more entries).
+/* 103: + bbx_design_cg_stats (solves and launches enqueued past the stopping
+ *      iteration since the last reset), bbx_launch_count.
+ * 102: + bbx_design_create_csr64 (64-bit index arrays, 2^31 or more entries).
  * 101: bbx_design_tiled_info takes nine pointers (`packed`, since round 4),
  *      bbx_setup_lock_acquire/_release, bbx_design_useful_bytes.  A binding
  *      compares bbx_version() with the BBX_VERSION it was written against
  *      (bayesbridge_amd/_lib.py does) instead of calling with a stale arity. */
-#define BBX_VERSION 102 /* 0.1.2 */
+#define BBX_VERSION 103 /* 0.1.3 */
 
 /* status codes */
 #define BBX_OK 0
@@ -220,6 +222,18 @@ int bbx_design_useful_bytes(const bbx_design* h, int64_t* dot_bytes,
  * update is merged, 5 otherwise.  Inside the CG loop the X~ v kernel that
  * bbx_design_timed_bytes describes then also moves 8 P-vectors. */
 int bbx_design_cg_launches(const bbx_design* h, int* per_iteration);
+/* The host side of that loop (cg_sampler.py:77-80 is a Python loop around two
+ * products; here the host only enqueues, runs ahead of the device's stop test
+ * and reads its outcome from a host-mapped progress word): CG solves on this
+ * design since creation / the last reset, and the kernel launches they enqueued
+ * past their stopping iteration (such kernels return at entry, ~2 us each).
+ * reset != 0 zeroes both after reading.  Output pointers may be NULL. */
+int bbx_design_cg_stats(bbx_design* h, int64_t* solves, int64_t* empty_launches,
+                        int reset);
+/* Kernel launches this process has made through the library, all designs and
+ * chains (a diagnostic: launches per second and rank is what the host side of
+ * an N-rank node has to sustain; the reference launches nothing). */
+uint64_t bbx_launch_count(void);
 /* The 3-launch form: the direction step inside the X~ v kernel -- every
  * workgroup re-adds the r.r partials (rho, stop test, beta), the kernel streams
  * X~ (s.*r) and its epilogue forms t_k = X~ (s.*r_k) + beta t_{k-1}, which is

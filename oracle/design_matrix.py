@@ -111,6 +111,21 @@ class OracleDenseDesign(_Counting):
         self.centered = center_predictor
         self.intercept_added = add_intercept
 
+    @classmethod
+    def from_full(cls, X_full, centered=True):
+        """Wraps an [n, P] float64 array that already IS the operator: column
+        0 the intercept's ones, the others centred (what
+        DenseDesignMatrix.__init__ leaves behind, dense_matrix.py:9-27) --
+        without the copies the constructor makes (bench.py's config-4 leg:
+        12.8 GB)."""
+        self = cls.__new__(cls)
+        _Counting.__init__(self)
+        assert X_full.dtype == np.float64 and X_full.ndim == 2
+        self.X = X_full
+        self.centered = centered
+        self.intercept_added = True
+        return self
+
     @property
     def shape(self):
         return self.X.shape
@@ -138,6 +153,8 @@ class OracleDenseDesign(_Counting):
 def make_design(X, add_intercept=True, center_predictor=True):
     """model/factory.py:10-52 for linear/logit: sparse input -> sparse operator,
     defaults add_intercept=True, center_predictor=True."""
+    if isinstance(X, _Counting):      # an operator built by the caller
+        return X
     cls = OracleSparseDesign if sp.issparse(X) else OracleDenseDesign
     return cls(X, center_predictor=center_predictor,
                add_intercept=add_intercept)

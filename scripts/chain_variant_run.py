@@ -1,7 +1,7 @@
 """A short device chain (bbx_chain_run) on a seeded problem, samples saved to
 an .npz -- for comparing variants that are selected once per process
 (BBX_CHAIN_FORK=0|1, BBX_CG_MERGE_RESID=0|1, BBX_CG_MERGE_UPDATE=0|1):
-    python scripts/chain_variant_run.py out.npz [logit|linear] [n] [p] [iters]
+    python scripts/chain_variant_run.py out.npz [logit|linear] [n] [p] [iters] [binary_frac]
 """
 import os
 import sys
@@ -19,8 +19,10 @@ family = sys.argv[2] if len(sys.argv) > 2 else "logit"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
 p = int(sys.argv[4]) if len(sys.argv) > 4 else 300
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 6
+binary_frac = float(sys.argv[6]) if len(sys.argv) > 6 else .8
 warnings.simplefilter("ignore")
-X = simulate.simulate_design_csr(n, p, binary_frac=.8, binary_pred_freq=.1, seed=3)
+X = simulate.simulate_design_csr(n, p, binary_frac=binary_frac,
+                                 binary_pred_freq=.1, seed=3)
 beta = np.zeros(p)
 beta[:5], beta[5:10] = 1.5, -1.
 y = simulate.simulate_outcome(X, beta, family, seed=4)
@@ -41,4 +43,5 @@ kept, n_unconv = chain.run(iters, save=('coef', 'local_scale', 'obs_prec'))
 np.savez(out, coef=kept['coef'], local_scale=kept['local_scale'],
          obs_prec=kept['obs_prec'], global_scale=kept['global_scale'],
          logp=kept['logp'], n_cg_iter=kept['n_cg_iter'])
-print("n_cg", kept['n_cg_iter'].tolist(), "unconverged", n_unconv)
+print("n_cg", kept['n_cg_iter'].tolist(), "unconverged", n_unconv,
+      "format", hip.storage_format, "cg launches", hip.cg_launches)

@@ -30,3 +30,25 @@ def test_iteration_byte_model_is_within_3_percent_of_the_pmc_counters(name):
     assert abs(model / measured - 1.) <= .03, (model, measured)
     # the operator's two products are what moves: > 95 % of an iteration
     assert ncg * (prof["dot_bytes"] + prof["tdot_bytes"]) > .9 * measured
+
+
+def test_dense_cpu_baseline_leg_reports_cores_and_blas():
+    """bench.py --config config4's `cpu_baseline`: the oracle chain on NumPy
+    dgemv products (dense_matrix.py:42,52) with the BLAS thread count stated;
+    run here on a small matrix from a made-up chain state."""
+    import numpy as np
+    import bench
+    rng = np.random.default_rng(0)
+    n, p = 3000, 40
+    x = rng.standard_normal((n, p)).astype(np.float32)
+    offset = x.astype(np.float64).mean(axis=0)
+    beta = np.zeros(p)
+    beta[:3] = 1.
+    y = x.astype(np.float64).dot(beta) + rng.standard_normal(n)
+    P = p + 1
+    state = (np.zeros(P), 1., np.ones(p), .05, np.zeros(P), np.ones(P), 0)
+    out = bench.cpu_baseline_dense(x, offset, y, state, 2, 1)
+    assert out["kind"] == "port" and out["value"] > 0
+    assert out["cores"] >= 1 and out["unit"] == "Gibbs iters/sec"
+    assert out["sample"].startswith("2 Gibbs iterations")
+    assert out["blas"] and out["dot_gbs"] > 0 and out["tdot_gbs"] > 0

@@ -54,6 +54,22 @@ def test_single_gpu_line_has_roofline_and_both_cpu_baselines():
     assert line["config"]["startup_s"] > 0 and line["config"]["peak_host_rss_mb"] > 0
 
 
+def test_dense_line_has_a_cpu_baseline():
+    """config 4's shape in miniature: the dense line carries `cpu_baseline`
+    (NumPy dgemv products + SciPy cg, BLAS threads stated), like the sparse
+    line carries the SciPy CSR one."""
+    line = _bench("--config", "tiny-dense", "--steps", "6", "--warmup", "2",
+                  "--burnin", "4", "--multi-chain", "4")
+    assert line["value"] > 0 and line["roofline"]["bound"] == "hbm"
+    assert "dense" in line["config"]["workload"]
+    b = line["cpu_baseline"]
+    assert b["kind"] == "port" and b["value"] > 0 and b["cores"] >= 1
+    assert b["sample"].startswith("2 Gibbs iterations")
+    assert "dgemv" in b["sample"] and b["blas"]
+    assert b["dot_gbs"] > 0 and b["tdot_gbs"] > 0
+    assert line["multi_chain"]["k=4"]["chain_iters_per_sec"] > 0
+
+
 def test_gpus_2_launches_two_ranks_by_itself():
     line = _bench("--gpus", "2", "--config", "tiny", "--steps", "4",
                   "--warmup", "1", "--burnin", "2")

@@ -258,8 +258,13 @@ def test_device_chain_agrees_with_reference_stream_chain():
 
 def test_dense_linear_chain_config1_summary(golden_dir):
     """BASELINE config 1 (dense 2000x500 linear, cg): the reference's 20
-    iterations are summarised in the fixture; the exact-seed mode reproduces
-    them, the device mode lands in the same region."""
+    iterations are summarised in the fixture.  The exact-seed mode reproduces
+    them at the reference's own CPU-vs-GPU bound (atol 1e-5 on the samples,
+    tests/gpu_tests/test_gibbs.py:44) -- the CPU oracle's own chain moves by
+    <= 1.2e-6 and its stopping iterations by <= 4 when X is perturbed by 1e-15
+    (profiles/r06_config1_sensitivity.txt) -- and the device-RNG mode, other
+    random streams, climbs the same transient: tau from .005 to ~.02 within
+    the 20 iterations, the 15 signals found, CG effort growing alike."""
     import os
     from bayesbridge_amd import BayesBridge, RegressionCoefPrior, \
         RegressionModel, simulate
@@ -277,12 +282,33 @@ def test_dense_linear_chain_config1_summary(golden_dir):
         s, info = BayesBridge(RegressionModel(y, X, 'linear'), prior).gibbs(
             20, 0, init={'global_scale': .01}, coef_sampler_type='cg',
             seed=111, options={'rng': 'reference'})
-    assert np.allclose(s['coef'][:, -1], g['coef_last'], atol=1e-4)
-    assert np.allclose(s['global_scale'], g['global_scale'], rtol=1e-3)
-    # ~80 CG iterations on a flat stretch of the residual curve: the stopping
-    # iteration moves by a few with the summation order
+    assert np.allclose(s['coef'][:, -1], g['coef_last'], atol=1e-5)
+    assert np.allclose(s['coef'][:, 10:].mean(axis=1), g['coef_mean_last10'],
+                       atol=1e-5)
+    assert np.allclose(s['global_scale'], g['global_scale'], rtol=1e-5)
+    assert np.allclose(s['logp'], g['logp'], rtol=1e-6)
+    # ~80 CG iterations on a flat stretch of the residual curve: the oracle's
+    # own stopping iteration moves by up to 4 under 1e-15 perturbations
     assert np.abs(info['_reg_coef_sampling_info']['n_cg_iter']
-                  - g['n_cg_iter']).max() <= 8
+                  - g['n_cg_iter']).max() <= 5
+
+    # the device-RNG mode (what gibbs() runs by default) on the same problem
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        d, dinfo = BayesBridge(RegressionModel(y, X, 'linear'), prior).gibbs(
+            20, 0, init={'global_scale': .01}, coef_sampler_type='cg',
+            seed=111)
+    assert dinfo['options']['rng'] == 'device'
+    m_d, m_r = d['coef'][:, 10:].mean(axis=1), g['coef_mean_last10']
+    # posterior sd of a coefficient ~ 1 / sqrt(n) = .022; ten correlated draws
+    assert np.abs(m_d - m_r)[1:16].max() < .25   # (still in the transient)
+    assert np.abs(m_d[16:]).max() < .12 and np.abs(m_r[16:]).max() < .12
+    assert np.all((d['global_scale'][:4] > .003) & (d['global_scale'][:4] < .008))
+    assert np.all((d['global_scale'][14:] > .012) & (d['global_scale'][14:] < .04))
+    n_d = dinfo['_reg_coef_sampling_info']['n_cg_iter']
+    assert n_d[:4].max() <= 12 and 50 <= n_d[15:].mean() <= 110
+    assert abs(d['logp'][10:].mean() - g['logp'][10:].mean()) \
+        < 3 * max(g['logp'][10:].std(), d['logp'][10:].std())
 
 
 def _variant_chain(tmp_path, env, family='logit', iters=6, n=4000, p=300):

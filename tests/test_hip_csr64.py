@@ -206,6 +206,10 @@ def test_a_design_of_more_than_2_31_stored_entries():
     block = HipSparseDesignMatrix.from_csr_arrays(
         (N_A, P_BIG), ptr_a.astype(np.int32), cols_a.ravel(),
         add_intercept=False, storage='tiled')
+    import scipy.sparse as sparse
+    A_block = sparse.csr_matrix(
+        (np.ones(nnz_a), cols_a.ravel().copy(), ptr_a.astype(np.int32)),
+        shape=(N_A, P_BIG))
     n, nnz = N_A * COPIES, nnz_a * COPIES
     assert nnz >= 2 ** 31
     indices = np.empty(nnz, dtype=np.int64)
@@ -231,16 +235,22 @@ def test_a_design_of_more_than_2_31_stored_entries():
     assert hip.shape == (n, P_BIG)
     v, w = rng.standard_normal(P_BIG), rng.standard_normal(n)
     t, g = hip.dot(v), hip.Tdot(w)
-    ref_t = np.tile(block.dot(v), COPIES)
+    # the oracle: SciPy's CSR products of the block (sparse_matrix.py:96,126)
+    # -- the design is COPIES stacked copies of it, so X v is the block's
+    # product tiled and X^T w the block's transposed product of the summed w
+    ref_t = np.tile(A_block.dot(v), COPIES)
     assert np.abs(t - ref_t).max() <= 1e-11 * np.abs(ref_t).max()
-    ref_g = block.Tdot(w.reshape(COPIES, N_A).sum(axis=0))
+    ref_g = A_block.T.dot(w.reshape(COPIES, N_A).sum(axis=0))
     assert np.abs(g - ref_g).max() <= 1e-10 * np.abs(ref_g).max()
+    # ... and the HIP operator of the block alone agrees with both
+    assert np.abs(np.tile(block.dot(v), COPIES) - ref_t).max() \
+        <= 1e-11 * np.abs(ref_t).max()
     lhs, rhs = np.dot(t, w), np.dot(v, g)
     assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs), 1.)
     # the data part of the CG operator through the launches the CG loop uses
     omega = rng.random(n) + .5
     gm = hip.gram_matvec(omega, v)
-    ref_gm = block.Tdot((omega * ref_t).reshape(COPIES, N_A).sum(axis=0))
+    ref_gm = A_block.T.dot((omega * ref_t).reshape(COPIES, N_A).sum(axis=0))
     assert np.abs(gm - ref_gm).max() <= 1e-9 * np.abs(ref_gm).max()
     # a device chain runs on it: three Gibbs iterations of the logit model
     from bayesbridge_amd import HipGibbsChain
