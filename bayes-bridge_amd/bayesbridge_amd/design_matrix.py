@@ -385,6 +385,9 @@ class HipSparseDesignMatrix(HipDesignMatrix):
         nnz = int(indptr[-1]) if len(indptr) else 0
         if len(indptr) != n + 1 or len(indices) < nnz:
             raise ValueError("indptr / indices do not describe %d rows" % n)
+        if data is not None and len(data) < nnz:
+            raise ValueError("data holds %d values, indptr[-1] says %d"
+                             % (len(data), nnz))
         create = (self._lib.bbx_design_create_csr64 if wide
                   else self._lib.bbx_design_create_csr)
         _lib.check(create(
@@ -399,7 +402,11 @@ class HipSparseDesignMatrix(HipDesignMatrix):
         """The design from raw CSR arrays in host memory, int32 or int64 --
         for matrices too large to also hold SciPy's float64 `data` of a
         binary design (`data=None`: every stored value is 1.0).  Column ids
-        must ascend within a row; `column_offset` (p) centres the columns."""
+        must ascend within a row; `column_offset` (p) centres the columns.
+        Unlike the main constructor (abstract_matrix.py:93-107) this path does
+        NOT look for constant columns: a column of ones next to
+        `add_intercept=True` makes the design rank-deficient -- drop it
+        before calling."""
         self = cls.__new__(cls)
         HipDesignMatrix.__init__(self)
         _lib.require_gpu()

@@ -9,6 +9,7 @@
 #include <sys/file.h>
 #include <unistd.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <unordered_set>
@@ -306,7 +307,12 @@ static int validate_csr(bbx_design* h) {
 // a design constructor used to hang): one descriptor, one depth counter, the
 // flock taken at depth 0 -> 1 and dropped at 1 -> 0.  bbx_setup_lock_acquire /
 // _release are the exported form (chains.setup_turn goes through them).
+// The re-entrancy is per THREAD: a second thread of the owning process waits
+// (condition variable) until the owner's depth is back at 0 -- it neither runs
+// its device set-up beside the owner's nor can it drop the owner's flock.
 static std::mutex g_setup_mutex;
+static std::condition_variable g_setup_cv;
+static std::thread::id g_setup_owner;
 static int g_setup_fd = -1;
 static int g_setup_depth = 0;
 static bool g_setup_warned = false;
@@ -314,39 +320,52 @@ static bool g_setup_warned = false;
 static int setup_lock_acquire() {
   const char* path = getenv("BBX_SETUP_LOCK");
   if (!path || !*path) return 0;
-  std::lock_guard<std::mutex> guard(g_setup_mutex);
-  if (g_setup_depth == 0) {
-    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
-    if (fd < 0) {
-      if (!g_setup_warned) {
-        fprintf(stderr, "libbbx: BBX_SETUP_LOCK=%s cannot be opened (%s): the "
-                "device set-up of this process is NOT serialised\n", path,
-                strerror(errno));
-        g_setup_warned = true;
-      }
-      return 0;
-    }
-    int rc;
-    do { rc = flock(fd, LOCK_EX); } while (rc != 0 && errno == EINTR);
-    if (rc != 0) {
-      fprintf(stderr, "libbbx: flock(%s) failed (%s): not serialised\n", path,
-              strerror(errno));
-      (void)close(fd);
-      return 0;
-    }
-    g_setup_fd = fd;
+  std::unique_lock<std::mutex> guard(g_setup_mutex);
+  const std::thread::id me = std::this_thread::get_id();
+  if (g_setup_depth > 0 && g_setup_owner == me) {
+    ++g_setup_depth;
+    return 1;
   }
-  ++g_setup_depth;
+  g_setup_cv.wait(guard, [] { return g_setup_depth == 0; });
+  const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
+  if (fd < 0) {
+    if (!g_setup_warned) {
+      fprintf(stderr, "libbbx: BBX_SETUP_LOCK=%s cannot be opened (%s): the "
+              "device set-up of this process is NOT serialised\n", path,
+              strerror(errno));
+      g_setup_warned = true;
+    }
+    return 0;
+  }
+  // (the flock is waited for with the mutex held: other threads of this
+  // process queue on the mutex, which is what they would do anyway)
+  int rc;
+  do { rc = flock(fd, LOCK_EX); } while (rc != 0 && errno == EINTR);
+  if (rc != 0) {
+    fprintf(stderr, "libbbx: flock(%s) failed (%s): not serialised\n", path,
+            strerror(errno));
+    (void)close(fd);
+    return 0;
+  }
+  g_setup_fd = fd;
+  g_setup_owner = me;
+  g_setup_depth = 1;
   return 1;
 }
 
 static void setup_lock_release() {
   std::lock_guard<std::mutex> guard(g_setup_mutex);
-  if (g_setup_depth <= 0) return;
-  if (--g_setup_depth == 0 && g_setup_fd >= 0) {
-    (void)flock(g_setup_fd, LOCK_UN);
-    (void)close(g_setup_fd);
-    g_setup_fd = -1;
+  // (only the owner's release counts: an unbalanced call from another thread
+  // must not drop the flock under the owner)
+  if (g_setup_depth <= 0 || g_setup_owner != std::this_thread::get_id()) return;
+  if (--g_setup_depth == 0) {
+    if (g_setup_fd >= 0) {
+      (void)flock(g_setup_fd, LOCK_UN);
+      (void)close(g_setup_fd);
+      g_setup_fd = -1;
+    }
+    g_setup_owner = std::thread::id();
+    g_setup_cv.notify_all();
   }
 }
 
@@ -535,14 +554,19 @@ static int create_csr64_big(int64_t n, int64_t p, int64_t nnz,
   h->centred = (col_offset != nullptr);
   h->format = BBX_FORMAT_TILED;
   auto body = [&]() -> int {
-    BBX_TRY(design_alloc_work(h));
-    BBX_TRY(h->offset.alloc(sizeof(double) * (size_t)p));
-    if (col_offset)
-      BBX_HIP(hipMemcpy(h->offset.ptr, col_offset, sizeof(double) * (size_t)p,
-                        hipMemcpyHostToDevice));
-    else
-      BBX_HIP(hipMemset(h->offset.ptr, 0, sizeof(double) * (size_t)p));
-    BBX_HIP(hipDeviceSynchronize());
+    {
+      // (the device part of this constructor takes its turn like finish_csr's;
+      // the host-side layout build below runs beside other ranks' builds)
+      SetupTurn lock;
+      BBX_TRY(design_alloc_work(h));
+      BBX_TRY(h->offset.alloc(sizeof(double) * (size_t)p));
+      if (col_offset)
+        BBX_HIP(hipMemcpy(h->offset.ptr, col_offset, sizeof(double) * (size_t)p,
+                          hipMemcpyHostToDevice));
+      else
+        BBX_HIP(hipMemset(h->offset.ptr, 0, sizeof(double) * (size_t)p));
+      BBX_HIP(hipDeviceSynchronize());
+    }
     h->host_csr[0] = &x;
     h->host_csr[1] = &xt;
     const int st_b = build_tiled(h);

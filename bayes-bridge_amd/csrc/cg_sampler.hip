@@ -16,8 +16,12 @@
 //
 // The loop's scalars live in a CGState on the device; the host only enqueues
 // kernels and polls the `done` flag every few iterations.
+#include <sys/prctl.h>
+#include <time.h>
+
 #include "common.hpp"
 #include "philox.hpp"
+#include "tiled_layout.hpp"
 
 namespace bbx {
 
@@ -349,8 +353,13 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
   // where an iteration outlasts the host's launches by far, more on small
   // designs (launch-bound: the host must not wait for every test)
   static const int ahead_env = getenv("BBX_CG_AHEAD") ? atoi(getenv("BBX_CG_AHEAD")) : 0;
+  // (measured, profiles/r06_cg_word_ab.txt: 1M x 50k 103.3 / 104.6 / 105.0 us per
+  // CG iteration with AHEAD = 1 / 2 / 3, the read-back look of round 5 104.3;
+  // 100k x 10k 35.0 / 35.1 / 35.4, round 5 35.3)
+  // small designs are launch-bound: 20k x 1k 29.5 / 29.1 / 29.9 with AHEAD = 1 / 2 /
+  // 4 (round 5: 30.4), dense 6000 x 400 35.7 / 35.6 / 35.2 (r06_cg_word_small.txt)
   const int ahead = ahead_env >= 1 ? (ahead_env < 64 ? ahead_env : 64)
-                    : h->n >= 250000 ? 1 : h->n >= 50000 ? 2 : 4;
+                    : h->n >= 50000 ? 1 : h->n >= 10000 ? 2 : 4;
   int free_run = 0;
   if (h->cg_recent_n > 0) {
     free_run = h->cg_recent[0];
@@ -359,12 +368,37 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
     free_run -= 1;   // (the solve that stops AT the smallest count is common)
   }
   if (free_run > maxiter) free_run = maxiter;
+  // Between two tests the host has nothing to do.  It polls -- one core per
+  // rank -- unless host cores are scarce: with fewer than three per rank
+  // (affinity mask and cgroup quota over LOCAL_WORLD_SIZE: eight ranks on a
+  // 16-CPU quota) and iterations longer than 60 us (1M x 50k: ~100 us) it
+  // SLEEPS until 3/4 of the measured period after the last passed test and
+  // polls from there; with AHEAD = 1 the queue then still holds the rest of
+  // the running iteration (~85 us).  Measured on one rank at 1M x 50k
+  // (profiles/r06_sleep_ab.txt): 0.87 instead of 1.68 busy cores, 105.7
+  // instead of 104.4 us per CG iteration (late wake-ups) -- which is why it is
+  // not the default where cores are plentiful.  BBX_CG_SLEEP=0 | 1 forces it.
+  static const int sleep_env = getenv("BBX_CG_SLEEP") ? atoi(getenv("BBX_CG_SLEEP")) : -1;
+  static const bool sleep_on = sleep_env >= 0 ? sleep_env != 0 : cores_per_rank() < 3;
+  static thread_local bool slack_set = false;
+  if (sleep_on && !slack_set) {
+    (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);   // 1 us (default 50)
+    slack_set = true;
+  }
+  auto now_ns = []() -> int64_t {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec;
+  };
   *hword = tag;      // this solve: nothing passed yet (host store, before any launch)
   int k = 0;
   for (; k < free_run; ++k) BBX_TRY(iteration(k));
   bool done = false, bad = false;
   int n_iter = 0;
   unsigned spins = 0;
+  int seen = 0;             // tests the host has seen pass
+  int64_t t_seen = 0;       // ... and when it saw the last one
+  bool slept = false;
   while (true) {
     const unsigned long long w = *hword;
     int passed = 0;
@@ -377,11 +411,33 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
       }
       passed = (int)(w & 0xFFFFFFFFull);
     }
+    if (passed > seen) {
+      const int64_t t = now_ns();
+      if (t_seen && passed - seen <= 2) {
+        // running mean of the period between two tests (this design)
+        const int64_t per = (t - t_seen) / (passed - seen);
+        h->cg_period_ns = h->cg_period_ns ? (3 * h->cg_period_ns + per) / 4 : per;
+      }
+      seen = passed;
+      t_seen = t;
+      slept = false;
+    }
     if (k >= maxiter) break;       // exhausted: SciPy has no test after the last
     if (k < passed + ahead) {
       BBX_TRY(iteration(k));
       ++k;
       spins = 0;
+      continue;
+    }
+    if (sleep_on && !slept && t_seen && ahead == 1 && h->cg_period_ns > 60000) {
+      const int64_t until = t_seen + (h->cg_period_ns * 3) / 4;
+      if (until - now_ns() > 15000) {
+        timespec ts;
+        ts.tv_sec = until / 1000000000LL;
+        ts.tv_nsec = until % 1000000000LL;
+        (void)clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &ts, nullptr);
+      }
+      slept = true;     // (once per test: then poll)
       continue;
     }
     if (++spins > (1u << 14)) {

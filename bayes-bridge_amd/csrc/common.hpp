@@ -263,6 +263,7 @@ struct bbx_design {
   unsigned long long cg_serial = 0;   // solves so far: the word's tag
   int cg_recent[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // iteration counts of the last solves
   int cg_recent_n = 0;
+  int64_t cg_period_ns = 0;   // running mean of the time between two stop tests
   // the last solve returned with its finish kernel enqueued, not waited for:
   // `ev_poll` is recorded behind it (another stream that reads coef waits on it)
   bool coef_in_flight = false;

@@ -86,7 +86,11 @@ __device__ inline double polya_gamma_block(
   while (need) {
     const int e = __ffs(need) - 1;
     const int64_t i = base + (int64_t)e * 256 + tid;
+    // attempts 0 .. 125 have a sub-stream each; a later attempt (probability
+    // < 1e-19 per element) continues in sub-stream 126 further down its
+    // counter, 64 blocks per attempt, so that it never replays a rejection
     Philox g(seed, stream, (uint64_t)i, 1u + (att < 125u ? att : 125u));
+    if (att > 125u) g.ctr[0] += ((att - 125u) & 0x3FFFu) << 6;
     double x;
     if (PolyaGamma::trunc_inv_gauss_attempt(g, s_z[e][tid], PolyaGamma::kCut, x)) {
       s_x[e][tid] = x;

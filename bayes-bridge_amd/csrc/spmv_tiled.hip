@@ -153,6 +153,7 @@ struct HybridParts {
   // DENSE_EPI_MAX < kd <= HYB_FUSED_MAX_KD (hyb_dense_fused_kernel)
   DevMem D_rm;
   int ld_rm = 0;
+  bool fused_attr_set = false;  // the widest one-pass kernels' LDS attribute (per design, hence per device)
   DevMem addend;         // double[n]
   DevMem d_part;         // double[HYB_TDOT_CHUNKS][kd]: partial sums of D^T w
   // operator applications (bbx_design::in_operator): D^T (Omega t) partials
@@ -2241,15 +2242,14 @@ static int launch_dot_hybrid(bbx_design* h, const double* d_v,
       const int gw = ldp <= WAVE ? 1 : ldp <= 2 * WAVE ? 2 : ldp <= 4 * WAVE ? 4 : 8;
       const int nt = gw == 8 ? 512 : 1024;
       // (the widest forms hold 64 KB + of per-wave partials in dynamic LDS)
-      static bool lds_attr_set = false;
-      if (!lds_attr_set) {
+      if (!hp->fused_attr_set) {
         BBX_HIP(hipFuncSetAttribute(
             reinterpret_cast<const void*>(&hyb_dense_fused_kernel<4, 2, 1024>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
         BBX_HIP(hipFuncSetAttribute(
             reinterpret_cast<const void*>(&hyb_dense_fused_kernel<8, 1, 512>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
-        lds_attr_set = true;
+        hp->fused_attr_set = true;
       }
       const size_t lds =
           sizeof(double) * (size_t)((nt / WAVE) * 2 * WAVE * gw + 2 * (nt / WAVE));

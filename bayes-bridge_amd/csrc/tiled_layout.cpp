@@ -43,6 +43,20 @@ static int cgroup_cpu_quota() {
 // shared evenly among the local ranks (LOCAL_WORLD_SIZE of
 // torch.distributed.run), capped by `max_threads`.  BBX_BUILD_THREADS=N
 // overrides all of it (N <= 0: the machine's core count, the old behaviour).
+int cores_per_rank() {
+  int n = 0;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (n < 1) n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  const int quota = cgroup_cpu_quota();
+  if (quota > 0 && quota < n) n = quota;
+  int ranks = 1;
+  if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+  return std::max(1, n / ranks);
+}
+
 int builder_threads(int max_threads) {
   if (const char* e = getenv("BBX_BUILD_THREADS")) {
     int n = atoi(e);

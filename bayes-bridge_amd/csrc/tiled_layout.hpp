@@ -159,6 +159,9 @@ double tiled_model_cost(int64_t R, int64_t C, int64_t nnz,
 // Worker threads of the builder: affinity mask, capped by the cgroup CPU quota,
 // divided by LOCAL_WORLD_SIZE, capped by max_threads (BBX_BUILD_THREADS overrides).
 int builder_threads(int max_threads);
+// Host cores this rank can keep busy: affinity mask, capped by the cgroup CPU
+// quota, divided by LOCAL_WORLD_SIZE (what builder_threads starts from).
+int cores_per_rank();
 
 // CPU emulation of tiled_spmv_kernel's walk over the layout: every workgroup,
 // every wave's schedule, lane-private sums flushed into the panel's

@@ -443,7 +443,8 @@ def committed_traffic(design, which, cfg):
     n, P = design.shape
     rows = n if which == "dot" else P - 1
     n_wg = -(-rows // info["PR"]) * info["G"]
-    for name in ("r05_spmv_profile.json", "r04_spmv_profile.json",
+    for name in ("r06_spmv_profile.json", "r05_spmv_profile.json",
+                 "r04_spmv_profile.json",
                  "r03_spmv_traffic.json",
                  "r02_spmv_profile.json", "r01_spmv_profile.json"):
         tag = name.split("_")[0]

@@ -96,8 +96,10 @@ int bbx_builder_threads(int* count);
  * time: when the environment variable BBX_SETUP_LOCK names a lock file, the
  * constructors hold an exclusive flock on it around their device work, and a
  * host wrapper brackets its own device set-up (data generation) with this
- * pair.  The lock is process-global and RE-ENTRANT: nested acquires -- a
- * constructor called inside a bracket -- only count.  acquire returns 1 when
+ * pair.  The lock is process-global and RE-ENTRANT for the thread that holds
+ * it: nested acquires -- a constructor called inside a bracket -- only count;
+ * another thread of the same process waits until the holder's last release,
+ * and a release from a thread that does not hold it is ignored.  acquire returns 1 when
  * the lock is held afterwards (release it), 0 when BBX_SETUP_LOCK is unset or
  * the file cannot be opened (a note goes to stderr; nothing to release).
  * (No counterpart in the reference: one chain per process, one process per

@@ -277,3 +277,56 @@ def test_setup_turn_is_reentrant_inside_a_process(tmp_path):
                              capture_output=True, text=True, timeout=120)
         assert out.returncode == 0 and "DEGRADED_OK" in out.stdout, out.stderr
         assert out.stderr.count("NOT serialised") == 1, out.stderr
+
+
+def test_setup_lock_is_owned_by_a_thread(tmp_path):
+    """The depth counter belongs to the THREAD that took the lock: a second
+    thread of the same process waits until the holder's last release (it does
+    not run its device set-up beside the holder's), and its stray release
+    cannot drop the holder's flock."""
+    code = textwrap.dedent("""
+        import fcntl, os, sys, threading, time
+        sys.path.insert(0, os.path.join(%r, "bayes-bridge_amd"))
+        from bayesbridge_amd import _lib
+        lib = _lib.load()
+        path = os.environ["BBX_SETUP_LOCK"]
+        def free():
+            fh = open(path, "a+")
+            try:
+                fcntl.flock(fh, fcntl.LOCK_EX | fcntl.LOCK_NB)
+            except OSError:
+                return False
+            finally:
+                fh.close()
+            return True
+        assert lib.bbx_setup_lock_acquire() == 1       # main thread holds it
+        assert lib.bbx_setup_lock_acquire() == 1       # nested: counts
+        got = []
+        def other():
+            lib.bbx_setup_lock_release()               # not the holder: ignored
+            got.append(("stray", free()))
+            t0 = time.time()
+            assert lib.bbx_setup_lock_acquire() == 1   # waits for the holder
+            got.append(("acquired_after", time.time() - t0))
+            lib.bbx_setup_lock_release()
+        th = threading.Thread(target=other)
+        th.start()
+        time.sleep(.5)
+        assert not free() and th.is_alive()            # still ours, other waits
+        lib.bbx_setup_lock_release()
+        time.sleep(.2)
+        assert th.is_alive() and not free()            # depth 1 left
+        lib.bbx_setup_lock_release()
+        th.join(30)
+        assert not th.is_alive()
+        assert got[0] == ("stray", False), got
+        assert got[1][0] == "acquired_after" and got[1][1] > .5, got
+        assert free()
+        print("THREAD_OWNED_OK")
+    """ % ROOT)
+    env = dict(os.environ, BBX_SETUP_LOCK=str(tmp_path / "setup.lock"),
+               BBX_NO_TORCH="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "THREAD_OWNED_OK" in out.stdout, \
+        out.stdout[-2000:] + out.stderr[-2000:]

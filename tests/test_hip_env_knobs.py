@@ -71,6 +71,9 @@ CASES = [
     ('BBX_PG_ELEMS', '8', {}, BINARY, 'bitwise'),
     ('BBX_TILED_STATS', '1', {}, BINARY, 'bitwise'),
     ('BBX_BUILD_THREADS', '1', {}, BINARY, 'bitwise'),
+    ('BBX_CG_AHEAD', '1', {}, BINARY, 'bitwise'),
+    ('BBX_CG_AHEAD', '7', {}, BINARY, 'bitwise'),
+    ('BBX_CG_SLEEP', '0', {'BBX_CG_AHEAD': '1'}, BINARY, 'bitwise'),
     ('BBX_CG_FOLD', '0', {}, BINARY, 'rounding'),
     ('BBX_TILED_PR', '1024', {}, BINARY, 'rounding'),
     ('BBX_TILED_PACK', '1', {}, BINARY, 'rounding'),

@@ -91,11 +91,14 @@ def _device_series(case, seed, keep=lc.DEV_KEEP, omega_scale=None):
                                             'obs_prec'))
                 for k in rows:
                     rows[k].append(out[k][0])
-            s = {'coef': np.array(rows['coef']).T,
-                 'local_scale': np.array(rows['local_scale']).T,
+            s = {'coef': np.ascontiguousarray(np.array(rows['coef']).T),
+                 'local_scale': np.ascontiguousarray(
+                     np.array(rows['local_scale']).T),
                  'global_scale': np.array(rows['global_scale']),
                  'logp': np.array(rows['logp']),
-                 'obs_prec': np.array(rows['obs_prec']).T
+                 # (C-contiguous like the chunked path's array: NumPy's
+                 # reductions add in another order over a transposed view)
+                 'obs_prec': np.ascontiguousarray(np.array(rows['obs_prec']).T)
                  if case['family'] == 'logit'
                  else np.array(rows['obs_prec'])[:, 0]}
             bridge.prior.adjust_scale(s['global_scale'], s['local_scale'],
