@@ -121,3 +121,54 @@ def test_multichain_gathers_device_slabs_over_rccl_with_one_rank(tmp_path):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "DEVICE_GATHER_OK" in out.stdout
+
+
+TWO_RANK_WORKER = """
+import os, sys, warnings
+sys.path.insert(0, %(pkg)r)
+sys.path.insert(0, %(tests)r)
+import numpy as np
+import torch
+import torch.distributed as dist
+from bayesbridge_amd import chains
+import test_hip_chains_device as T
+warnings.simplefilter('ignore')
+rank, world, _ = chains.init_process_group_from_env()
+assert world == 2
+with chains.setup_turn():
+    bridge = T._bridge('logit')
+# five chains over two ranks: rank 0 runs chains 0, 2, 4, rank 1 chains 1, 3
+merged, infos = bridge.gibbs_multichain(
+    5, 10, n_burnin=2, thin=2, seed=300,
+    params_to_save=('coef', 'local_scale', 'global_scale', 'logp'))
+assert [i['chain'] for i in infos] == chains.split_chains(5, 2, rank)
+if rank == 0:
+    assert merged['coef'].shape == (5, bridge.n_pred, 4)
+    for k in range(5):
+        s, info = bridge.gibbs(
+            10, n_burnin=2, thin=2, seed=300 + k,
+            params_to_save=('coef', 'local_scale', 'global_scale', 'logp'))
+        for name in ('coef', 'local_scale', 'global_scale', 'logp'):
+            assert np.array_equal(merged[name][k], s[name]), (name, k)
+        assert np.array_equal(merged['n_cg_iter'][k],
+                              info['_reg_coef_sampling_info']['n_cg_iter'])
+    print('TWO_RANK_OK backend=%%s' %% dist.get_backend())
+else:
+    assert merged is None
+dist.destroy_process_group()
+"""
+
+
+def test_multichain_over_two_ranks_equals_single_chains(tmp_path):
+    """config 5's API path in miniature on the GPU box: two ranks (sharing
+    the one device, gloo; one rank per GPU over RCCL on a node) split five
+    chains, every chain's device slab goes into the gather, and rank 0 holds
+    bit for bit what bridge.gibbs returns seed by seed."""
+    from bayesbridge_amd import chains
+    script = tmp_path / "worker.py"
+    script.write_text(TWO_RANK_WORKER % {
+        "pkg": os.path.join(ROOT, "bayes-bridge_amd"),
+        "tests": os.path.join(ROOT, "tests")})
+    out = chains.launch_ranks(2, [str(script)], capture=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "TWO_RANK_OK" in out.stdout
