@@ -87,7 +87,7 @@ def _declare(lib):
         "bbx_design_fused_operator_bytes": ([hp, POINTER(c_int64)], c_int),
         "bbx_design_cg_launches": ([hp, POINTER(c_int)], c_int),
         "bbx_design_cg_stats": ([hp, POINTER(c_int64), POINTER(c_int64),
-                                 c_int], c_int),
+                                 POINTER(c_int64), c_int], c_int),
         "bbx_launch_count": ([], c_uint64),
         "bbx_design_set_cg_fold": ([hp, c_int], c_int),
         "bbx_design_hybrid_info": (

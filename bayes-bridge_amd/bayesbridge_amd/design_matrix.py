@@ -142,13 +142,14 @@ class HipDesignMatrix():
         return int(v.value)
 
     def cg_stats(self, reset=False):
-        """(CG solves, launches they enqueued past their stopping iteration)
-        on this design since creation / the last reset."""
+        """(CG solves, launches they enqueued past their stopping iteration,
+        naps of the host between two stop tests) on this design since
+        creation / the last reset."""
         from ctypes import c_int64
-        a, b = c_int64(), c_int64()
-        _lib.check(self._lib.bbx_design_cg_stats(self._h, byref(a), byref(b),
-                                                 1 if reset else 0))
-        return int(a.value), int(b.value)
+        a, b, c = c_int64(), c_int64(), c_int64()
+        _lib.check(self._lib.bbx_design_cg_stats(
+            self._h, byref(a), byref(b), byref(c), 1 if reset else 0))
+        return int(a.value), int(b.value), int(c.value)
 
     def set_cg_fold(self, on):
         """Direction step of the CG loop inside the X~ v kernel (3 launches per

@@ -1243,11 +1243,12 @@ uint64_t bbx_launch_count(void) {
 }
 
 int bbx_design_cg_stats(bbx_design* h, int64_t* solves, int64_t* empty_launches,
-                        int reset) {
+                        int64_t* naps, int reset) {
   BBX_TRY(check_handle(h));
   if (solves) *solves = h->cg_solves;
   if (empty_launches) *empty_launches = h->cg_empty_launches;
-  if (reset) h->cg_solves = h->cg_empty_launches = 0;
+  if (naps) *naps = h->cg_naps;
+  if (reset) h->cg_solves = h->cg_empty_launches = h->cg_naps = 0;
   return BBX_OK;
 }
 

@@ -436,6 +436,7 @@ int cg_sample_device(bbx_design* h, const double* d_omega, const double* d_phi,
         ts.tv_sec = until / 1000000000LL;
         ts.tv_nsec = until % 1000000000LL;
         (void)clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &ts, nullptr);
+        h->cg_naps += 1;
       }
       slept = true;     // (once per test: then poll)
       continue;

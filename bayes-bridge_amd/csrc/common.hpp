@@ -268,7 +268,7 @@ struct bbx_design {
   // `ev_poll` is recorded behind it (another stream that reads coef waits on it)
   bool coef_in_flight = false;
   // what the last solve enqueued past its stopping iteration (bench.py)
-  int64_t cg_empty_launches = 0, cg_solves = 0;
+  int64_t cg_empty_launches = 0, cg_solves = 0, cg_naps = 0;
   // Set around the dot + Tdot of ONE operator application (apply_operator,
   // gram_matvec): the Tdot's input is the dot's scaled output, so a mixed
   // design's dense block can ride in the dot kernel's epilogue for both

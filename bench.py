@@ -633,7 +633,7 @@ def main():
     t_run = time.perf_counter()
     own_cpu = time.process_time() - cpu0
     launches = (lib.bbx_launch_count() - launches0) if has_stats else None
-    cg_solves, cg_empty = design.cg_stats() if has_stats else (0, 0)
+    cg_solves, cg_empty, cg_naps = design.cg_stats() if has_stats else (0, 0, 0)
     gathered = chains.gather_chain_samples(d_coef, dst=0)
     if grouped:
         torch.cuda.synchronize()
@@ -653,6 +653,10 @@ def main():
         launches_per_sec=round(launches / own_run, 0)
         if launches is not None and own_run > 0 else None,
         empty_launches_per_draw=round(cg_empty / max(cg_solves, 1), 2)
+        if has_stats else None,
+        # > 0: the host slept between stop tests (fewer than three cores
+        # per rank, or BBX_CG_SLEEP=1) instead of polling
+        naps_per_draw=round(cg_naps / max(cg_solves, 1), 1)
         if has_stats else None)
     elapsed = chains.max_over_ranks(elapsed)
     progress("timed region done (%.3f s)" % elapsed)

@@ -228,10 +228,12 @@ int bbx_design_cg_launches(const bbx_design* h, int* per_iteration);
  * products; here the host only enqueues, runs ahead of the device's stop test
  * and reads its outcome from a host-mapped progress word): CG solves on this
  * design since creation / the last reset, and the kernel launches they enqueued
- * past their stopping iteration (such kernels return at entry, ~2 us each).
- * reset != 0 zeroes both after reading.  Output pointers may be NULL. */
+ * past their stopping iteration (such kernels return at entry, ~2 us each);
+ * `naps`: how often the host slept between two stop tests instead of polling
+ * (only with fewer than three host cores per rank, or BBX_CG_SLEEP=1).
+ * reset != 0 zeroes all after reading.  Output pointers may be NULL. */
 int bbx_design_cg_stats(bbx_design* h, int64_t* solves, int64_t* empty_launches,
-                        int reset);
+                        int64_t* naps, int reset);
 /* Kernel launches this process has made through the library, all designs and
  * chains (a diagnostic: launches per second and rank is what the host side of
  * an N-rank node has to sustain; the reference launches nothing). */

@@ -25,15 +25,16 @@ _cache = {}
 
 
 def _run(tmp_path_factory, env, family='logit', n=4000, p=300, iters=4,
-         binary_frac=.8):
-    key = (tuple(sorted(env.items())), family, n, p, iters, binary_frac)
+         binary_frac=.8, freq=.1):
+    key = (tuple(sorted(env.items())), family, n, p, iters, binary_frac, freq)
     if key in _cache:
         return _cache[key]
     out = str(tmp_path_factory.mktemp("knob") / "chain.npz")
-    full = dict(os.environ, BBX_NO_TORCH="1", **env)
+    full = dict(os.environ, BBX_NO_TORCH="1")
+    full.update(env)
     run = subprocess.run(
         [sys.executable, os.path.join(ROOT, "scripts", "chain_variant_run.py"),
-         out, family, str(n), str(p), str(iters), str(binary_frac)],
+         out, family, str(n), str(p), str(iters), str(binary_frac), str(freq)],
         env=full, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     _cache[key] = (dict(np.load(out)), run.stdout)
@@ -106,3 +107,24 @@ def test_one_lane_polya_gamma_kernel_of_rounds_1_to_4_still_runs(
     assert np.all(np.isfinite(old['logp'])) and np.all(old['obs_prec'] > 0)
     assert abs(old['n_cg_iter'].mean() - base['n_cg_iter'].mean()) < 6
     assert abs(old['obs_prec'].mean() / base['obs_prec'].mean() - 1) < .02
+
+
+def test_host_sleeping_between_stop_tests_changes_no_bit(tmp_path_factory):
+    """BBX_CG_SLEEP=1 (what a rank does by itself with fewer than three host
+    cores): on a design whose CG iteration outlasts 60 us -- 1M x 2000, ~8e7
+    entries -- the host sleeps through three quarters of every iteration
+    instead of polling the progress word.  Same samples bit for bit, same
+    stopping iterations; three launches enqueued in vain per draw either way."""
+    big = dict(n=1000000, p=2000, iters=3, binary_frac=1., freq=.04)
+    # (the design is generated in HBM with torch: no BBX_NO_TORCH here)
+    poll, log_p = _run(tmp_path_factory, {'BBX_CG_SLEEP': '0',
+                                          'BBX_NO_TORCH': '0'}, **big)
+    nap, log_n = _run(tmp_path_factory, {'BBX_CG_SLEEP': '1',
+                                         'BBX_NO_TORCH': '0'}, **big)
+    _bitwise(nap, poll, 'BBX_CG_SLEEP')
+    assert "cg launches 4" in log_p and "format tiled" in log_p
+    # the path under test was taken: several naps per solve, none when polling
+    assert "naps 0" in log_p
+    naps = int(log_n.split("naps")[1].split()[0])
+    assert naps >= 3 * 5, log_n
+    assert poll['n_cg_iter'].min() >= 5
