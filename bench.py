@@ -70,6 +70,12 @@ def parse_args(argv=None):
                          "iteration is ~110 operator applications of two "
                          "12.8 GB dgemv each)")
     ap.add_argument("--seed", type=int, default=111)
+    ap.add_argument("--live-traffic", type=int, default=1, choices=[0, 1],
+                    help="rank 0 at N = 1, sparse configs 2 / 3: measure "
+                         "`roofline.traffic` in this run by two rocprofv3 --pmc "
+                         "child passes over the product kernels (adds ~40 s "
+                         "after the timed region); 0: the committed profile's "
+                         "figure")
     ap.add_argument("--dense-storage", default="float32",
                     choices=["float32", "float64"],
                     help="config4 only: storage type of the dense matrix "
@@ -461,6 +467,64 @@ def committed_traffic(design, which, cfg):
     return None, None
 
 
+def live_traffic(cfg, n_wg, reps=6, timeout=200):
+    """HBM bytes per launch of the dominant kernel MEASURED in this run: two
+    `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE: separate passes, the
+    program itself after `--`, never combined with tracing) over
+    scripts/bench_spmv.py -- the same generator, seed and layout builder, hence
+    the same matrix, layout and launch grids as the chain above; the product
+    kernels alone -- as CHILD processes of this one, after the timed region.
+    bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB; MI355X_MICROARCH.md, HBM: on
+    gfx950 FETCH_SIZE reports half the bytes of a 16-byte-per-lane stream).
+    Returns (bytes, source) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    got = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="bbx_pmc_", dir="/tmp")
+        try:
+            run = subprocess.run(
+                [exe, "--pmc", counter, "--output-format", "csv", "-d", out,
+                 "--", sys.executable,
+                 os.path.join(ROOT, "scripts", "bench_spmv.py"), cfg, "tiled",
+                 str(reps)],
+                cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                capture_output=True, text=True, timeout=timeout)
+            vals = []
+            for path in glob.glob(os.path.join(out, "**",
+                                               "*counter_collection.csv"),
+                                  recursive=True):
+                with open(path, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if "tiled_spmv" in row.get("Kernel_Name", "") \
+                                and row.get("Counter_Name") == counter \
+                                and int(row["Grid_Size"]) // 1024 == n_wg:
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "rocprofv3 --pmc %s: no launch of grid %d seen " \
+                    "(rc %d: %s)" % (counter, n_wg, run.returncode,
+                                     (run.stderr or "")[-200:])
+            got[counter] = sum(vals) / len(vals)
+        except Exception as exc:      # noqa: BLE001 (never costs the line)
+            return None, "rocprofv3 --pmc %s failed: %s" % (counter, exc)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    total = 1024. * (2. * got["FETCH_SIZE"] + got["WRITE_SIZE"])
+    return int(total), (
+        "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two "
+        "child passes over scripts/bench_spmv.py %s tiled (the product kernel "
+        "alone on the same matrix and layout, %d launches of grid %d each; "
+        "2 x FETCH_SIZE + WRITE_SIZE; %.0f s)"
+        % (cfg, len(vals), n_wg, time.perf_counter() - t0))
+
+
 def main():
     t_proc = time.perf_counter()
     args = parse_args()
@@ -762,6 +826,18 @@ def main():
         useful_gbs = useful_b / per[dom]["avg_ms"] / 1e6 \
             if per[dom]["avg_ms"] > 0 else 0.
         traffic, traffic_src = committed_traffic(design, dom, args.config)
+        traffic_committed = traffic
+        if solo and args.live_traffic and not dense \
+                and design.storage_format == "tiled" \
+                and args.config in ("config2", "config3") \
+                and args.seed == 111 and args.storage in ("auto", "tiled"):
+            info_dom = design.tiled_info()["X" if dom == "dot" else "Xt"]
+            live, live_src = live_traffic(args.config, int(info_dom["grid"]))
+            if live is not None:
+                traffic, traffic_src = live, live_src
+            else:
+                traffic_src = "%s; live measurement skipped: %s" % (
+                    traffic_src, live_src)
         # whole operator application (dot + Tdot + epilogue kernel)
         op_cnt, op_ms = timing["operator"]
         op_avg = op_ms / max(op_cnt, 1)
@@ -802,6 +878,7 @@ def main():
             bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
             unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
             traffic_source=traffic_src,
+            traffic_committed_profile=traffic_committed,
             kernel=kernel_name,
             avg_launch_ms=round(per[dom]["avg_ms"], 5),
             algorithmic_bytes_per_launch=per[dom]["bytes"],

@@ -54,6 +54,26 @@ def test_single_gpu_line_has_roofline_and_both_cpu_baselines():
     assert line["config"]["startup_s"] > 0 and line["config"]["peak_host_rss_mb"] > 0
 
 
+def test_roofline_traffic_is_measured_in_the_run():
+    """`roofline.traffic` of the sparse BASELINE configs comes from two
+    rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that bench.py runs
+    itself after the timed region, over the product kernels on the same matrix
+    and layout -- not from a committed profile.  Config 2: the launch's HBM
+    bytes within 10 % of its algorithmic bytes (part of the 26 MB is served by
+    the Infinity Cache)."""
+    line = _bench("--config", "config2", "--steps", "20", "--warmup", "5",
+                  "--burnin", "30", "--cpu-baseline-iters", "0",
+                  "--multi-chain", "0", "--repeat", "1")
+    r = line["roofline"]
+    assert r["traffic_source"].startswith("measured in this run"), \
+        r["traffic_source"]
+    assert .85 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.15
+    off = _bench("--config", "config2", "--steps", "5", "--warmup", "2",
+                 "--burnin", "5", "--cpu-baseline-iters", "0",
+                 "--multi-chain", "0", "--repeat", "1", "--live-traffic", "0")
+    assert off["roofline"]["traffic"] is None      # no committed config-2 profile
+
+
 def test_dense_line_has_a_cpu_baseline():
     """config 4's shape in miniature: the dense line carries `cpu_baseline`
     (NumPy dgemv products + SciPy cg, BLAS threads stated), like the sparse
