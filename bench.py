@@ -485,6 +485,15 @@ def live_traffic(cfg, n_wg, reps=6, timeout=200):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    # (this process itself under a profiler: its preloaded tool library would
+    # be inherited by the child passes)
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) \
+            or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "bench.py runs under a profiler itself"
+    child_env = {k: v for k, v in os.environ.items()
+                 if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK",
+                              "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    child_env["TMPDIR"] = "/tmp"
     got = {}
     t0 = time.perf_counter()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -495,7 +504,7 @@ def live_traffic(cfg, n_wg, reps=6, timeout=200):
                  "--", sys.executable,
                  os.path.join(ROOT, "scripts", "bench_spmv.py"), cfg, "tiled",
                  str(reps)],
-                cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                cwd="/tmp", env=child_env,
                 capture_output=True, text=True, timeout=timeout)
             vals = []
             for path in glob.glob(os.path.join(out, "**",
