@@ -43,4 +43,8 @@ same = all(np.array_equal(runs[0][k], runs[1][k]) for k in runs[0])
 print("%s: two runs of %d iterations %s" % (
     what, N, "agree bit for bit (coef, local_scale, global_scale, logp, n_cg)"
     if same else "DIFFER"))
+if os.environ.get("BBX_SOAK_SAVE"):
+    # (scripts/r06_soak.sh compares the samples ACROSS host-side variants)
+    np.savez(os.environ["BBX_SOAK_SAVE"], **{
+        k: (v[::50] if v.ndim > 1 else v) for k, v in runs[0].items()})
 sys.exit(0 if same else 1)
