@@ -2,6 +2,8 @@
 # A/B of the CG loop's host side (round 6): the look through hipMemcpyAsync +
 # event wait of rounds 2-5 (package built from the round-5 HEAD under ab_base/)
 # against the host-mapped progress word, at BBX_CG_AHEAD = 1, 2, 3.
+#   (before: rm -rf ab_base && mkdir ab_base && git archive ef6ce49 bayes-bridge_amd include | tar -x -C ab_base
+#    && make -C ab_base/bayes-bridge_amd/csrc -j8; ab_base/ is not kept in the tree)
 #   bash scripts/r06_cg_word_ab.sh > gpurun_out/r06_cg_word_ab.txt
 pick='import json,sys
 d=json.loads(sys.stdin.readline())
