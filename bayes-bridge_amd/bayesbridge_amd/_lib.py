@@ -147,6 +147,7 @@ def _declare(lib):
         "bbx_chain_run": (
             [hp, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
              c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+        "bbx_chain_set_progress": ([hp, c_int, c_void_p, c_void_p], c_int),
         "bbx_chain_run_host": (
             [hp, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
              c_void_p, c_void_p, c_void_p, c_void_p], c_int),

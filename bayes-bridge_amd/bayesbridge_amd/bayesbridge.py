@@ -182,7 +182,7 @@ class BayesBridge():
         else:
             out = self._gibbs_device(
                 n_iter, n_burnin, thin, seed, init, params_to_save, options,
-                _resume_from, _device_out)
+                _resume_from, _device_out, n_status_update)
         samples, mcmc_info = self._package(
             out, n_iter, n_burnin, thin, seed, params_to_save, options,
             time.time() - start_time)
@@ -639,7 +639,8 @@ class BayesBridge():
         self._chain_seed = seed
 
     def _gibbs_device(self, n_iter, n_burnin, thin, seed, init,
-                      params_to_save, options, resume_from, device_out=None):
+                      params_to_save, options, resume_from, device_out=None,
+                      n_status_update=0):
         model, prior = self.model, self.prior
         bridge_exp = prior.bridge_exp
         if resume_from is not None:
@@ -656,6 +657,21 @@ class BayesBridge():
         chain = self._chain
         init_used, optim_info = self._device_setup(chain, seed, init, options,
                                                    resume_from)
+        # status lines as the reference prints them (gibbs_util.py:214-238),
+        # from the library's host loop through a callback
+        n_status_update = min(n_iter, int(n_status_update or 0))
+        if n_status_update > 0:
+            stamp = [time.time()]
+
+            def report(mcmc_iter):
+                now = time.time()
+                print("{:d} Gibbs iterations complete: {:.3g} minutes has "
+                      "elasped since the last update.".format(
+                          mcmc_iter, (now - stamp[0]) / 60))
+                stamp[0] = now
+            chain.set_progress(int(n_iter / n_status_update), report)
+        else:
+            chain.set_progress(0)
         device_out = dict(device_out or {})
         host_params = tuple(k for k in params_to_save if k not in device_out)
         samples, _ = self._pre_allocate(n_iter - n_burnin, thin, host_params)

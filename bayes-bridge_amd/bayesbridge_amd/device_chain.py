@@ -159,6 +159,21 @@ class HipGibbsChain():
                                            _ptr(e2)))
         return e1, e2
 
+    def set_progress(self, every, fn=None):
+        """fn(iteration) is called every `every` iterations of run() /
+        run_device() (BayesBridge.gibbs(n_status_update=...)); every = 0 or
+        fn = None switches it off."""
+        import ctypes
+        if fn is None or not every:
+            self._progress_cb = None
+            _lib.check(self._lib.bbx_chain_set_progress(self._c, 0, None, None))
+            return
+        proto = ctypes.CFUNCTYPE(None, ctypes.c_int, c_void_p)
+        self._progress_cb = proto(lambda it, _ctx: fn(int(it)))   # kept alive
+        _lib.check(self._lib.bbx_chain_set_progress(
+            self._c, int(every), ctypes.cast(self._progress_cb, c_void_p),
+            None))
+
     def logp(self):
         """(log-likelihood, log-posterior) left by the last iteration."""
         ll, lp = c_double(), c_double()

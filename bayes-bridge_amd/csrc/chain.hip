@@ -1237,12 +1237,27 @@ static int bbx_chain_run_impl(bbx_chain* c, int n_iter, int n_burnin, int thin,
     int info = chain_step(c, maxiter, atol, &ncg);
     if (info < 0) return info;
     if (info > 0) ++n_unconverged;
-    if (!kept) continue;
-    BBX_TRY(chain_save_sample(c, idx, d_coef, d_lscale, d_obs_prec));
-    if (n_cg_iter) n_cg_iter[idx] = (double)ncg;
+    if (kept) {
+      BBX_TRY(chain_save_sample(c, idx, d_coef, d_lscale, d_obs_prec));
+      if (n_cg_iter) n_cg_iter[idx] = (double)ncg;
+    }
+    // (the draw of iteration `it` is complete on the host's side of the
+    // queue: the CG loop has seen its stop test fire)
+    if (c->progress && c->progress_every > 0 && it % c->progress_every == 0)
+      c->progress(it, c->progress_ctx);
   }
   BBX_TRY(chain_end_run(c, n_sample, gscale, logp));
   return n_unconverged;
+}
+
+int bbx_chain_set_progress(bbx_chain* c, int every, void (*fn)(int, void*),
+                           void* ctx) {
+  BBX_TRY(chain_check(c));
+  if (every < 0) return fail(BBX_ERR_INVALID, "every must be >= 0");
+  c->progress = (every > 0) ? fn : nullptr;
+  c->progress_ctx = ctx;
+  c->progress_every = fn ? every : 0;
+  return BBX_OK;
 }
 
 int bbx_chain_run(bbx_chain* c, int n_iter, int n_burnin, int thin,

@@ -39,6 +39,11 @@ struct bbx_chain {
   int64_t n_averaged = 0;  // summariser count
   bool mean_zero = true;   // running mean still all zeros => CG warm start 0
   int gscale_update = BBX_GSCALE_SAMPLE;
+  // bbx_chain_set_progress: called from the host loop of a run every
+  // `progress_every` iterations (gibbs_util.py:214-238 prints from there)
+  void (*progress)(int, void*) = nullptr;
+  void* progress_ctx = nullptr;
+  int progress_every = 0;
   bbx::DevMem outcome, n_trial, kappa;  // n
   bbx::DevMem zbase;                    // P: X~^T kappa (logit) or X~^T y
   bbx::DevMem coef, phi, x0, sd, z, mean, square, sd_unshrunk;  // P-length

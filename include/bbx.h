@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* 103: + bbx_design_cg_stats (solves and launches enqueued past the stopping
- *      iteration since the last reset), bbx_launch_count.
+ *      iteration since the last reset), bbx_launch_count, bbx_chain_set_progress.
  * 102: + bbx_design_create_csr64 (64-bit index arrays, 2^31 or more entries).
  * 101: bbx_design_tiled_info takes nine pointers (`packed`, since round 4),
  *      bbx_setup_lock_acquire/_release, bbx_design_useful_bytes.  A binding
@@ -486,6 +486,13 @@ int bbx_chain_run(bbx_chain* c, int n_iter, int n_burnin, int thin,
                   int maxiter, double atol, double* d_coef, double* d_lscale,
                   double* d_obs_prec, double* gscale, double* logp,
                   double* n_cg_iter);
+/* Progress of a run (BayesBridge.gibbs(n_status_update=...), gibbs_util.py:
+ * 214-238 prints "<k> Gibbs iterations complete: ..."): fn(iteration, ctx) is
+ * called on the calling thread every `every` iterations of bbx_chain_run[_host],
+ * after the coefficient draw of that iteration has been confirmed; every = 0
+ * or fn = NULL switches it off.  The callback must not call back into the chain. */
+int bbx_chain_set_progress(bbx_chain* c, int every, void (*fn)(int, void*),
+                           void* ctx);
 /* Same with HOST sample buffers for coef/lscale/obs_prec (copied at the end). */
 int bbx_chain_run_host(bbx_chain* c, int n_iter, int n_burnin, int thin,
                        int maxiter, double atol, double* coef, double* lscale,

@@ -351,3 +351,32 @@ def test_automatic_two_stream_choice_matches_one_stream(tmp_path):
     for key in ('coef', 'local_scale', 'obs_prec', 'global_scale', 'logp',
                 'n_cg_iter'):
         assert np.array_equal(auto[key], one[key]), key
+
+
+def test_status_updates_are_printed_in_the_device_mode_too(capsys):
+    """gibbs(n_status_update=k) prints the reference's k status lines
+    (gibbs_util.py:214-238) in the default device-RNG mode as well -- from the
+    library's host loop through bbx_chain_set_progress -- and printing changes
+    no sample."""
+    from bayesbridge_amd import BayesBridge, RegressionCoefPrior, \
+        RegressionModel
+    X, y, _ = _problem(n=1500, p=40, seed=2)
+    prior = RegressionCoefPrior(bridge_exponent=.5, regularizing_slab_size=2.)
+    init = {'global_scale': .05, 'coef': np.zeros(X.shape[1] + 1)}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bridge = BayesBridge(RegressionModel(y, X, 'logit'), prior)
+        capsys.readouterr()
+        quiet, _ = bridge.gibbs(12, init=dict(init), seed=4)
+        assert "iterations complete" not in capsys.readouterr().out
+        loud, _ = bridge.gibbs(12, init=dict(init), seed=4, n_status_update=3)
+    out = capsys.readouterr().out
+    lines = [ln for ln in out.splitlines() if "Gibbs iterations complete" in ln]
+    assert [int(ln.split()[0]) for ln in lines] == [4, 8, 12], out
+    assert all("has elasped since the last update." in ln for ln in lines)
+    assert np.array_equal(quiet['coef'], loud['coef'])
+    # more updates than iterations: one line per iteration, as the reference
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        bridge.gibbs(3, init=dict(init), seed=4, n_status_update=10)
+    assert capsys.readouterr().out.count("iterations complete") == 3
