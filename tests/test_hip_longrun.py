@@ -55,13 +55,17 @@ def _bridge(case):
     return BayesBridge(model, RegressionCoefPrior(**case['prior_kw']))
 
 
-def _device_series(case, seed, keep=lc.DEV_KEEP, omega_scale=None):
+def _device_series(case, seed, keep=lc.DEV_KEEP, omega_scale=None,
+                   lambda_scale=None):
     """Per-iteration statistics [keep, K] of one device-RNG chain through
     BayesBridge.gibbs / gibbs_resume (the default mode), in chunks so that
     the n x T array of Omega samples never exists at once.  omega_scale: the
     negative control -- the chain is stepped one iteration at a time and
     Omega (the scalar noise precision for the linear model) is multiplied by
-    it between the Polya-Gamma draw and the next coefficient draw."""
+    it between the Polya-Gamma draw and the next coefficient draw
+    (lambda_scale: the local scales likewise)."""
+    if lambda_scale is not None and omega_scale is None:
+        omega_scale = 1.
     bridge = _bridge(case)
     parts, n_cg = [], []
     with warnings.catch_warnings():
@@ -85,8 +89,10 @@ def _device_series(case, seed, keep=lc.DEV_KEEP, omega_scale=None):
             rows = {k: [] for k in ('coef', 'local_scale', 'obs_prec',
                                     'global_scale', 'logp')}
             for _ in range(keep):
-                coef, obs, _, _ = chain.get_state()
+                coef, obs, ls, _ = chain.get_state()
                 chain.set_state(obs_prec=np.asarray(obs) * omega_scale)
+                if lambda_scale is not None:
+                    chain.set_state(local_scale=ls * lambda_scale)
                 out, _ = chain.run(1, save=('coef', 'local_scale',
                                             'obs_prec'))
                 for k in rows:
@@ -166,6 +172,23 @@ def test_negative_control_omega_scaled_by_5_percent_fails(golden_dir):
     assert np.abs(zm).max() > 2 * lc.Z_MAX, report
     assert (np.abs(zm) > lc.Z_MAX).sum() >= 5, report
     assert np.sqrt((zm ** 2).mean()) > 1.5, report
+
+
+def test_negative_control_local_scales_scaled_by_5_percent_fails(golden_dir):
+    """... and likewise when every lambda_j is 5 % too large by the time the
+    coefficient draw reads it (8 000 iterations suffice: the coefficients are
+    shrunk less, the full-length run shows |z| = 33 and 98 statistics beyond
+    the bound, profiles/r06_longrun_power.txt)."""
+    name = 'logit_mixed_ntrial'
+    case = lc.make_case(name)
+    ref = _fixture(golden_dir, name, case)
+    S, _, _ = _device_series(case, seed=20261, keep=8000, lambda_scale=1.05)
+    zm, zv, report = _compare(name + ' [lambda x 1.05]', lc.batch_stats([S]),
+                              ref, lc.series_names(case))
+    print(report)
+    assert max(np.abs(zm).max(), np.abs(zv).max()) > 2 * lc.Z_MAX, report
+    assert (np.abs(zm) > lc.Z_MAX).sum() + (np.abs(zv) > lc.Z_MAX).sum() >= 5, \
+        report
 
 
 def test_negative_control_passes_unscaled(golden_dir):
